@@ -1,0 +1,157 @@
+"""Generate tests/golden/*.npz by executing the REAL reference (build container only).
+
+    python -m oracle.make_golden            # from the repo root; needs /root/reference
+
+The reference holds no tests or golden vectors; these fixtures are the pin:
+outputs of the reference's own modules (``SynthesizerInfer``, ``Whisper.encoder``, ``svc_infer``) on
+seeded weights/inputs with the stochastic draws injected (oracle/ref_import.py).  The script also
+asserts that the oracle restatement agrees with the reference on every fixture before writing it.
+Weights are never stored: they are regenerated from their seed (oracle/weights.py); a checksum of
+the regenerated tensors is stored so RNG drift is detected instead of mis-reported as a parity bug.
+"""
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+from . import config as C
+from . import inputs as I
+from . import ref_import as R
+from . import svc_oracle as O
+from . import weights as W
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+TOL = 5e-5
+
+
+def checksum(tensors):
+    """Order-independent fp64 digest of a dict/list of tensors."""
+    if isinstance(tensors, dict):
+        tensors = [tensors[k] for k in sorted(tensors)]
+    return float(sum(t.double().abs().sum().item() + 0.5 * t.double().sum().item() for t in tensors))
+
+
+def _agree(name, a, b, tol=TOL):
+    err = (a - b).abs().max().item()
+    print(f"  oracle vs reference [{name}]: max-abs {err:.3e}")
+    assert err <= tol, (name, err)
+
+
+def vits_fixture(tag, hp, T, B, lengths=None, store_inputs=False, seed=1):
+    print(f"[{tag}] T={T} B={B}")
+    sd = W.make_vits_state(hp, seed=1234)
+    ref = R.ref_synthesizer(hp, sd)
+    d = I.synth_clip(T=T, hp=hp, seed=seed, B=B)
+    lens = d["lengths"] if lengths is None else torch.tensor(lengths, dtype=torch.long)
+    from vits.utils import f0_to_coarse
+    with torch.no_grad():
+        with R.injected_noise([d["src_noise"]], [d["rand_ini"]]):
+            src = ref.pitch2source(d["pit"])
+        with R.injected_noise([d["enc_noise"]]):
+            z_p, m_p, logs_p, mask, _ = ref.enc_p(d["ppg"], lens, d["vec"], f0=f0_to_coarse(d["pit"]))
+        z, _ = ref.flow(z_p, mask, g=d["spk"], reverse=True)
+        with R.injected_noise([d["enc_noise"]]):
+            wav = ref.inference(d["ppg"], d["vec"], d["pit"], d["spk"], lens, src)
+        pitwav = ref.source2wav(src[:1])
+        o_src = O.pitch2source(sd, hp, d["pit"], d["rand_ini"], d["src_noise"])
+        o_wav, parts = O.synth_inference(sd, hp, d["ppg"], d["vec"], d["pit"], d["spk"], lens, o_src,
+                                         d["enc_noise"], return_parts=True)
+    _agree("source", o_src, src, 1e-6)
+    _agree("z_p", parts["z_p"], z_p)
+    _agree("z", parts["z"], z)
+    _agree("wave", o_wav, wav)
+    out = {
+        "T": T, "B": B, "seed": seed, "lengths": lens.numpy(),
+        "weights_checksum": checksum(sd), "inputs_checksum": checksum({k: v for k, v in d.items()}),
+        "source": src.numpy(), "z_p": z_p.numpy(), "z": z.numpy(), "wave": wav.numpy(),
+        "pitwav": pitwav, "f0_coarse": f0_to_coarse(d["pit"]).numpy(),
+    }
+    if store_inputs:
+        for k, v in d.items():
+            out["in_" + k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), **out)
+
+
+def whisper_fixture(tag, dims, n, store_all=True):
+    print(f"[{tag}] n_mel_frames={n}")
+    ck = W.make_whisper_state(dims)
+    ref = R.ref_whisper_encoder(ck)
+    g = torch.Generator().manual_seed(5)
+    mel = (torch.randn(1, 80, n, generator=g) * 0.5).clamp(-1.0, 1.5)
+    nz = torch.randn(1, 80, n, generator=g)
+    with torch.no_grad():
+        # whisper/inference.py:46-47: mel + randn_like(mel)*0.1 then encoder
+        with R.injected_noise([nz[0]]):
+            m = mel[0] + torch.randn_like(mel[0]) * 0.1
+        ppg = ref.encoder(m.unsqueeze(0))
+        o = O.audio_encoder(ck["model_state_dict"], (mel + 0.1 * nz), dims["n_audio_head"], O.whisper_kept_layers(dims))
+    _agree("ppg", o, ppg)
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), n=n, mel=mel.numpy(), mel_noise=nz.numpy(),
+                        ppg=ppg.numpy(), weights_checksum=checksum(ck["model_state_dict"]))
+
+
+def _import_ref_driver():
+    """Import the reference's svc_inference.py with its unavailable third-party imports stubbed
+    (omegaconf, faiss, the crepe-based pitch package); the code under test -- svc_infer, lines
+    77-134 -- touches none of them."""
+    R._prepare()
+    for name, attrs in (("omegaconf", {"OmegaConf": object}), ("faiss", {"IndexIVF": object, "Index": object}),
+                        ("pitch", {"load_csv_pitch": None})):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            for k, v in attrs.items():
+                setattr(m, k, v)
+            sys.modules[name] = m
+    import svc_inference
+    return svc_inference
+
+
+def svc_infer_fixture(tag, hp, T):
+    """Two-chunk run through the reference's own host loop (chunk 2500 + halo 10, svc_inference.py:94-131)."""
+    print(f"[{tag}] T={T}")
+    drv = _import_ref_driver()
+    from feature_retrieval import DummyRetrieval
+    sd = W.make_vits_state(hp, seed=1234)
+    ref = R.ref_synthesizer(hp, sd)
+    d = I.synth_clip(T=T, hp=hp, seed=2, B=1)
+    plan = O.chunk_schedule(T, hp.data.hop_length)
+    g = torch.Generator().manual_seed(77)
+    enc_noises = [torch.randn(1, hp.vits.inter_channels, ce - cs, generator=g) for (cs, ce, _, _) in plan]
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            with R.injected_noise([d["src_noise"]] + enc_noises, [d["rand_ini"]]):
+                wav = drv.svc_infer(ref, DummyRetrieval(), d["spk"][0], d["pit"][0], d["ppg"][0], d["vec"][0], hp, "cpu")
+        finally:
+            os.chdir(cwd)
+    with torch.no_grad():
+        o_wav, o_pit = O.svc_infer(sd, hp, d["spk"][0], d["pit"][0], d["ppg"][0], d["vec"][0],
+                                   d["rand_ini"], d["src_noise"], enc_noises)
+    _agree("svc_infer wave", torch.from_numpy(o_wav), torch.from_numpy(wav))
+    L = T * hp.data.hop_length
+    assert wav.shape[0] == L - 1, wav.shape            # cut_e_out = -1 drops the last sample (:112,129)
+    seam = C.CHUNK_FRAMES * hp.data.hop_length
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), T=T, length=wav.shape[0], plan=np.array(plan),
+                        wave_sub=wav[::97].copy(), wave_seam=wav[seam - 3000:seam + 3000].copy(),
+                        wave_tail=wav[-2000:].copy(),
+                        weights_checksum=checksum(sd), inputs_checksum=checksum(d))
+
+
+def main():
+    assert R.available(), "needs /root/reference"
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    vits_fixture("vits_tiny_ragged", C.tiny_hp(), T=24, B=2, lengths=[24, 17], store_inputs=True)
+    vits_fixture("vits_base_T60", C.base_hp(), T=60, B=1)
+    whisper_fixture("whisper_tiny", C.WHISPER_TINY_TEST, n=301)
+    whisper_fixture("whisper_large_v2_n200", C.WHISPER_LARGE_V2, n=200)
+    svc_infer_fixture("svc_infer_tiny_2chunks", C.tiny_hp(), T=2600)
+    print("golden fixtures written to", OUT)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,189 @@
+"""Seeded synthetic checkpoints with the reference's key names (test infrastructure).
+
+No pretrained weights ship with the reference, so parity runs on
+random-but-seeded tensors.  Key names and shapes follow ``SynthesizerInfer.state_dict()``
+(903 tensors at base.yaml; layout documented in SURVEY.md appendix A.2) and the Whisper
+checkpoint format ``{"dims", "model_state_dict"}`` (whisper/inference.py:12-20).
+
+Parameters the reference initialises to zero/identity (ResidualCouplingLayer.post,
+vits/modules.py:283-284; SpeakerAdapter, vits_decoder/generator.py:30-34; SnakeBeta alpha/beta,
+vits_decoder/alias/act.py:69-71) are drawn non-trivially here so every branch carries signal.
+Distributions are ours (fan-in scaled so activations stay O(1)); they do not mimic the
+reference's initialisers -- parity only needs both sides to see the same tensors.
+"""
+import math
+
+import torch
+
+from . import config as C
+
+
+def kaiser_sinc_filter(cutoff=0.25, half_width=0.3, taps=12):
+    """The one 12-tap low-pass shared by every up/down sampler (vits_decoder/alias/filter.py:28-57,
+    called with cutoff=0.5/ratio, half_width=0.6/ratio, ratio=2 -- resample.py:18-20,41-44)."""
+    half = taps // 2
+    delta_f = 4 * half_width
+    att = 2.285 * (half - 1) * math.pi * delta_f + 7.95
+    if att > 50.0:
+        beta = 0.1102 * (att - 8.7)
+    elif att >= 21.0:
+        beta = 0.5842 * (att - 21.0) ** 0.4 + 0.07886 * (att - 21.0)
+    else:
+        beta = 0.0
+    window = torch.kaiser_window(taps, beta=beta, periodic=False)
+    time = torch.arange(-half, half) + 0.5
+    f = 2 * cutoff * window * torch.sinc(2 * cutoff * time)
+    f = f / f.sum()
+    return f.view(1, 1, taps)
+
+
+class _Rng:
+    def __init__(self, seed):
+        self.g = torch.Generator().manual_seed(seed)
+
+    def normal(self, *shape, std=1.0, mean=0.0):
+        return torch.randn(*shape, generator=self.g) * std + mean
+
+    def uniform(self, *shape, lo=0.0, hi=1.0):
+        return torch.rand(*shape, generator=self.g) * (hi - lo) + lo
+
+
+def _conv(sd, r, name, cout, cin, k, bias=True, gain=1.0):
+    sd[name + ".weight"] = r.normal(cout, cin, k, std=gain / math.sqrt(cin * k))
+    if bias:
+        sd[name + ".bias"] = r.normal(cout, std=0.05)
+
+
+def _wn_conv(sd, r, name, d0, d1, k, fan_in, nbias, gain=1.0):
+    """weight-normed conv: tensors ``weight_v`` [d0,d1,k] and ``weight_g`` [d0,1,1] (norm over dims 1,2)."""
+    v = r.normal(d0, d1, k, std=gain / math.sqrt(fan_in))
+    sd[name + ".bias"] = r.normal(nbias, std=0.05)
+    sd[name + ".weight_g"] = v.flatten(1).norm(dim=1).view(d0, 1, 1) * r.uniform(d0, 1, 1, lo=0.8, hi=1.2)
+    sd[name + ".weight_v"] = v
+
+
+def make_vits_state(hp=None, seed=1234):
+    """state_dict of ``SynthesizerInfer`` (vits/models.py:211-239) filled with seeded tensors."""
+    hp = hp or C.base_hp()
+    r = _Rng(seed)
+    sd = {}
+    H, F_, I = hp.vits.hidden_channels, hp.vits.filter_channels, hp.vits.inter_channels
+    dk = H // C.ENC_HEADS
+    # enc_p  (vits/models.py:26-37)
+    _conv(sd, r, "enc_p.pre", H, hp.vits.ppg_dim, 5)
+    _conv(sd, r, "enc_p.hub", H, hp.vits.vec_dim, 5)
+    sd["enc_p.pit.weight"] = r.normal(256, H, std=0.5)
+    for i in range(C.ENC_LAYERS):
+        a = f"enc_p.enc.attn_layers.{i}"
+        sd[a + ".emb_rel_k"] = r.normal(1, 2 * C.ENC_WINDOW + 1, dk, std=dk ** -0.5)
+        sd[a + ".emb_rel_v"] = r.normal(1, 2 * C.ENC_WINDOW + 1, dk, std=dk ** -0.5)
+        for n in ("conv_q", "conv_k", "conv_v", "conv_o"):
+            _conv(sd, r, f"{a}.{n}", H, H, 1)
+        sd[f"enc_p.enc.norm_layers_1.{i}.gamma"] = r.normal(H, std=0.1, mean=1.0)
+        sd[f"enc_p.enc.norm_layers_1.{i}.beta"] = r.normal(H, std=0.1)
+        _conv(sd, r, f"enc_p.enc.ffn_layers.{i}.conv_1", F_, H, C.ENC_FFN_KERNEL, gain=1.4)
+        _conv(sd, r, f"enc_p.enc.ffn_layers.{i}.conv_2", H, F_, C.ENC_FFN_KERNEL)
+        sd[f"enc_p.enc.norm_layers_2.{i}.gamma"] = r.normal(H, std=0.1, mean=1.0)
+        sd[f"enc_p.enc.norm_layers_2.{i}.beta"] = r.normal(H, std=0.1)
+    _conv(sd, r, "enc_p.proj", 2 * I, H, 1, gain=0.5)
+    # flow (vits/models.py:66-78, vits/modules.py:250-286); Flip modules at odd indices hold no tensors
+    half = I // 2
+    for f in range(C.FLOW_N):
+        p = f"flow.flows.{2 * f}"
+        _conv(sd, r, p + ".pre", H, half, 1)
+        for l in range(C.FLOW_WN_LAYERS):
+            _wn_conv(sd, r, f"{p}.enc.in_layers.{l}", 2 * H, H, C.FLOW_KERNEL, H * C.FLOW_KERNEL, 2 * H)
+            rs = 2 * H if l < C.FLOW_WN_LAYERS - 1 else H
+            _wn_conv(sd, r, f"{p}.enc.res_skip_layers.{l}", rs, H, 1, H, rs, gain=0.7)
+        _conv(sd, r, p + ".post", half, H, 1, gain=0.5)      # zero-init in the reference: de-zeroed
+        sd[p + ".snac.weight"] = r.normal(2 * half, hp.vits.spk_dim, 1, std=0.3 / math.sqrt(hp.vits.spk_dim))
+        sd[p + ".snac.bias"] = r.normal(2 * half, std=0.1)
+    # dec (vits_decoder/generator.py:52-112)
+    U = hp.gen.upsample_input
+    C0 = hp.gen.upsample_initial_channel
+    sd["dec.adapter.W_scale.weight"] = r.normal(U, hp.vits.spk_dim, std=0.2 / math.sqrt(hp.vits.spk_dim))
+    sd["dec.adapter.W_scale.bias"] = r.normal(U, std=0.1, mean=1.0)
+    sd["dec.adapter.W_bias.weight"] = r.normal(U, hp.vits.spk_dim, std=0.2 / math.sqrt(hp.vits.spk_dim))
+    sd["dec.adapter.W_bias.bias"] = r.normal(U, std=0.1)
+    _conv(sd, r, "dec.conv_pre", C0, U, 7)
+    sd["dec.m_source.merge_w"] = torch.tensor([C.NSF_MERGE_W], dtype=torch.float32)
+    sd["dec.m_source.merge_b"] = torch.tensor([C.NSF_MERGE_B], dtype=torch.float32)
+    rates, ksz = list(hp.gen.upsample_rates), list(hp.gen.upsample_kernel_sizes)
+    filt = kaiser_sinc_filter()
+    n_up = len(rates)
+    for i in range(n_up):
+        cin, cout = C0 // (2 ** i), C0 // (2 ** (i + 1))
+        if i + 1 < n_up:
+            s = 1
+            for u in rates[i + 1:]:
+                s *= u
+            _conv(sd, r, f"dec.noise_convs.{i}", cout, 1, 2 * s, gain=1.0)
+        else:
+            _conv(sd, r, f"dec.noise_convs.{i}", cout, 1, 1, gain=1.0)
+        # ConvTranspose1d weight is [C_in, C_out, k]; weight-norm g is per INPUT channel (dim 0)
+        _wn_conv(sd, r, f"dec.ups.{i}", cin, cout, ksz[i], cin * ksz[i] / rates[i], cout)
+    rk = list(hp.gen.resblock_kernel_sizes)
+    for i in range(n_up):
+        ch = C0 // (2 ** (i + 1))
+        for j, k in enumerate(rk):
+            b = f"dec.resblocks.{i * len(rk) + j}"
+            for q in range(3):
+                _wn_conv(sd, r, f"{b}.convs1.{q}", ch, ch, k, ch * k, ch, gain=1.0)
+                _wn_conv(sd, r, f"{b}.convs2.{q}", ch, ch, k, ch * k, ch, gain=0.4)
+            for q in range(6):
+                sd[f"{b}.activations.{q}.act.alpha"] = r.normal(ch, std=0.3)
+                sd[f"{b}.activations.{q}.act.beta"] = r.normal(ch, std=0.3)
+                sd[f"{b}.activations.{q}.upsample.filter"] = filt.clone()
+                sd[f"{b}.activations.{q}.downsample.lowpass.filter"] = filt.clone()
+    ch = C0 // (2 ** n_up)
+    sd["dec.activation_post.act.alpha"] = r.normal(ch, std=0.3)
+    sd["dec.activation_post.act.beta"] = r.normal(ch, std=0.3)
+    sd["dec.activation_post.upsample.filter"] = filt.clone()
+    sd["dec.activation_post.downsample.lowpass.filter"] = filt.clone()
+    sd["dec.conv_post.weight"] = r.normal(1, ch, 7, std=0.15 / math.sqrt(ch * 7))
+    return {k: v.float().contiguous() for k, v in sd.items()}
+
+
+def sinusoids(length, channels, max_timescale=10000.0):
+    """Positional table of the audio encoder (whisper/model.py:48-54)."""
+    inc = math.log(max_timescale) / (channels // 2 - 1)
+    inv = torch.exp(-inc * torch.arange(channels // 2))
+    t = torch.arange(length)[:, None] * inv[None, :]
+    return torch.cat([torch.sin(t), torch.cos(t)], dim=1)
+
+
+def make_whisper_state(dims=None, seed=4321, n_layers_present=None):
+    """A Whisper checkpoint dict ``{"dims", "model_state_dict"}`` holding the ENCODER keys only.
+
+    whisper/inference.py:16-20 deletes the decoder and the last quarter of the encoder blocks and loads
+    with strict=False, so decoder.* keys and blocks >= 3/4 n_audio_layer never matter; by default we
+    materialise just the blocks that survive (24 for large-v2) to keep the 1.9 GB build fast.
+    """
+    dims = dict(dims or C.WHISPER_LARGE_V2)
+    S, L = dims["n_audio_state"], dims["n_audio_layer"]
+    keep = L - L // 4 if n_layers_present is None else n_layers_present
+    r = _Rng(seed)
+    sd = {}
+    sd["encoder.conv1.weight"] = r.normal(S, dims["n_mels"], 3, std=1.0 / math.sqrt(dims["n_mels"] * 3))
+    sd["encoder.conv1.bias"] = r.normal(S, std=0.05)
+    sd["encoder.conv2.weight"] = r.normal(S, S, 3, std=1.0 / math.sqrt(S * 3))
+    sd["encoder.conv2.bias"] = r.normal(S, std=0.05)
+    sd["encoder.positional_embedding"] = sinusoids(dims["n_audio_ctx"], S)
+    for i in range(keep):
+        b = f"encoder.blocks.{i}"
+        for n in ("query", "key", "value", "out"):
+            g = 0.5 if n == "out" else 1.0
+            sd[f"{b}.attn.{n}.weight"] = r.normal(S, S, std=g / math.sqrt(S))
+            if n != "key":                       # key has no bias (whisper/model.py:62)
+                sd[f"{b}.attn.{n}.bias"] = r.normal(S, std=0.05)
+        sd[f"{b}.attn_ln.weight"] = r.normal(S, std=0.1, mean=1.0)
+        sd[f"{b}.attn_ln.bias"] = r.normal(S, std=0.1)
+        sd[f"{b}.mlp.0.weight"] = r.normal(4 * S, S, std=1.0 / math.sqrt(S))
+        sd[f"{b}.mlp.0.bias"] = r.normal(4 * S, std=0.05)
+        sd[f"{b}.mlp.2.weight"] = r.normal(S, 4 * S, std=0.5 / math.sqrt(4 * S))
+        sd[f"{b}.mlp.2.bias"] = r.normal(S, std=0.05)
+        sd[f"{b}.mlp_ln.weight"] = r.normal(S, std=0.1, mean=1.0)
+        sd[f"{b}.mlp_ln.bias"] = r.normal(S, std=0.1)
+    sd["encoder.ln_post.weight"] = r.normal(S, std=0.1, mean=1.0)
+    sd["encoder.ln_post.bias"] = r.normal(S, std=0.1)
+    return {"dims": dims, "model_state_dict": {k: v.float().contiguous() for k, v in sd.items()}}

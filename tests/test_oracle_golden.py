@@ -1,0 +1,114 @@
+"""The oracle restatement against the golden vectors produced by the real reference
+(oracle/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import config as C
+from oracle import inputs as I
+from oracle import svc_oracle as O
+from oracle import weights as W
+from oracle.make_golden import checksum
+
+TOL = 5e-5   # fp32 CPU vs fp32 CPU (different BLAS blocking across hosts); waveform in [-1,1]
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_filter_taps_match_reference_constants():
+    # taps quoted in SURVEY.md a28 (computed from vits_decoder/alias/filter.py:28-57)
+    f = W.kaiser_sinc_filter().view(-1).numpy()
+    want = [0.00202896, 0.00938947, -0.02554346, -0.05765738, 0.12857258, 0.44320980]
+    assert np.allclose(f[:6], want, atol=2e-8) and np.allclose(f[6:], want[::-1], atol=2e-8)
+
+
+@pytest.mark.parametrize("tag,hp", [("vits_tiny_ragged", C.tiny_hp()), ("vits_base_T60", C.base_hp())])
+def test_vits_path_against_reference_golden(golden_dir, tag, hp):
+    g = _load(golden_dir, tag)
+    sd = W.make_vits_state(hp, seed=1234)
+    assert checksum(sd) == pytest.approx(float(g["weights_checksum"]), rel=1e-9), "weight RNG drifted"
+    d = I.synth_clip(T=int(g["T"]), hp=hp, seed=int(g["seed"]), B=int(g["B"]))
+    assert checksum(d) == pytest.approx(float(g["inputs_checksum"]), rel=1e-9), "input RNG drifted"
+    lens = _t(g["lengths"])
+    with torch.no_grad():
+        src = O.pitch2source(sd, hp, d["pit"], d["rand_ini"], d["src_noise"])
+        wav, parts = O.synth_inference(sd, hp, d["ppg"], d["vec"], d["pit"], d["spk"], lens, src,
+                                       d["enc_noise"], return_parts=True)
+    assert (O.f0_to_coarse(d["pit"]).numpy() == g["f0_coarse"]).all()
+    assert (src - _t(g["source"])).abs().max() <= 1e-6
+    assert (parts["z_p"] - _t(g["z_p"])).abs().max() <= TOL
+    assert (parts["z"] - _t(g["z"])).abs().max() <= TOL
+    assert (wav - _t(g["wave"])).abs().max() <= TOL
+    assert np.abs(O.source2wav(src[:1]).astype(np.int32) - g["pitwav"].astype(np.int32)).max() <= 1
+
+
+def test_tiny_fixture_carries_its_inputs(golden_dir):
+    g = _load(golden_dir, "vits_tiny_ragged")
+    d = I.synth_clip(T=int(g["T"]), hp=C.tiny_hp(), seed=int(g["seed"]), B=int(g["B"]))
+    for k, v in d.items():
+        assert np.array_equal(v.numpy(), g["in_" + k]), k
+
+
+@pytest.mark.parametrize("tag,dims", [("whisper_tiny", C.WHISPER_TINY_TEST)])
+def test_whisper_encoder_against_reference_golden(golden_dir, tag, dims):
+    g = _load(golden_dir, tag)
+    ck = W.make_whisper_state(dims)
+    assert checksum(ck["model_state_dict"]) == pytest.approx(float(g["weights_checksum"]), rel=1e-9)
+    with torch.no_grad():
+        out = O.audio_encoder(ck["model_state_dict"], _t(g["mel"]) + 0.1 * _t(g["mel_noise"]),
+                              dims["n_audio_head"], O.whisper_kept_layers(dims))
+    assert (out - _t(g["ppg"])).abs().max() <= TOL
+
+
+def test_chunk_schedule_matches_reference_plan(golden_dir):
+    g = _load(golden_dir, "svc_infer_tiny_2chunks")
+    plan = O.chunk_schedule(int(g["T"]), 320)
+    assert np.array_equal(np.array(plan), g["plan"])
+    # 30 s clip -> [0,2510) keep [0,-3200) ; [2490,3000) keep [3200,-1)
+    assert O.chunk_schedule(3000, 320) == [(0, 2510, 0, -3200), (2490, 3000, 3200, -1)]
+    assert O.chunk_schedule(1000, 320) == [(0, 1000, 0, -1)]
+
+
+def test_svc_infer_two_chunks_against_reference_golden(golden_dir):
+    g = _load(golden_dir, "svc_infer_tiny_2chunks")
+    hp = C.tiny_hp()
+    T = int(g["T"])
+    sd = W.make_vits_state(hp, seed=1234)
+    d = I.synth_clip(T=T, hp=hp, seed=2, B=1)
+    gen = torch.Generator().manual_seed(77)
+    enc_noises = [torch.randn(1, hp.vits.inter_channels, ce - cs, generator=gen)
+                  for (cs, ce, _, _) in O.chunk_schedule(T, 320)]
+    with torch.no_grad():
+        wav, _ = O.svc_infer(sd, hp, d["spk"][0], d["pit"][0], d["ppg"][0], d["vec"][0],
+                             d["rand_ini"], d["src_noise"], enc_noises)
+    assert wav.shape[0] == int(g["length"]) == T * 320 - 1
+    seam = C.CHUNK_FRAMES * 320
+    assert np.abs(wav[::97] - g["wave_sub"]).max() <= TOL
+    assert np.abs(wav[seam - 3000:seam + 3000] - g["wave_seam"]).max() <= TOL
+    assert np.abs(wav[-2000:] - g["wave_tail"]).max() <= TOL
+
+
+@pytest.mark.needs_reference
+def test_oracle_equals_live_reference_on_fresh_seed():
+    """Not just the stored vectors: a different seed/shape through the imported reference."""
+    from oracle import ref_import as R
+    hp = C.tiny_hp()
+    sd = W.make_vits_state(hp, seed=99)
+    ref = R.ref_synthesizer(hp, sd)
+    d = I.synth_clip(T=31, hp=hp, seed=5, B=1)
+    with torch.no_grad():
+        with R.injected_noise([d["src_noise"]], [d["rand_ini"]]):
+            src = ref.pitch2source(d["pit"])
+        with R.injected_noise([d["enc_noise"]]):
+            wav = ref.inference(d["ppg"], d["vec"], d["pit"], d["spk"], d["lengths"], src)
+        o = O.synth_inference(sd, hp, d["ppg"], d["vec"], d["pit"], d["spk"], d["lengths"],
+                              O.pitch2source(sd, hp, d["pit"], d["rand_ini"], d["src_noise"]), d["enc_noise"])
+    assert (o - wav).abs().max() <= TOL
