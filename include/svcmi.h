@@ -1,0 +1,176 @@
+/* svcmi.h -- C ABI of libsvcmi.so, the MI355X (gfx950) kernels of the SVC inference hot path.
+ *
+ * The reference (PlayVoice/whisper-vits-svc) has NO native/FFI interface: the path sits behind
+ * Python callables.  This header is therefore the boundary a maintainer
+ * would bind (ctypes stub in INTEGRATION.md).  Each entry point cites the reference code whose
+ * arithmetic it replaces.  Conventions:
+ *   - extern "C", plain pointers and sizes, no torch / C++ types, no exceptions, no hidden
+ *     allocation; the caller owns every buffer and keeps it alive until the stream has drained.
+ *   - every pointer is a DEVICE pointer (HBM); `stream` is a hipStream_t passed as void*.
+ *   - activations are fp32, time-major / channels-last: element (b, t, c) of a tensor lives at
+ *     base + b*bstride + t*ld + c.   (The reference is NCL [B,C,T]; the Python facade converts
+ *     at the API edge.)  Leading dimensions are multiples of 4 floats and bases 16-byte aligned
+ *     unless a function says otherwise.
+ *   - `lengths` (int32[batch], may be NULL = all rows valid) carries the reference's x_mask
+ *     (vits/commons.py:147-151): rows t >= lengths[b] are "masked".
+ *   - return value: 0 = launched; <0 = svcmi_status (argument error, nothing launched);
+ *     >0 = hipError_t from the launch.  Kernels are asynchronous on `stream`.
+ */
+#ifndef SVCMI_H
+#define SVCMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVCMI_ABI_VERSION 1
+
+enum svcmi_status { SVCMI_OK = 0, SVCMI_EINVAL = -1, SVCMI_EUNSUPPORTED = -2, SVCMI_EALIGN = -3 };
+
+enum svcmi_act { SVCMI_ACT_NONE = 0, SVCMI_ACT_RELU = 1, SVCMI_ACT_GELU = 2, SVCMI_ACT_MISH = 3, SVCMI_ACT_TANH = 4 };
+
+enum svcmi_conv_flags {
+    SVCMI_CONV_ACCUMULATE = 1, /* y += result instead of y = result                          */
+    SVCMI_CONV_MASK_IN = 2,    /* input rows >= lengths[b] read as zero   (conv(x * x_mask))  */
+    SVCMI_CONV_MASK_OUT = 4,   /* output rows >= lengths[b] written as zero  (... * x_mask)   */
+    /* tuning knob (bits 8-9): force the block tile (time x channels); 0 = library heuristic        */
+    SVCMI_CONV_TILE_64x64 = 0x100,
+    SVCMI_CONV_TILE_128x64 = 0x200,
+    SVCMI_CONV_TILE_128x128 = 0x300,
+    SVCMI_CONV_TILE_MASK = 0x300
+};
+
+int svcmi_abi_version(void);
+/* "hip:gfx950" for the product build; the CPU SIMT emulator used by the unit tests says "emu". */
+const char* svcmi_build_info(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * 1-D convolution / linear layer as an implicit GEMM on the fp32 matrix cores
+ * (v_mfma_f32_32x32x2_f32, exact fp32).  Replaces every nn.Conv1d / nn.Linear / ConvTranspose1d
+ * (polyphase-packed) on the path:
+ *   whisper/model.py:34-45 (Linear, Conv1d), :144-163 (conv stem), :66-86,:118-129 (q/k/v/out, mlp);
+ *   vits/models.py:26-37,44-46,49 (pre, hub, proj); vits/attentions.py:193-196 (conv_q/k/v/o),
+ *   :390-403 (FFN); vits/modules.py:148-176,186,196 (WN in/res_skip), :273,281,285 (pre, post, snac);
+ *   vits_decoder/generator.py:36-47 (adapter linears), :60,:69-99,:108 (conv_pre, ups, noise_convs,
+ *   conv_post); vits_decoder/bigv.py:22-39 (AMP convs).
+ *
+ *   y[b,t,n] = epilogue( sum_{k<ksize} sum_{ci<c_in} x[b, (t*stride + k*dilation - pad) >> x_row_shift, ci]
+ *                                                   * w[n, k*c_in + ci] )
+ *   epilogue(v): v += bias[n]; v = act(v); v += res[b,t,n]; v *= alpha; (ACCUMULATE) v += y_old;
+ *                (MASK_OUT) v = t < lengths[b] ? v : 0.
+ * Input rows outside [0, t_in) (and, with MASK_IN, >= lengths[b]) read as zero.  x_row_shift = 1
+ * fuses the np.repeat(ppg, 2, 0) of svc_inference.py:175-182 into the load (t_in is then the
+ * repeated length).  w is [n_out][ldw] with ldw >= ksize*c_in, ldw % 4 == 0, zero padded.
+ * c_in % 4 == 0 and ldx % 4 == 0 select 16-byte loads; any other c_in/ldx uses scalar loads.
+ * y may alias res (in-place residual).  bias / res / lengths may be NULL.
+ */
+typedef struct svcmi_conv_desc {
+    const float* x;
+    const float* w;
+    const float* bias;
+    const float* res;
+    float* y;
+    const int32_t* lengths;
+    int64_t x_bstride, y_bstride, res_bstride; /* in floats */
+    int32_t batch, t_in, t_out, c_in, ldx, n_out, ldw, ldy, ldr;
+    int32_t ksize, stride, dilation, pad, x_row_shift;
+    int32_t act;   /* enum svcmi_act */
+    int32_t flags; /* enum svcmi_conv_flags */
+    float alpha;
+} svcmi_conv_desc;
+
+int svcmi_conv_gemm_f32(const svcmi_conv_desc* d, void* stream);
+
+/* LayerNorm over the channel dim of time-major rows, optional pre-add:
+ *   y[r,:] = (v - mean(v)) / sqrt(var(v) + eps) * gamma + beta,   v = x[r,:] + (res ? res[r,:] : 0)
+ * rows = batch*rows_per_batch contiguous rows of stride ldx/ldr/ldy.  gamma/beta (NULL = 1/0) are
+ * indexed [ (r / rows_per_batch) * gb_bstride + c ] so a per-utterance affine can be applied.
+ * Replaces whisper/model.py:28-31 (attn_ln, mlp_ln, ln_post), vits/modules.py:19-22 fused with the
+ * `x + y` of vits/attentions.py:66,70, and the speaker-conditioned LN of
+ * vits_decoder/generator.py:36-47 (gamma/beta = W_scale(spk)/W_bias(spk), gb_bstride = c).
+ * c % 4 == 0, c <= 2048. */
+int svcmi_layernorm_f32(const float* x, const float* res, const float* gamma, const float* beta, float* y,
+                        int32_t batch, int32_t rows_per_batch, int32_t c, int32_t ldx, int32_t ldr, int32_t ldy,
+                        int32_t gb_bstride, float eps, void* stream);
+
+/* Multi-head self-attention with exact (fp32, online) softmax.
+ *   S[i,j] = scale * ( q_i . k_j  +  (|j-i| <= window ? q_i . rel_k[j-i+window] : 0) )
+ *   S[i,j] = -1e4 where i >= lengths[b] or j >= lengths[b]           (masked_fill, attentions.py:249)
+ *   P = softmax_j(S);  o_i = sum_j P[i,j] v_j  +  sum_{|j-i|<=window} P[i,j] rel_v[j-i+window]
+ * q/k/v/o: element (b, t, h, d) at base + b*bstride + t*ld + h*head_dim + d (so q,k,v can point into
+ * one fused [T, 3C] projection).  rel_k/rel_v: [2*window+1][head_dim] shared by heads, or NULL
+ * (then window is ignored).  head_dim in {16, 32, 64, 96}.
+ * Replaces whisper/model.py:88-101 (scale = head_dim^-0.5, no rel, no mask) and
+ * vits/attentions.py:225-274 incl. the relative-position skew helpers :276-347. */
+int svcmi_attention_f32(const float* q, const float* k, const float* v, float* o,
+                        int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo,
+                        int64_t q_bstride, int64_t k_bstride, int64_t v_bstride, int64_t o_bstride,
+                        int32_t batch, int32_t t, int32_t heads, int32_t head_dim, float scale,
+                        const float* rel_k, const float* rel_v, int32_t window,
+                        const int32_t* lengths, void* stream);
+
+/* Anti-aliased SnakeBeta (vits_decoder/alias/act.py:124-129): 2x Kaiser-sinc polyphase upsample with
+ * replicate padding (resample.py:25-33), x + sin^2(x*e^alpha)/(e^beta + 1e-9) (act.py:79-92), 12-tap
+ * low-pass + 2x decimation (filter.py:86-95).  x,y: [batch][len][ld] time-major, c <= ld channels;
+ * alpha_log/beta_log: [c]; filt: the 12 taps (filter.py:28-57).  SURVEY.md A.5. */
+int svcmi_snake_alias_f32(const float* x, float* y, const float* alpha_log, const float* beta_log,
+                          const float* filt, int32_t batch, int32_t len, int32_t c, int32_t ld, void* stream);
+
+/* WaveNet gate, vits/commons.py:126-133 with input_b == 0 (vits/modules.py:190-193):
+ *   out[r, c] = tanh(a[r, c]) * sigmoid(a[r, h + c]),  c < h. */
+int svcmi_wn_gate_f32(const float* a, float* out, int64_t rows, int32_t h, int32_t lda, int32_t ldo, void* stream);
+
+/* WaveNet residual/skip bookkeeping, vits/modules.py:196-203, from rs = res_skip_layer(acts):
+ *   !last: x = (x + rs[:, :h]) * mask ; skip (+)= rs[:, h:2h]        last: skip (+)= rs[:, :h]; skip *= mask
+ * `first` makes skip = instead of += (output = zeros_like(x) at :179). */
+int svcmi_wn_update_f32(const float* rs, float* x, float* skip, const int32_t* lengths,
+                        int32_t batch, int32_t t, int32_t h, int32_t ldrs, int32_t first, int32_t last, void* stream);
+
+/* Speaker-normalised coupling, reverse direction (vits/modules.py:288-321 with mean_only).
+ * ms_vs: [batch][2*half] = snac(spk) laid out (m_s | v_s), already permuted for flipped layers.
+ * pre :  out[b,t,c] = (x[b,t,x0_off+c] - m_s[c]) * exp(-v_s[c]) * mask
+ * post:  x1 = x[b,t,x1_off+c];  x1 = (x1 - m[b,t,c]) * mask;  x[b,t,x1_off+c] = (m_s[c] + x1*exp(v_s[c])) * mask
+ * torch.flip (modules.py:225-229) is folded into the x0/x1 offsets and weight permutations at load. */
+int svcmi_coupling_pre_f32(const float* x, int32_t ldx, int32_t x0_off, const float* ms_vs, float* out, int32_t ldo,
+                           const int32_t* lengths, int32_t batch, int32_t t, int32_t half, void* stream);
+int svcmi_coupling_post_f32(float* x, int32_t ldx, int32_t x1_off, const float* m, int32_t ldm, const float* ms_vs,
+                            const int32_t* lengths, int32_t batch, int32_t t, int32_t half, void* stream);
+
+/* x[b,t,:] = (x[b,t,:] + emb[f0_to_coarse(pit[b,t]), :]) * mask   -- vits/utils.py:20-33 (Hz -> bin 1..255)
+ * + nn.Embedding lookup and the sum/mask of vits/models.py:44-48.  emb: [256][c]. */
+int svcmi_embed_pitch_f32(float* x, int32_t ldx, const float* pit, const float* emb, const int32_t* lengths,
+                          int32_t batch, int32_t t, int32_t c, void* stream);
+
+/* z[b,t,c] = (m + noise[b,c,t] * exp(logs)) * mask with (m | logs) = stats[b,t,0:i | i:2i]
+ * (vits/models.py:49-51).  noise is the reference's randn_like(m) in ITS layout [batch][i][t]. */
+int svcmi_sample_prior_f32(const float* stats, int32_t lds, const float* noise_ncl, const int32_t* lengths,
+                           float* z, int32_t ldz, int32_t batch, int32_t t, int32_t i, void* stream);
+
+/* Layout bridges at the API edge.  ncl_to_nlc: y[b,t,c] = x[b,c,t] + add_scale*add[b,c,t] (add may be NULL;
+ * used for `mel + 0.1*randn`, whisper/inference.py:46).  nlc_to_ncl: y[b,c,t] = x[b,t,c]. */
+int svcmi_ncl_to_nlc_f32(const float* x, const float* add, float add_scale, float* y,
+                         int32_t batch, int32_t c, int32_t t, int32_t ldy, void* stream);
+int svcmi_nlc_to_ncl_f32(const float* x, int32_t ldx, float* y, int32_t batch, int32_t c, int32_t t, void* stream);
+
+/* Harmonic source (vits_decoder/generator.py:160-165 -> nsf.py:223-253,284-316,383-394).
+ * Step 1: per-frame phase prefix.  rad[f,k] = fmodf(f0[b,f]*(k+1)/sr, 1) in fp32 exactly as :228; the sample-level
+ *   double cumsum of :246-253 collapses (F0 is piecewise constant over a hop) to
+ *   prefix[b,f,k] = frac(rand_ini[b,k] + hop * sum_{f'<f} rad[f',k]) accumulated in fp64.  rand_ini column 0 is
+ *   treated as 0 (:235).
+ * Step 2: out[b, f*hop+j] = tanh(sum_k merge_w[k]*(0.1*sin(2*pi*(prefix + (j+1)*rad))*uv + amp*noise[b,t,k]) + merge_b),
+ *   uv = f0 > 0, amp = uv ? 0.003 : 0.1/3 (:305-314); noise: [batch][t*hop][11] as drawn by randn_like(:311). */
+int svcmi_pitch_prefix_f64(const float* f0, const float* rand_ini, double* prefix,
+                           int32_t batch, int32_t t, int32_t hop, float sr, void* stream);
+int svcmi_pitch_source_f32(const float* f0, const double* prefix, const float* noise, const float* merge_w,
+                           float merge_b, float* out, int32_t batch, int32_t t, int32_t hop, float sr, void* stream);
+
+/* int16 side output, vits_decoder/generator.py:167-173: clamp(32768*x, -32768, 32767) truncated to short. */
+int svcmi_source2wav_i16(const float* x, int16_t* y, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVCMI_H */

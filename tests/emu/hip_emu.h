@@ -1,0 +1,119 @@
+// hip_emu.h -- TEST-ONLY fiber-based SIMT emulator for the subset of HIP that svcmi kernels use.
+//
+// Purpose: execute the product's kernel source (whisper-vits-svc_amd/csrc/*.hip, compiled with
+// g++ -DSVCMI_EMU) on the CPU so that `pytest -m "not gpu"` can check tiling / indexing / masking
+// logic in a container without a GPU.  Each workgroup runs as blockDim cooperative fibers
+// (ucontext) on one OS thread; __syncthreads and wave-level collectives (shuffles, the fp32 MFMA)
+// are rendezvous points.  Blocks run sequentially, so `__shared__` is plain static storage.
+// Nothing here is a fallback for the product: svcmi (Python) only ever loads the hipcc-built
+// library and refuses to run without it.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__ static
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float2 { float x, y; };
+struct alignas(16) float4 { float x, y, z, w; };
+struct alignas(16) int4 { int x, y, z, w; };
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+
+typedef float svcmi_f32x16 __attribute__((vector_size(64)));
+typedef float svcmi_f32x4 __attribute__((vector_size(16)));
+
+typedef void* hipStream_t;
+
+namespace emu {
+struct Fiber;
+extern dim3 g_blockIdx, g_blockDim, g_gridDim;
+const dim3& cur_tid();
+int cur_lane();
+void syncthreads();
+void wave_exchange(const void* mine, size_t bytes, void* all64);  // all-gather within the wave
+void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+extern int g_last_error;
+}  // namespace emu
+
+#define threadIdx (emu::cur_tid())
+#define blockIdx (emu::g_blockIdx)
+#define blockDim (emu::g_blockDim)
+#define gridDim (emu::g_gridDim)
+
+static inline void __syncthreads() { emu::syncthreads(); }
+
+template <class T>
+static inline T __shfl(T v, int src, int width = 64) {
+    T all[64];
+    emu::wave_exchange(&v, sizeof(T), all);
+    int lane = emu::cur_lane();
+    int base = lane & ~(width - 1);
+    return all[base + (src & (width - 1))];
+}
+template <class T>
+static inline T __shfl_xor(T v, int mask, int width = 64) {
+    T all[64];
+    emu::wave_exchange(&v, sizeof(T), all);
+    int lane = emu::cur_lane();
+    int t = lane ^ mask;
+    if ((t & ~(width - 1)) != (lane & ~(width - 1))) t = lane;
+    return all[t];
+}
+template <class T>
+static inline T __shfl_down(T v, int delta, int width = 64) {
+    T all[64];
+    emu::wave_exchange(&v, sizeof(T), all);
+    int lane = emu::cur_lane();
+    int t = lane + delta;
+    if ((t & ~(width - 1)) != (lane & ~(width - 1))) t = lane;
+    return all[t];
+}
+template <class T>
+static inline T __shfl_up(T v, int delta, int width = 64) {
+    T all[64];
+    emu::wave_exchange(&v, sizeof(T), all);
+    int lane = emu::cur_lane();
+    int t = lane - delta;
+    if (t < 0 || (t & ~(width - 1)) != (lane & ~(width - 1))) t = lane;
+    return all[t];
+}
+
+// v_mfma_f32_32x32x2_f32 with the gfx950 operand layout (cdna_hip_programming.md section 3):
+// lane l holds A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]; D: col=l&31, row=(r&3)+8*(r>>2)+4*(l>>5);
+// numerics = k-ordered fmaf chain.
+static inline svcmi_f32x16 svcmi_mfma_32x32x2(float a, float b, svcmi_f32x16 c) {
+    float ab[2] = {a, b};
+    float all[64][2];
+    emu::wave_exchange(ab, sizeof(ab), all);
+    int l = emu::cur_lane();
+    int j = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        acc = fmaf(all[i][0], all[j][1], acc);
+        acc = fmaf(all[i + 32][0], all[j + 32][1], acc);
+        c[r] = acc;
+    }
+    return c;
+}
+
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+
+#define SVCMI_LAUNCH(kernel, grid, block, shmem, stream, ...) \
+    emu::launch(grid, block, [=]() { kernel(__VA_ARGS__); })
+#define SVCMI_LAST_ERROR() (emu::g_last_error)
+#define SVCMI_UNIFORM(x) (x)

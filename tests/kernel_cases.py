@@ -1,0 +1,269 @@
+"""Per-kernel parity checks shared by the emulator tests (CPU, not gpu) and the GPU tests.
+
+Each check draws seeded inputs on the CPU, evaluates a plain torch fp32 / oracle reference there,
+runs the kernel through ``ops`` (C ABI) on ``device`` and compares.  Tolerances are fp32 round-off
+class (different summation orders), stated per check.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from oracle import svc_oracle as O
+from oracle import weights as W
+from svcmi import weights as PW
+from svcmi.ops import ACT_GELU, ACT_MISH, ACT_NONE, ACT_RELU, ACT_TANH
+
+
+def _g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def _close(got, want, tol, what=""):
+    got = got.detach().cpu()
+    err = (got - want).abs().max().item()
+    scale = max(1.0, want.abs().max().item())
+    assert err <= tol * scale, f"{what}: max-abs err {err:.3e} (scale {scale:.2f}) > {tol:.1e}"
+
+
+_ACT = {ACT_NONE: lambda v: v, ACT_RELU: torch.relu, ACT_GELU: F.gelu,
+        ACT_MISH: lambda v: v * torch.tanh(F.softplus(v)), ACT_TANH: torch.tanh}
+
+# id, B, T, Cin, N, K, stride, dil, pad, act, res, alpha, accumulate, lengths, mask_in, mask_out, repeat, tile
+CONV_CASES_SMALL = [
+    dict(id="linear_1x1", B=1, T=37, cin=16, n=10, k=1),
+    dict(id="k5_dil2_relu_res", B=2, T=37, cin=8, n=10, k=5, dil=2, pad=4, act=ACT_RELU, res=True),
+    dict(id="k3_stride2_gelu", B=1, T=41, cin=32, n=40, k=3, stride=2, pad=1, act=ACT_GELU),
+    dict(id="k5_masks", B=2, T=29, cin=12, n=24, k=5, pad=2, lengths=[29, 17], mask_in=True, mask_out=True),
+    dict(id="k3_chunk_tap_multi_kstep", B=1, T=70, cin=64, n=70, k=3, pad=1, act=ACT_MISH),
+    dict(id="repeat2_fused", B=1, T=20, cin=16, n=8, k=5, pad=2, repeat=True),
+    dict(id="cin1_scalar_path", B=2, T=64, cin=1, n=6, k=8, stride=4, pad=2),
+    dict(id="accumulate_alpha", B=1, T=33, cin=8, n=8, k=7, pad=3, res=True, alpha=1.0 / 3.0, accumulate=True),
+    dict(id="n1_tanh_nobias", B=1, T=50, cin=12, n=1, k=7, pad=3, act=ACT_TANH, bias=False),
+    dict(id="tile_128x64", B=1, T=150, cin=16, n=70, k=3, pad=1, tile=2),
+    dict(id="tile_128x128", B=1, T=150, cin=16, n=140, k=1, tile=3),
+]
+CONV_CASES_LARGE = [
+    dict(id="whisper_qkv", B=1, T=500, cin=1280, n=3840, k=1),
+    dict(id="whisper_mlp2_res", B=1, T=500, cin=5120, n=1280, k=1, res=True),
+    dict(id="encp_pre_repeat", B=1, T=1000, cin=1280, n=192, k=5, pad=2, repeat=True),
+    dict(id="amp_k11_d5", B=1, T=5000, cin=160, n=160, k=11, dil=5, pad=25, res=True),
+    dict(id="stage4_c12_k11", B=1, T=40000, cin=12, n=12, k=11, pad=5, res=True),
+    dict(id="auto_tile_big", B=2, T=20000, cin=80, n=80, k=7, pad=3),
+]
+
+
+def check_conv(ops, c, device):
+    B, T, cin, n, k = c["B"], c["T"], c["cin"], c["n"], c["k"]
+    stride, dil, pad = c.get("stride", 1), c.get("dil", 1), c.get("pad", 0)
+    act = c.get("act", ACT_NONE)
+    g = _g(hash(c["id"]) % 10000)
+    rep = c.get("repeat", False)
+    t_phys = T // 2 if rep else T
+    x = torch.randn(B, t_phys, cin, generator=g)
+    w = torch.randn(n, cin, k, generator=g) / math.sqrt(cin * k)
+    bias = torch.randn(n, generator=g) if c.get("bias", True) else None
+    xl = x.repeat_interleave(2, dim=1) if rep else x                      # logical input
+    Tl = xl.shape[1]
+    lengths = torch.tensor(c["lengths"], dtype=torch.int32) if "lengths" in c else None
+    mask = (torch.arange(Tl)[None, :] < lengths[:, None]).float().unsqueeze(-1) if lengths is not None else None
+    xin = xl * mask if c.get("mask_in") else xl
+    ref = F.conv1d(xin.transpose(1, 2), w, bias, stride=stride, dilation=dil, padding=pad).transpose(1, 2)
+    t_out = ref.shape[1]
+    ref = _ACT[act](ref)
+    res = torch.randn(B, t_out, n, generator=g) if c.get("res") else None
+    if res is not None:
+        ref = ref + res
+    ref = ref * c.get("alpha", 1.0)
+    y0 = torch.randn(B, t_out, n, generator=g) if c.get("accumulate") else None
+    if y0 is not None:
+        ref = ref + y0
+    if c.get("mask_out"):
+        ref = ref * mask[:, :t_out]
+    wp = PW.pack_conv(w).to(device)
+    dev = lambda t: None if t is None else t.to(device)
+    out = dev(y0.clone()) if y0 is not None else None
+    xd = dev(x)
+    if cin == 1:
+        xd = xd.reshape(B, t_phys)      # a plain signal, ldx = 1
+    y = ops.conv(xd, wp, dev(bias), ksize=k, stride=stride, dilation=dil, pad=pad, act=act, res=dev(res),
+                 alpha=c.get("alpha", 1.0), accumulate=c.get("accumulate", False), lengths=dev(lengths),
+                 mask_in=c.get("mask_in", False), mask_out=c.get("mask_out", False), out=out,
+                 x_row_shift=1 if rep else 0, c_in=cin, ldx=cin, n_out=n, tile=c.get("tile", 0),
+                 t_in=Tl, x_bstride=t_phys * cin)
+    assert y.shape == ref.shape
+    _close(y, ref, 2e-5 if cin * k < 4096 else 1e-4, c["id"])
+
+
+def check_layernorm(ops, c, device):
+    g = _g(c)
+    B, T = 2, 9
+    x, r = torch.randn(B, T, c, generator=g) * 2 + 0.5, torch.randn(B, T, c, generator=g)
+    gamma, beta = torch.randn(c, generator=g), torch.randn(c, generator=g)
+    _close(ops.layernorm(x.to(device), gamma.to(device), beta.to(device), res=r.to(device)),
+           F.layer_norm(x + r, (c,), gamma, beta, 1e-5), 2e-5, "ln+res")
+    _close(ops.layernorm(x.to(device)), F.layer_norm(x, (c,), None, None, 1e-5), 2e-5, "ln plain")
+    gb, bb = torch.randn(B, c, generator=g), torch.randn(B, c, generator=g)
+    want = F.layer_norm(x, (c,), None, None, 1e-5) * gb[:, None] + bb[:, None]
+    _close(ops.layernorm(x.to(device), gb.to(device), bb.to(device), per_batch_affine=True), want, 2e-5, "ln per-batch")
+
+
+ATTN_CASES_SMALL = [
+    dict(id="d16_rel_w4_ragged", B=2, T=45, H=2, D=16, rel=True, W=4, lengths=[45, 31]),
+    dict(id="d32_plain", B=1, T=70, H=3, D=32),
+    dict(id="d64_plain_T130", B=1, T=130, H=2, D=64),
+    dict(id="d96_rel_short_T3", B=1, T=3, H=2, D=96, rel=True, W=4),
+    dict(id="d96_rel_T67", B=1, T=67, H=2, D=96, rel=True, W=4, lengths=[60]),
+]
+ATTN_CASES_LARGE = [
+    dict(id="whisper_T500", B=1, T=500, H=20, D=64),
+    dict(id="encp_T1000", B=1, T=1000, H=2, D=96, rel=True, W=4),
+    dict(id="encp_ragged_B3", B=3, T=301, H=2, D=96, rel=True, W=4, lengths=[301, 250, 7]),
+]
+
+
+def attention_reference(qkv, H, scale, rel_k, rel_v, W, lengths):
+    B, T, C3 = qkv.shape
+    Cc = C3 // 3
+    D = Cc // H
+    q, k, v = [t.view(B, T, H, D).permute(0, 2, 1, 3).double() for t in qkv.split(Cc, dim=-1)]
+    s = q @ k.transpose(-1, -2)
+    idx = torch.arange(T)
+    rel = idx[None, :] - idx[:, None]
+    if rel_k is not None:
+        band = rel.abs() <= W
+        relc = (rel + W).clamp(0, 2 * W)
+        qe = q @ rel_k.double().t()
+        s = s + torch.where(band, qe.gather(-1, relc.expand(B, H, T, T)), torch.zeros((), dtype=torch.double))
+    s = s * scale
+    if lengths is not None:
+        m = (idx[None, :] < lengths[:, None])
+        mm = (m[:, :, None] & m[:, None, :])[:, None]
+        s = s.masked_fill(~mm, -1e4)
+    p = torch.softmax(s, dim=-1)
+    o = p @ v
+    if rel_k is not None:
+        pb = torch.where(band, p, torch.zeros((), dtype=torch.double))
+        rw = torch.zeros(B, H, T, 2 * W + 1, dtype=torch.double)
+        rw.scatter_add_(-1, relc.expand(B, H, T, T), pb)
+        o = o + rw @ rel_v.double()
+    return o.permute(0, 2, 1, 3).reshape(B, T, Cc).float()
+
+
+def check_attention(ops, c, device):
+    g = _g(7 + c["T"])
+    B, T, H, D = c["B"], c["T"], c["H"], c["D"]
+    qkv = torch.randn(B, T, 3 * H * D, generator=g)
+    rel_k = torch.randn(2 * c["W"] + 1, D, generator=g) * D ** -0.5 if c.get("rel") else None
+    rel_v = torch.randn(2 * c["W"] + 1, D, generator=g) * D ** -0.5 if c.get("rel") else None
+    lengths = torch.tensor(c["lengths"], dtype=torch.int32) if "lengths" in c else None
+    scale = D ** -0.5
+    want = attention_reference(qkv, H, scale, rel_k, rel_v, c.get("W", 0), lengths)
+    dev = lambda t: None if t is None else t.to(device)
+    got = ops.attention(dev(qkv), H, scale, rel_k=dev(rel_k), rel_v=dev(rel_v), window=c.get("W", 0), lengths=dev(lengths))
+    if lengths is not None:   # rows past the length are "don't care" in the engine contract? No: they match too.
+        pass
+    _close(got, want, 2e-5, c["id"])
+
+
+def check_snake(ops, n, c, device):
+    g = _g(n * 100 + c)
+    B = 2
+    x = torch.randn(B, n, c, generator=g) * 1.5
+    al, be = torch.randn(c, generator=g) * 0.3, torch.randn(c, generator=g) * 0.3
+    filt = W.kaiser_sinc_filter().view(-1)
+    want = O.snake_alias(x.transpose(1, 2), al, be, filt).transpose(1, 2)
+    got = ops.snake_alias(x.to(device), al.to(device), be.to(device), filt.to(device))
+    _close(got, want, 1e-5, f"snake n={n} c={c}")
+
+
+def check_flow_glue(ops, device):
+    g = _g(11)
+    B, T, H = 2, 13, 8
+    lengths = torch.tensor([13, 6], dtype=torch.int32)
+    mask = (torch.arange(T)[None, :] < lengths[:, None]).float().unsqueeze(-1)
+    a = torch.randn(B, T, 2 * H, generator=g)
+    _close(ops.wn_gate(a.to(device)), torch.tanh(a[..., :H]) * torch.sigmoid(a[..., H:]), 1e-6, "gate")
+    # update, not last
+    rs, x, skip = torch.randn(B, T, 2 * H, generator=g), torch.randn(B, T, H, generator=g), torch.randn(B, T, H, generator=g)
+    xd, sd = x.clone().to(device), skip.clone().to(device)
+    ops.wn_update(rs.to(device), xd, sd, lengths.to(device), first=False, last=False)
+    _close(xd, (x + rs[..., :H]) * mask, 1e-6, "wn x")
+    _close(sd, skip + rs[..., H:], 1e-6, "wn skip")
+    sd = torch.full((B, T, H), 7.0).to(device)
+    ops.wn_update(rs.to(device), x.clone().to(device), sd, lengths.to(device), first=True, last=False)
+    _close(sd, rs[..., H:], 1e-6, "wn skip first")
+    rs1 = torch.randn(B, T, H, generator=g)
+    sd = skip.clone().to(device)
+    ops.wn_update(rs1.to(device), None, sd, lengths.to(device), first=False, last=True)
+    _close(sd, (skip + rs1) * mask, 1e-6, "wn skip last")
+    # coupling
+    half = 6
+    xx = torch.randn(B, T, 2 * half, generator=g)
+    msvs = torch.randn(B, 2 * half, generator=g) * 0.3
+    ms, vs = msvs[:, None, :half], msvs[:, None, half:]
+    for x0_off in (0, half):
+        got = ops.coupling_pre(xx.to(device), x0_off, msvs.to(device), lengths.to(device), half)
+        _close(got, (xx[..., x0_off:x0_off + half] - ms) * torch.exp(-vs) * mask, 1e-6, "coupling pre")
+        m = torch.randn(B, T, half, generator=g) * mask
+        xd = xx.clone().to(device)
+        x1_off = half - x0_off
+        ops.coupling_post(xd, x1_off, m.to(device), msvs.to(device), lengths.to(device), half)
+        want = xx.clone()
+        x1 = (xx[..., x1_off:x1_off + half] - m) * mask
+        want[..., x1_off:x1_off + half] = (ms + x1 * torch.exp(vs)) * mask
+        _close(xd, want, 1e-6, "coupling post")
+
+
+def check_prior_glue(ops, device):
+    g = _g(12)
+    B, T, Cc, I = 2, 37, 8, 12
+    lengths = torch.tensor([37, 20], dtype=torch.int32)
+    mask = (torch.arange(T)[None, :] < lengths[:, None]).float().unsqueeze(-1)
+    x = torch.randn(B, T, Cc, generator=g)
+    pit = torch.cat([torch.zeros(B, 5), torch.rand(B, T - 5, generator=g) * 1200.0], dim=1).round()
+    emb = torch.randn(256, Cc, generator=g)
+    xd = x.clone().to(device)
+    ops.embed_pitch(xd, pit.to(device), emb.to(device), lengths.to(device))
+    _close(xd, (x + emb[O.f0_to_coarse(pit)]) * mask, 1e-6, "embed_pitch")
+    stats = torch.randn(B, T, 2 * I, generator=g) * 0.5
+    noise = torch.randn(B, I, T, generator=g)
+    want = (stats[..., :I] + noise.transpose(1, 2) * torch.exp(stats[..., I:])) * mask
+    _close(ops.sample_prior(stats.to(device), noise.to(device), lengths.to(device)), want, 1e-6, "sample_prior")
+
+
+def check_bridges(ops, device):
+    g = _g(13)
+    B, Cc, T = 2, 80, 45
+    x, n = torch.randn(B, Cc, T, generator=g), torch.randn(B, Cc, T, generator=g)
+    _close(ops.ncl_to_nlc(x.to(device), n.to(device), 0.1), (x + 0.1 * n).transpose(1, 2), 1e-7, "ncl_to_nlc")
+    y = ops.ncl_to_nlc(x[:, :6].contiguous().to(device), ld=8)
+    _close(y[..., :6], x[:, :6].transpose(1, 2), 1e-7, "ncl_to_nlc padded")
+    assert float(y[..., 6:].abs().max()) == 0.0
+    z = torch.randn(B, T, 12, generator=g)
+    _close(ops.nlc_to_ncl(z.to(device), c=10), z[..., :10].transpose(1, 2), 1e-7, "nlc_to_ncl")
+
+
+def check_pitch2source(ops, T, B, device, hop=320):
+    from oracle import config as C
+    from oracle import inputs as I
+    hp = C.base_hp()
+    if hop != 320:
+        hp = C.AttrDict({**C.BASE, "gen": {**C.BASE["gen"], "upsample_rates": [hop], "upsample_kernel_sizes": [2 * hop]}})
+    g = _g(T)
+    f0 = torch.stack([I.synth_f0(T, seed=3 + b, base=200.0 + 150 * b) for b in range(B)])
+    rand_ini = torch.rand(B, 11, generator=g)
+    noise = torch.randn(B, T * hop, 11, generator=g)
+    sd = {"dec.m_source.merge_w": torch.tensor([C.NSF_MERGE_W]), "dec.m_source.merge_b": torch.tensor([C.NSF_MERGE_B])}
+    want = O.pitch2source(sd, hp, f0, rand_ini, noise)[:, 0]
+    got = ops.pitch2source(f0.to(device), rand_ini.to(device), noise.to(device),
+                           sd["dec.m_source.merge_w"].view(-1).to(device), C.NSF_MERGE_B, hop, 32000.0)
+    # the reference accumulates 3.2e5 fp32 adds; re-association is worth ~3e-6
+    _close(got, want, 5e-5, "pitch2source")
+
+
+def check_source2wav(ops, device):
+    g = _g(14)
+    x = torch.cat([torch.randn(1000, generator=g) * 0.6, torch.tensor([1.0, -1.0, 0.99999, 2.0, -2.0, 0.0])])
+    got = ops.source2wav(x.to(device)).cpu()
+    assert torch.equal(got, torch.from_numpy(O.source2wav(x)))

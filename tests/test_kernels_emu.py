@@ -1,0 +1,69 @@
+"""Kernel logic under the CPU SIMT emulator (tests/emu): the SAME csrc/*.hip sources compiled with
+g++ -DSVCMI_EMU, called through the C ABI, checked against torch / the oracle on small shapes.
+This is what `-m "not gpu"` can verify about the HIP kernels without a GPU: tiling, indexing,
+masking, epilogues.  The gpu-marked tests run the identical checks on the real library."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import svc_oracle as O
+from oracle import weights as W
+from tests import kernel_cases as K
+from tests.emu import emu_ops
+
+
+@pytest.fixture(scope="module")
+def ops():
+    return emu_ops()
+
+
+@pytest.mark.parametrize("case", K.CONV_CASES_SMALL, ids=lambda c: c["id"])
+def test_conv_gemm(ops, case):
+    K.check_conv(ops, case, device="cpu")
+
+
+@pytest.mark.parametrize("c", [32, 192, 1280])
+def test_layernorm(ops, c):
+    K.check_layernorm(ops, c, device="cpu")
+
+
+@pytest.mark.parametrize("case", K.ATTN_CASES_SMALL, ids=lambda c: c["id"])
+def test_attention(ops, case):
+    K.check_attention(ops, case, device="cpu")
+
+
+@pytest.mark.parametrize("n,c", [(3, 4), (7, 12), (23, 4), (61, 12), (130, 20)])
+def test_snake_alias(ops, n, c):
+    K.check_snake(ops, n, c, device="cpu")
+
+
+def test_flow_glue(ops):
+    K.check_flow_glue(ops, device="cpu")
+
+
+def test_prior_glue(ops):
+    K.check_prior_glue(ops, device="cpu")
+
+
+def test_layout_bridges(ops):
+    K.check_bridges(ops, device="cpu")
+
+
+@pytest.mark.parametrize("T,B", [(5, 2), (1100, 1)])
+def test_pitch2source(ops, T, B):
+    K.check_pitch2source(ops, T, B, device="cpu", hop=16 if T > 100 else 320)
+
+
+def test_source2wav(ops):
+    K.check_source2wav(ops, device="cpu")
+
+
+def test_argument_errors_are_reported(ops):
+    x = torch.zeros(1, 8, 8)
+    w = torch.zeros(4, 8)
+    with pytest.raises(Exception):
+        ops.conv(x, w, ksize=2)          # ldw < ksize*c_in
+    with pytest.raises(Exception):
+        ops.attention(torch.zeros(1, 4, 3 * 20), heads=1, scale=1.0)   # head_dim 20 unsupported

@@ -1,0 +1,41 @@
+"""Build libsvcmi.so (HIP, gfx950) in-tree:  python whisper-vits-svc_amd/build.py
+
+hipcc cross-compiles without a GPU; the .so lands next to the Python package
+(whisper-vits-svc_amd/svcmi/libsvcmi.so) so it travels with the source tree.
+"""
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "svcmi", "libsvcmi.so")
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def needs_build(out, srcs):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    deps = list(srcs) + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "svcmi.h")]
+    return any(os.path.getmtime(s) > t for s in deps)
+
+
+def build_hip(force=False, verbose=False):
+    srcs = sources()
+    if not force and not needs_build(OUT, srcs):
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", OUT] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build_hip(force="--force" in sys.argv, verbose=True))

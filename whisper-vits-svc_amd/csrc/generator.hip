@@ -1,0 +1,198 @@
+// generator.hip -- NSF-BigVGAN pieces that are not convolutions: the anti-aliased SnakeBeta
+// activation (the dominant cost of the reference CPU path), the harmonic source
+// (SineGen + merge), and the int16 side output.  All are HBM-bound streaming kernels on
+// time-major [batch][len][ld] tensors; a thread owns one channel and a run of RT consecutive samples
+// so the 12-tap polyphase windows are reused from registers (3.25 sin evaluations per output
+// instead of 12) while neighbouring lanes walk neighbouring channels (contiguous bytes).
+#include "svcmi_rt.h"
+#include "../../include/svcmi.h"
+
+namespace {
+
+constexpr int TPB = 256;
+constexpr int RT = 8;   // outputs per thread along time
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+__device__ __forceinline__ float snake_fn(float y, float a, float inv_b) {
+    const float sn = sinf(y * a);
+    return y + inv_b * (sn * sn);
+}
+
+// Border path: s[u] at clamped up-sampled index, straight from global memory.
+__device__ float snake_s_at(const float* xc, int ld, int n, int u, const float* f, float a, float inv_b) {
+    u = clampi(u, 0, 2 * n - 1);
+    const int tq = u >> 1;
+    float y = 0.f;
+    if ((u & 1) == 0) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) y = fmaf(f[2 * j + 1], xc[(long long)clampi(tq + 2 - j, 0, n - 1) * ld], y);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) y = fmaf(f[2 * j], xc[(long long)clampi(tq + 3 - j, 0, n - 1) * ld], y);
+    }
+    return snake_fn(2.f * y, a, inv_b);
+}
+
+__global__ __launch_bounds__(TPB) void snake_alias_kernel(const float* x, float* y, const float* alpha_log,
+                                                          const float* beta_log, const float* filt,
+                                                          int n, int c, int ld) {
+    const int b = blockIdx.y;
+    const long long e = (long long)blockIdx.x * TPB + threadIdx.x;
+    const int ch = (int)(e % c);
+    const long long run = e / c;
+    const long long t0l = run * RT;
+    if (t0l >= n) return;                       // no barriers in this kernel
+    const int t0 = (int)t0l;
+    const float a = expf(alpha_log[ch]);
+    const float inv_b = 1.0f / (expf(beta_log[ch]) + 1e-9f);
+    const float* xc = x + (long long)b * n * ld + ch;
+    float* yc = y + (long long)b * n * ld + ch;
+
+    if (t0 >= 5 && t0 + RT + 4 <= n - 1) {
+        float f[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) f[k] = filt[k];
+        float xw[RT + 10];
+#pragma unroll
+        for (int i = 0; i < RT + 10; ++i) xw[i] = xc[(long long)(t0 - 5 + i) * ld];
+        float s[2 * RT + 10];
+#pragma unroll
+        for (int m = 0; m < RT + 5; ++m) {
+            float yo = 0.f, ye = 0.f;           // i = 2m: odd phase (even taps); i = 2m+1: even phase (odd taps)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                yo = fmaf(f[2 * j], xw[5 - j + m], yo);
+                ye = fmaf(f[2 * j + 1], xw[5 - j + m], ye);
+            }
+            s[2 * m] = snake_fn(2.f * yo, a, inv_b);
+            s[2 * m + 1] = snake_fn(2.f * ye, a, inv_b);
+        }
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            float z = 0.f;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) z = fmaf(f[k], s[2 * r + k], z);
+            yc[(long long)(t0 + r) * ld] = z;
+        }
+    } else {
+        for (int r = 0; r < RT; ++r) {
+            const int t = t0 + r;
+            if (t >= n) break;
+            float z = 0.f;
+            for (int k = 0; k < 12; ++k) z = fmaf(filt[k], snake_s_at(xc, ld, n, 2 * t + k - 5, filt, a, inv_b), z);
+            yc[(long long)t * ld] = z;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ harmonic source
+constexpr int NH = 11;
+
+__device__ __forceinline__ float rad_of(float f0, int k, float sr) {
+    // (f0 * (k+1) / sr) % 1 in fp32, nsf.py:228,293-297
+    return fmodf((f0 * (float)(k + 1)) / sr, 1.0f);
+}
+
+__global__ __launch_bounds__(TPB) void pitch_prefix_kernel(const float* f0, const float* rand_ini, double* prefix,
+                                                           int t, int hop, float sr) {
+    __shared__ float f0s[1024];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    double acc = (tid > 0 && tid < NH) ? (double)rand_ini[b * NH + tid] : 0.0;   // column 0 forced to 0 (:235)
+    for (int base = 0; base < t; base += 1024) {
+        __syncthreads();
+        for (int i = tid; i < 1024; i += TPB) f0s[i] = (base + i < t) ? f0[(long long)b * t + base + i] : 0.f;
+        __syncthreads();
+        if (tid < NH) {
+            const int lim = (t - base) < 1024 ? (t - base) : 1024;
+            for (int i = 0; i < lim; ++i) {
+                prefix[((long long)b * t + base + i) * NH + tid] = acc;
+                acc += (double)hop * (double)rad_of(f0s[i], tid, sr);
+                acc -= floor(acc);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(TPB) void pitch_source_kernel(const float* f0, const double* prefix, const float* noise,
+                                                           const float* merge_w, float merge_b, float* out,
+                                                           int t, int hop, float sr) {
+    const int b = blockIdx.y;
+    const long long L = (long long)t * hop;
+    const long long s = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (s >= L) return;
+    const int fr = (int)(s / hop), j = (int)(s - (long long)fr * hop);
+    const float f0v = f0[(long long)b * t + fr];
+    const float uv = f0v > 0.f ? 1.f : 0.f;
+    const float namp = uv * 0.003f + (1.f - uv) * 0.1f / 3.f;      // nsf.py:310
+    const double* pf = prefix + ((long long)b * t + fr) * NH;
+    const float* nz = noise + ((long long)b * L + s) * NH;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < NH; ++k) {
+        const float rad = rad_of(f0v, k, sr);
+        double ph = pf[k] + (double)(j + 1) * (double)rad;
+        ph -= floor(ph);
+        const float sine = sinf(((float)ph * 2.0f) * 3.14159265358979323846f) * 0.1f;
+        const float hk = sine * uv + namp * nz[k];
+        acc = fmaf(hk, merge_w[k], acc);
+    }
+    out[(long long)b * L + s] = tanhf(acc + merge_b);
+}
+
+__global__ __launch_bounds__(TPB) void source2wav_kernel(const float* x, int16_t* y, long long n) {
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long long)gridDim.x * TPB) {
+        float v = 32768.0f * x[i];
+        v = v < -32768.0f ? -32768.0f : (v > 32767.0f ? 32767.0f : v);
+        y[i] = (int16_t)v;     // torch .short(): truncation toward zero
+    }
+}
+
+}  // namespace
+
+extern "C" int svcmi_snake_alias_f32(const float* x, float* y, const float* alpha_log, const float* beta_log,
+                                     const float* filt, int32_t batch, int32_t len, int32_t c, int32_t ld, void* stream) {
+    if (!x || !y || !alpha_log || !beta_log || !filt || batch <= 0 || len <= 0 || c <= 0 || ld < c) return SVCMI_EINVAL;
+    if (x == y) return SVCMI_EINVAL;            // halo reads: not an in-place op
+    if (batch > 65535) return SVCMI_EUNSUPPORTED;
+    const long long runs = ((long long)len + RT - 1) / RT;
+    const long long threads = runs * c;
+    SVCMI_LAUNCH(snake_alias_kernel, dim3((unsigned)((threads + TPB - 1) / TPB), batch), dim3(TPB), 0, stream, x, y,
+                 alpha_log, beta_log, filt, len, c, ld);
+    return SVCMI_LAST_ERROR();
+}
+
+extern "C" int svcmi_pitch_prefix_f64(const float* f0, const float* rand_ini, double* prefix, int32_t batch, int32_t t,
+                                      int32_t hop, float sr, void* stream) {
+    if (!f0 || !rand_ini || !prefix || batch <= 0 || t <= 0 || hop <= 0 || !(sr > 0.f)) return SVCMI_EINVAL;
+    SVCMI_LAUNCH(pitch_prefix_kernel, dim3(batch), dim3(TPB), 0, stream, f0, rand_ini, prefix, t, hop, sr);
+    return SVCMI_LAST_ERROR();
+}
+
+extern "C" int svcmi_pitch_source_f32(const float* f0, const double* prefix, const float* noise, const float* merge_w,
+                                      float merge_b, float* out, int32_t batch, int32_t t, int32_t hop, float sr, void* stream) {
+    if (!f0 || !prefix || !noise || !merge_w || !out || batch <= 0 || t <= 0 || hop <= 0 || !(sr > 0.f)) return SVCMI_EINVAL;
+    if (batch > 65535) return SVCMI_EUNSUPPORTED;
+    const long long L = (long long)t * hop;
+    SVCMI_LAUNCH(pitch_source_kernel, dim3((unsigned)((L + TPB - 1) / TPB), batch), dim3(TPB), 0, stream, f0, prefix, noise,
+                 merge_w, merge_b, out, t, hop, sr);
+    return SVCMI_LAST_ERROR();
+}
+
+extern "C" int svcmi_source2wav_i16(const float* x, int16_t* y, int64_t n, void* stream) {
+    if (!x || !y || n <= 0) return SVCMI_EINVAL;
+    long long nb = (n + TPB - 1) / TPB;
+    if (nb > 2048) nb = 2048;
+    SVCMI_LAUNCH(source2wav_kernel, dim3((unsigned)nb), dim3(TPB), 0, stream, x, y, (long long)n);
+    return SVCMI_LAST_ERROR();
+}
+
+extern "C" int svcmi_abi_version(void) { return SVCMI_ABI_VERSION; }
+
+extern "C" const char* svcmi_build_info(void) {
+#ifdef SVCMI_EMU
+    return "emu";
+#else
+    return "hip:gfx950";
+#endif
+}

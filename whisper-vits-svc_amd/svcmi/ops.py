@@ -1,0 +1,200 @@
+"""Thin tensor-level wrappers over the C ABI (include/svcmi.h).
+
+PyTorch is used for device memory and streams only.  Activations are time-major fp32 tensors
+``[B, T, C]`` (contiguous, ``C % 4 == 0``); see DESIGN.md for the layout rationale.  Every method
+launches one kernel on the current stream and returns its output tensor.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_GELU, ACT_MISH, ACT_NONE, ACT_RELU, ACT_TANH, CONV_ACCUMULATE, CONV_MASK_IN,  # noqa: F401
+                   CONV_MASK_OUT, ConvDesc, SvcmiError)
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+class Ops:
+    """Bound to one loaded library.  ``Ops()`` loads the hipcc-built libsvcmi.so and requires CUDA(HIP)
+    tensors; there is no CPU path in the product (tests/emu builds a separate emulation library from the
+    same kernel source and passes it in explicitly)."""
+
+    def __init__(self, lib=None):
+        self.lib = lib if lib is not None else _lib.load_library()
+        self.build = self.lib.svcmi_build_info().decode()
+        self.on_gpu = self.build.startswith("hip")
+        if self.on_gpu and not torch.cuda.is_available():
+            raise SvcmiError("libsvcmi.so is the gfx950 build but no GPU is visible; svcmi has no CPU fallback")
+        self.launches = 0
+
+    # ------------------------------------------------------------------ plumbing
+    def _stream(self):
+        return torch.cuda.current_stream().cuda_stream if self.on_gpu else 0
+
+    def _chk(self, *tensors):
+        for t in tensors:
+            if t is None:
+                continue
+            if t.is_cuda != self.on_gpu:
+                raise SvcmiError(f"tensor on {t.device} but library build is {self.build}")
+
+    def _call(self, name, *args):
+        rc = getattr(self.lib, name)(*args)
+        self.launches += 1
+        if rc != 0:
+            raise SvcmiError(f"{name} failed with code {rc}")
+
+    def empty(self, *shape, like=None, dtype=torch.float32):
+        return torch.empty(*shape, dtype=dtype, device=like.device if like is not None else ("cuda" if self.on_gpu else "cpu"))
+
+    # ------------------------------------------------------------------ conv / linear
+    def conv(self, x, w, bias=None, *, ksize=1, stride=1, dilation=1, pad=0, t_out=None, act=ACT_NONE,
+             res=None, alpha=1.0, accumulate=False, lengths=None, mask_in=False, mask_out=False, out=None,
+             x_row_shift=0, c_in=None, ldx=None, t_in=None, n_out=None, x_bstride=None, tile=0):
+        """y[b,t,n] = epilogue(sum_k sum_ci x[b, t*stride + k*dilation - pad, ci] * w[n, k*c_in + ci]).
+        ``x`` is [B, T, C]; ``w`` is [N, ldw] packed (weights.pack_conv)."""
+        self._chk(x, w, bias, res, out, lengths)
+        B = x.shape[0]
+        if t_in is None:
+            t_in = x.shape[1] << x_row_shift
+        if ldx is None:
+            ldx = x.shape[2] if x.dim() == 3 else 1
+        if c_in is None:
+            c_in = ldx
+        if x_bstride is None:
+            x_bstride = x.stride(0)
+        N = w.shape[0] if n_out is None else n_out
+        if t_out is None:
+            t_out = (t_in + 2 * pad - dilation * (ksize - 1) - 1) // stride + 1
+        if out is None:
+            out = torch.empty(B, t_out, N, dtype=torch.float32, device=x.device)
+        d = ConvDesc()
+        d.x, d.w, d.bias, d.res, d.y, d.lengths = _ptr(x), _ptr(w), _ptr(bias), _ptr(res), _ptr(out), _ptr(lengths)
+        d.x_bstride, d.y_bstride = x_bstride, out.stride(0)
+        d.res_bstride = res.stride(0) if res is not None else 0
+        d.batch, d.t_in, d.t_out, d.c_in, d.ldx = B, t_in, t_out, c_in, ldx
+        d.n_out, d.ldw, d.ldy = N, w.shape[1], out.stride(1)
+        d.ldr = res.stride(1) if res is not None else 0
+        d.ksize, d.stride, d.dilation, d.pad, d.x_row_shift = ksize, stride, dilation, pad, x_row_shift
+        d.act = act
+        d.flags = (CONV_ACCUMULATE if accumulate else 0) | (CONV_MASK_IN if mask_in else 0) | (CONV_MASK_OUT if mask_out else 0) | (tile << 8)
+        d.alpha = alpha
+        self._call("svcmi_conv_gemm_f32", ctypes.byref(d), self._stream())
+        return out
+
+    # ------------------------------------------------------------------ norm / attention
+    def layernorm(self, x, gamma=None, beta=None, *, res=None, eps=1e-5, per_batch_affine=False, out=None):
+        self._chk(x, gamma, beta, res, out)
+        B, T, Cc = x.shape
+        if out is None:
+            out = torch.empty_like(x)
+        self._call("svcmi_layernorm_f32", _ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(out), B, T, Cc,
+                   x.stride(1), res.stride(1) if res is not None else 0, out.stride(1),
+                   Cc if per_batch_affine else 0, eps, self._stream())
+        return out
+
+    def attention(self, qkv, heads, scale, *, rel_k=None, rel_v=None, window=0, lengths=None, out=None):
+        """qkv: [B, T, 3*C] fused projection (q | k | v).  Returns [B, T, C]."""
+        self._chk(qkv, rel_k, rel_v, lengths, out)
+        B, T, C3 = qkv.shape
+        Cc = C3 // 3
+        if out is None:
+            out = torch.empty(B, T, Cc, dtype=torch.float32, device=qkv.device)
+        base = qkv.data_ptr()
+        bs = qkv.stride(0)
+        self._call("svcmi_attention_f32", base, base + 4 * Cc, base + 8 * Cc, _ptr(out), C3, C3, C3, out.stride(1),
+                   bs, bs, bs, out.stride(0), B, T, heads, Cc // heads, scale, _ptr(rel_k), _ptr(rel_v), window,
+                   _ptr(lengths), self._stream())
+        return out
+
+    # ------------------------------------------------------------------ generator pieces
+    def snake_alias(self, x, alpha_log, beta_log, filt, out=None):
+        self._chk(x, alpha_log, beta_log, filt, out)
+        B, L, Cc = x.shape
+        if out is None:
+            out = torch.empty_like(x)
+        self._call("svcmi_snake_alias_f32", _ptr(x), _ptr(out), _ptr(alpha_log), _ptr(beta_log), _ptr(filt),
+                   B, L, Cc, x.stride(1), self._stream())
+        return out
+
+    def pitch2source(self, f0, rand_ini, noise, merge_w, merge_b, hop, sr):
+        """f0 [B,T], rand_ini [B,11], noise [B,T*hop,11] -> source [B, T*hop]."""
+        self._chk(f0, rand_ini, noise, merge_w)
+        B, T = f0.shape
+        prefix = torch.empty(B, T, 11, dtype=torch.float64, device=f0.device)
+        self._call("svcmi_pitch_prefix_f64", _ptr(f0), _ptr(rand_ini), _ptr(prefix), B, T, hop, float(sr), self._stream())
+        out = torch.empty(B, T * hop, dtype=torch.float32, device=f0.device)
+        self._call("svcmi_pitch_source_f32", _ptr(f0), _ptr(prefix), _ptr(noise), _ptr(merge_w), float(merge_b),
+                   _ptr(out), B, T, hop, float(sr), self._stream())
+        return out
+
+    def source2wav(self, x):
+        self._chk(x)
+        x = x.contiguous()
+        out = torch.empty(x.shape, dtype=torch.int16, device=x.device)
+        self._call("svcmi_source2wav_i16", _ptr(x), _ptr(out), x.numel(), self._stream())
+        return out
+
+    # ------------------------------------------------------------------ flow / prior glue
+    def wn_gate(self, a, out=None):
+        self._chk(a, out)
+        B, T, H2 = a.shape
+        H = H2 // 2
+        if out is None:
+            out = torch.empty(B, T, H, dtype=torch.float32, device=a.device)
+        self._call("svcmi_wn_gate_f32", _ptr(a), _ptr(out), B * T, H, a.stride(1), out.stride(1), self._stream())
+        return out
+
+    def wn_update(self, rs, x, skip, lengths, first, last):
+        self._chk(rs, x, skip, lengths)
+        B, T, H = skip.shape
+        self._call("svcmi_wn_update_f32", _ptr(rs), _ptr(x), _ptr(skip), _ptr(lengths), B, T, H, rs.stride(1),
+                   int(first), int(last), self._stream())
+
+    def coupling_pre(self, x, x0_off, ms_vs, lengths, half):
+        self._chk(x, ms_vs, lengths)
+        B, T, _ = x.shape
+        out = torch.empty(B, T, half, dtype=torch.float32, device=x.device)
+        self._call("svcmi_coupling_pre_f32", _ptr(x), x.stride(1), x0_off, _ptr(ms_vs), _ptr(out), half, _ptr(lengths),
+                   B, T, half, self._stream())
+        return out
+
+    def coupling_post(self, x, x1_off, m, ms_vs, lengths, half):
+        self._chk(x, m, ms_vs, lengths)
+        B, T, _ = x.shape
+        self._call("svcmi_coupling_post_f32", _ptr(x), x.stride(1), x1_off, _ptr(m), m.stride(1), _ptr(ms_vs),
+                   _ptr(lengths), B, T, half, self._stream())
+
+    def embed_pitch(self, x, pit, emb, lengths):
+        self._chk(x, pit, emb, lengths)
+        B, T, Cc = x.shape
+        self._call("svcmi_embed_pitch_f32", _ptr(x), x.stride(1), _ptr(pit), _ptr(emb), _ptr(lengths), B, T, Cc, self._stream())
+
+    def sample_prior(self, stats, noise_ncl, lengths):
+        self._chk(stats, noise_ncl, lengths)
+        B, T, I2 = stats.shape
+        I = I2 // 2
+        z = torch.empty(B, T, I, dtype=torch.float32, device=stats.device)
+        self._call("svcmi_sample_prior_f32", _ptr(stats), stats.stride(1), _ptr(noise_ncl), _ptr(lengths), _ptr(z), I,
+                   B, T, I, self._stream())
+        return z
+
+    def ncl_to_nlc(self, x, add=None, add_scale=0.0, ld=None):
+        self._chk(x, add)
+        B, Cc, T = x.shape
+        ld = ld or Cc
+        y = torch.empty(B, T, ld, dtype=torch.float32, device=x.device) if ld == Cc else \
+            torch.zeros(B, T, ld, dtype=torch.float32, device=x.device)
+        self._call("svcmi_ncl_to_nlc_f32", _ptr(x), _ptr(add), float(add_scale), _ptr(y), B, Cc, T, ld, self._stream())
+        return y
+
+    def nlc_to_ncl(self, x, c=None):
+        self._chk(x)
+        B, T, ld = x.shape
+        c = c or ld
+        y = torch.empty(B, c, T, dtype=torch.float32, device=x.device)
+        self._call("svcmi_nlc_to_ncl_f32", _ptr(x), x.stride(1), _ptr(y), B, c, T, self._stream())
+        return y
