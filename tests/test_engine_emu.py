@@ -1,0 +1,22 @@
+"""The whole svcmi facade (weight packing, Flip folding, polyphase transposed convs, chunk driver)
+executed on the CPU SIMT emulator at the tiny configuration and compared with the golden vectors of
+the real reference.  Slow-ish (fibers), sized to stay within the CPU test budget."""
+import pytest
+
+from oracle import config as C
+from tests import engine_cases as E
+from tests.emu import emu_ops
+
+
+@pytest.fixture(scope="module")
+def ops():
+    return emu_ops()
+
+
+def test_vits_tiny_ragged_matches_reference_golden(ops):
+    errs = E.check_vits_golden(ops, "cpu", "vits_tiny_ragged", C.tiny_hp())
+    print(errs)
+
+
+def test_whisper_tiny_matches_reference_golden(ops):
+    print(E.check_whisper_golden(ops, "cpu", "whisper_tiny", C.WHISPER_TINY_TEST))

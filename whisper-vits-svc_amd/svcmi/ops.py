@@ -74,10 +74,10 @@ class Ops:
         d = ConvDesc()
         d.x, d.w, d.bias, d.res, d.y, d.lengths = _ptr(x), _ptr(w), _ptr(bias), _ptr(res), _ptr(out), _ptr(lengths)
         d.x_bstride, d.y_bstride = x_bstride, out.stride(0)
-        d.res_bstride = res.stride(0) if res is not None else 0
+        d.res_bstride = res.stride(0) if (res is not None and res.dim() == 3) else 0   # 2-D res is shared by the batch
         d.batch, d.t_in, d.t_out, d.c_in, d.ldx = B, t_in, t_out, c_in, ldx
         d.n_out, d.ldw, d.ldy = N, w.shape[1], out.stride(1)
-        d.ldr = res.stride(1) if res is not None else 0
+        d.ldr = res.stride(-2) if res is not None else 0
         d.ksize, d.stride, d.dilation, d.pad, d.x_row_shift = ksize, stride, dilation, pad, x_row_shift
         d.act = act
         d.flags = (CONV_ACCUMULATE if accumulate else 0) | (CONV_MASK_IN if mask_in else 0) | (CONV_MASK_OUT if mask_out else 0) | (tile << 8)
@@ -93,7 +93,7 @@ class Ops:
             out = torch.empty_like(x)
         self._call("svcmi_layernorm_f32", _ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(out), B, T, Cc,
                    x.stride(1), res.stride(1) if res is not None else 0, out.stride(1),
-                   Cc if per_batch_affine else 0, eps, self._stream())
+                   (gamma.stride(0) if gamma is not None else beta.stride(0)) if per_batch_affine else 0, eps, self._stream())
         return out
 
     def attention(self, qkv, heads, scale, *, rel_k=None, rel_v=None, window=0, lengths=None, out=None):

@@ -1,0 +1,109 @@
+"""Drop-in for the synthesis driver of the reference's svc_inference.py (:61-134): same function names,
+argument order and results, with the chunk loop kept on the device.
+
+    model = SynthesizerInfer(hp.data.filter_length // 2 + 1, hp.data.segment_size // hp.data.hop_length, hp)
+    load_svc_model(path, model); model.eval(); model.to("cuda")
+    out = svc_infer(model, retrieval, spk, pit, ppg, vec, hp, "cuda")       # np.float32 [320*T - 1]
+
+Reference behaviours that are preserved on purpose: inputs truncated to the shortest of pit/vec/ppg (:78-85);
+2500-frame chunks with a 10-frame halo that is computed and discarded (:94-131) -- attention is global within
+a chunk, so the schedule is part of the numerics; the final sample is dropped because the last chunk uses
+``cut_e_out = -1`` (:112,129); ``svc_out_pit.wav`` side output (:91-92).
+"""
+import os
+
+import numpy as np
+import torch
+
+from .vits import consts as K
+
+
+class IRetrieval:
+    """feature_retrieval/retrieval.py:11-28 hook: per-chunk transform of the content features."""
+
+    def retriv_whisper(self, vec):
+        raise NotImplementedError
+
+    def retriv_hubert(self, vec):
+        raise NotImplementedError
+
+
+class DummyRetrieval(IRetrieval):
+    """svc_inference.py:25-28 default: identity (the reference clones to CPU; the engine keeps the
+    chunk on the device since nothing is changed)."""
+
+    def retriv_whisper(self, vec):
+        return vec
+
+    def retriv_hubert(self, vec):
+        return vec
+
+
+def load_svc_model(checkpoint_path, model):
+    """svc_inference.py:61-74: tolerant load of ``ckpt["model_g"]`` -- keys absent from the checkpoint keep
+    the model's current value and are reported, exactly like the reference."""
+    assert os.path.isfile(checkpoint_path)
+    checkpoint_dict = torch.load(checkpoint_path, map_location="cpu")
+    saved = checkpoint_dict["model_g"]
+    state = model.state_dict()
+    new_state = {}
+    for k, v in state.items():
+        if k in saved:
+            new_state[k] = saved[k]
+        else:
+            print("%s is not in the checkpoint" % k)
+            new_state[k] = v
+    model.load_state_dict(new_state)
+    return model
+
+
+def chunk_schedule(all_frame, hop_size, out_chunk=K.CHUNK_FRAMES, hop_frame=K.HALO_FRAMES):
+    """(cut_s, cut_e, cut_s_out, cut_e_out) per chunk -- the arithmetic of svc_inference.py:101-115."""
+    plan, out_index = [], 0
+    while out_index < all_frame:
+        if out_index == 0:
+            cut_s, cut_s_out = 0, 0
+        else:
+            cut_s, cut_s_out = out_index - hop_frame, hop_frame * hop_size
+        if out_index + out_chunk + hop_frame > all_frame:
+            cut_e, cut_e_out = all_frame, -1
+        else:
+            cut_e, cut_e_out = out_index + out_chunk + hop_frame, -1 * hop_frame * hop_size
+        plan.append((cut_s, cut_e, cut_s_out, cut_e_out))
+        out_index += out_chunk
+    return plan
+
+
+@torch.no_grad()
+def svc_infer(model, retrieval, spk, pit, ppg, vec, hp, device, noise=None, write_pit_wav=True, return_tensor=False):
+    """svc_inference.py:77-134.  spk [spk_dim], pit [T] Hz, ppg [T, ppg_dim], vec [T, vec_dim] (already
+    repeated x2 to 100 fps, :175-182).  ``noise`` (optional, for reproducible runs) =
+    {"rand_ini": [1,11], "src_noise": [1,L,11], "enc_noises": [[1,inter,len_i] per chunk]}.
+    Returns np.float32 [hop*T - 1] (or the device tensor with ``return_tensor``)."""
+    dev = torch.device(device)
+    n = min(pit.shape[0], vec.shape[0], ppg.shape[0])
+    pit = pit[:n].to(dev, torch.float32)
+    vec = vec[:n].to(dev, torch.float32)
+    ppg = ppg[:n].to(dev, torch.float32)
+    spk = spk.to(dev, torch.float32).unsqueeze(0)
+    src_noise = None if noise is None else (noise["rand_ini"], noise["src_noise"])
+    source = model.pitch2source(pit.unsqueeze(0), noise=src_noise)
+    if write_pit_wav:
+        from scipy.io.wavfile import write
+        write("svc_out_pit.wav", hp.data.sampling_rate, model.source2wav(source))
+    hop = hp.data.hop_length
+    retrieval = retrieval if retrieval is not None else DummyRetrieval()
+    passthrough = isinstance(retrieval, DummyRetrieval)
+    pieces = []
+    for i, (cs, ce, cso, ceo) in enumerate(chunk_schedule(n, hop)):
+        sub_ppg, sub_vec = ppg[cs:ce], vec[cs:ce]
+        if not passthrough:      # user hook works on CPU tensors (feature_retrieval/retrieval.py:11-28)
+            sub_ppg = retrieval.retriv_whisper(sub_ppg.cpu()).to(dev)
+            sub_vec = retrieval.retriv_hubert(sub_vec.cpu()).to(dev)
+        sub_len = torch.tensor([ce - cs], dtype=torch.int64)
+        enc_noise = None if noise is None else noise["enc_noises"][i]
+        sub_out = model.inference(sub_ppg.unsqueeze(0), sub_vec.unsqueeze(0), pit[cs:ce].unsqueeze(0), spk, sub_len,
+                                  source[:, :, cs * hop:ce * hop], noise=enc_noise)
+        pieces.append(sub_out[0, 0, cso:ceo])
+    out = torch.cat(pieces)
+    return out if return_tensor else out.cpu().numpy()

@@ -1,0 +1,209 @@
+"""Drop-in ``SynthesizerInfer`` (reference: vits/models.py:211-256) running on the svcmi HIP kernels.
+
+Same constructor, ``state_dict``/``load_state_dict`` key names, ``eval``/``to``, ``pitch2source``,
+``source2wav`` and ``inference`` signatures and tensor layouts as the reference class, so
+``svc_inference.py``-style callers need no change.  Differences, all additive:
+  * the three stochastic draws of the path (vits/models.py:51, vits_decoder/nsf.py:232-235,311) can be
+    passed explicitly (``noise=...``) so runs are reproducible / comparable; when omitted they are drawn
+    with torch's generator on the device, as the reference does;
+  * there is no autograd and no CPU path: without the gfx950 library construction of ``Ops`` raises.
+Internally everything is time-major ``[B, T, C]`` fp32.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+
+from .. import weights as PW
+from ..ops import ACT_MISH, ACT_NONE, ACT_RELU, ACT_TANH, Ops
+from . import consts as K
+from .spec import default_state_dict, param_shapes
+
+
+class SynthesizerInfer:
+    def __init__(self, spec_channels, segment_size, hp, ops=None):
+        self.spec_channels, self.segment_size, self.hp = spec_channels, segment_size, hp
+        self._ops = ops
+        self._sd = None          # CPU state dict (reference key names)
+        self._w = None           # packed device weights
+        self._device = None
+        self.training = False
+
+    # ------------------------------------------------------------------ nn.Module-like surface
+    @property
+    def ops(self):
+        if self._ops is None:
+            self._ops = Ops()    # raises if libsvcmi.so / GPU is missing: no fallback
+        return self._ops
+
+    def state_dict(self):
+        if self._sd is None:
+            self._sd = default_state_dict(self.hp)
+        return OrderedDict(self._sd)
+
+    def load_state_dict(self, sd, strict=True):
+        want = param_shapes(self.hp)
+        missing = [k for k in want if k not in sd]
+        unexpected = [k for k in sd if k not in want]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"load_state_dict: missing {missing[:5]}... unexpected {unexpected[:5]}...")
+        new = default_state_dict(self.hp) if missing else OrderedDict()
+        for k, shape in want.items():
+            if k in sd:
+                t = sd[k].detach().float().cpu()
+                if tuple(t.shape) != tuple(shape):
+                    raise RuntimeError(f"size mismatch for {k}: {tuple(t.shape)} vs {tuple(shape)}")
+                new[k] = t
+        self._sd = OrderedDict((k, new[k]) for k in want)
+        self._w = None
+        return self
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError("svcmi is an inference engine")
+        return self
+
+    def to(self, device):
+        self._device = torch.device(device)
+        self._w = None
+        return self
+
+    def remove_weight_norm(self):
+        """Weight-norm is folded at pack time; kept for API parity (the reference's own method raises,
+        vits/models.py:96-98)."""
+        return None
+
+    def parameters(self):
+        return iter(self.state_dict().values())
+
+    def _weights(self):
+        if self._w is None:
+            dev = self._device or torch.device("cuda" if self.ops.on_gpu else "cpu")
+            self._w = PW.VitsWeights(self.state_dict(), self.hp, dev)
+            self._device = dev
+        return self._w
+
+    # ------------------------------------------------------------------ reference methods
+    def pitch2source(self, f0, noise=None):
+        """f0 [B,T] Hz -> harmonic source [B,1,320*T] (vits_decoder/generator.py:160-165).
+        ``noise`` = (rand_ini [B,11], randn [B,L,11]) to pin the draws of nsf.py:232-235,311."""
+        w, ops = self._weights(), self.ops
+        f0 = f0.to(self._device, torch.float32).contiguous()
+        B, T = f0.shape
+        L = T * w.hop
+        if noise is None:
+            rand_ini = torch.rand(B, K.NSF_HARMONICS, device=f0.device)
+            nz = torch.randn(B, L, K.NSF_HARMONICS, device=f0.device)
+        else:
+            rand_ini, nz = (t.to(self._device, torch.float32).contiguous() for t in noise)
+        src = ops.pitch2source(f0, rand_ini, nz, w.merge_w, w.merge_b, w.hop, float(self.hp.data.sampling_rate))
+        return src.view(B, 1, L)
+
+    def source2wav(self, source):
+        """-> int16 numpy (vits_decoder/generator.py:167-173)."""
+        return self.ops.source2wav(source.to(self._device, torch.float32).squeeze()).cpu().numpy()
+
+    @torch.no_grad()
+    def inference(self, ppg, vec, pit, spk, ppg_l, source, noise=None, return_parts=False):
+        """vits/models.py:251-256.  ppg [B,T,ppg_dim], vec [B,T,vec_dim], pit [B,T] Hz, spk [B,spk_dim],
+        ppg_l int64 [B], source [B,1,hop*T] -> waveform [B,1,hop*T] (device tensor).
+        ``noise``: the randn_like(m) of vits/models.py:51 in the reference layout [B,inter,T]."""
+        w, ops, dev = self._weights(), self.ops, None
+        dev = self._device
+        ppg = ppg.to(dev, torch.float32).contiguous()
+        vec = vec.to(dev, torch.float32).contiguous()
+        pit = pit.to(dev, torch.float32).contiguous()
+        spk = spk.to(dev, torch.float32).contiguous()
+        lengths = ppg_l.to(dev, torch.int32).contiguous()
+        B, T, _ = ppg.shape
+        source = source.to(dev, torch.float32).contiguous().view(B, T * w.hop)
+        if noise is None:
+            noise = torch.randn(B, w.I, T, device=dev)
+        noise = noise.to(dev, torch.float32).contiguous()
+        z_p = self._prior_encoder(w, ops, ppg, vec, pit, lengths, noise)
+        z = self._flow_reverse(w, ops, z_p.clone() if return_parts else z_p, spk, lengths)
+        o = self._generator(w, ops, z, spk, source)
+        if return_parts:
+            return o, {"z_p": ops.nlc_to_ncl(z_p), "z": ops.nlc_to_ncl(z)}
+        return o
+
+    __call__ = inference
+
+    # ------------------------------------------------------------------ stages (time-major)
+    def _prior_encoder(self, w, ops, ppg, vec, pit, lengths, noise, ppg_row_shift=0):
+        """TextEncoder.forward, vits/models.py:39-52 + attentions.Encoder.forward, attentions.py:60-72."""
+        x = ops.conv(ppg, w.pre_w, w.pre_b, ksize=5, pad=2, lengths=lengths, mask_out=True, x_row_shift=ppg_row_shift)
+        ops.conv(vec, w.hub_w, w.hub_b, ksize=5, pad=2, res=x, lengths=lengths, mask_out=True, out=x)
+        ops.embed_pitch(x, pit, w.pit_emb, lengths)
+        scale = 1.0 / math.sqrt(w.H // w.n_heads)
+        for L in w.enc:
+            qkv = ops.conv(x, L["qkv_w"], L["qkv_b"])
+            a = ops.attention(qkv, w.n_heads, scale, rel_k=L["rel_k"], rel_v=L["rel_v"], window=K.ENC_WINDOW, lengths=lengths)
+            y = ops.conv(a, L["o_w"], L["o_b"])
+            x = ops.layernorm(x, L["g1"], L["b1"], res=y)
+            pl = (K.ENC_FFN_KERNEL - 1) // 2
+            h = ops.conv(x, L["f1_w"], L["f1_b"], ksize=K.ENC_FFN_KERNEL, pad=pl, act=ACT_RELU, lengths=lengths, mask_in=True, mask_out=True)
+            y = ops.conv(h, L["f2_w"], L["f2_b"], ksize=K.ENC_FFN_KERNEL, pad=pl, lengths=lengths, mask_out=True)
+            x = ops.layernorm(x, L["g2"], L["b2"], res=y)
+        stats = ops.conv(x, w.proj_w, w.proj_b, lengths=lengths, mask_in=True, mask_out=True)
+        return ops.sample_prior(stats, noise, lengths)
+
+    def _flow_reverse(self, w, ops, x, spk, lengths):
+        """ResidualCouplingBlock.forward(reverse=True), vits/models.py:89-94; layers vits/modules.py:288-321,178-203.
+        ``x`` [B,T,I] is updated in place."""
+        B, T, _ = x.shape
+        spk3 = spk.view(B, 1, -1)
+        half = w.half
+        skip = torch.empty(B, T, w.H, dtype=torch.float32, device=x.device)
+        for Lr in w.flow:
+            msvs = ops.conv(spk3, Lr["snac_w"], Lr["snac_b"]).view(B, 2 * half)
+            x0n = ops.coupling_pre(x, Lr["x0_off"], msvs, lengths, half)
+            h = ops.conv(x0n, Lr["pre_w"], Lr["pre_b"], lengths=lengths, mask_out=True)
+            n = len(Lr["wn"])
+            for l, Wl in enumerate(Lr["wn"]):
+                a = ops.conv(h, Wl["in_w"], Wl["in_b"], ksize=K.FLOW_KERNEL, pad=(K.FLOW_KERNEL - 1) // 2)
+                acts = ops.wn_gate(a)
+                rs = ops.conv(acts, Wl["rs_w"], Wl["rs_b"])
+                ops.wn_update(rs, h, skip, lengths, first=(l == 0), last=(l == n - 1))
+            m = ops.conv(skip, Lr["post_w"], Lr["post_b"], lengths=lengths, mask_out=True)
+            ops.coupling_post(x, Lr["x1_off"], m, msvs, lengths, half)
+        return x
+
+    def _generator(self, w, ops, z, spk, source):
+        """Generator.inference, vits_decoder/generator.py:175-200 (+ SpeakerAdapter :36-47, AMPBlock bigv.py:50-58).
+        z [B,T,U] time-major, source [B, hop*T] -> [B,1,hop*T]."""
+        B, T, U = z.shape
+        sb = ops.conv(spk.view(B, 1, -1), w.ad_w, w.ad_b).view(B, 2 * U)
+        x = ops.layernorm(z, sb[:, :U], sb[:, U:], per_batch_affine=True)
+        x = ops.conv(x, w.pre_conv_w, w.pre_conv_b, ksize=7, pad=3, act=ACT_MISH)
+        for st in w.stages:
+            t_in = x.shape[1]
+            y = ops.conv(x, st["up_w"], st["up_b"], ksize=st["up_taps"], pad=st["up_pad"], t_out=t_in)
+            y = y.view(B, t_in * st["u"], st["cp"])
+            ops.conv(source, st["nz_w"], st["nz_b"], ksize=st["nz_k"], stride=st["nz_stride"], pad=st["nz_pad"],
+                     c_in=1, ldx=1, t_in=source.shape[1], t_out=y.shape[1], accumulate=True, out=y,
+                     x_bstride=source.stride(0))
+            acc = torch.empty_like(y)
+            xj = torch.empty_like(y)
+            nb = len(st["blocks"])
+            for j, blk in enumerate(st["blocks"]):
+                k = blk["k"]
+                xc = y
+                for q, d in enumerate(blk["d"]):
+                    a = ops.snake_alias(xc, blk["a1"][q][0], blk["a1"][q][1], w.filt)
+                    b = ops.conv(a, blk["c1"][q][0], blk["c1"][q][1], ksize=k, dilation=d, pad=(k * d - d) // 2)
+                    a2 = ops.snake_alias(b, blk["a2"][q][0], blk["a2"][q][1], w.filt, out=a)
+                    if q < len(blk["d"]) - 1:
+                        ops.conv(a2, blk["c2"][q][0], blk["c2"][q][1], ksize=k, pad=(k - 1) // 2, res=xc, out=xj)
+                        xc = xj
+                    else:   # last iteration: (conv + x)/3 accumulated into the stage output (generator.py:188-194)
+                        ops.conv(a2, blk["c2"][q][0], blk["c2"][q][1], ksize=k, pad=(k - 1) // 2, res=xc,
+                                 alpha=1.0 / nb, accumulate=(j > 0), out=acc)
+            x = acc
+        a = ops.snake_alias(x, w.post_a[0], w.post_a[1], w.filt)
+        o = ops.conv(a, w.post_w, None, ksize=7, pad=3, act=ACT_TANH, n_out=1)
+        return o.view(B, 1, -1)

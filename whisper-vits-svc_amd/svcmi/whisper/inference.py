@@ -1,0 +1,109 @@
+"""Drop-in for the reference's whisper/inference.py: ``load_model`` / ``pred_ppg`` on svcmi kernels.
+
+``load_model(path, device)`` consumes the OpenAI checkpoint format ``{"dims", "model_state_dict"}`` and,
+like whisper/inference.py:11-29, keeps only the audio encoder truncated to the first 3/4 of its blocks
+(24 of 32 for large-v2).  The returned object exposes ``.encoder(mel[B,80,n]) -> [B, ceil(n/2), state]``.
+Arithmetic is fp32 (the reference runs fp16 on CUDA, fp32 on CPU -- :22-23; fp32 is the parity default,
+SURVEY.md section 0).
+"""
+import numpy as np
+import torch
+
+from .. import weights as PW
+from ..ops import ACT_GELU, Ops
+from ..vits import consts as K
+
+
+class AudioEncoder:
+    """whisper/model.py:132-163 (conv stem + pre-LN attention blocks + ln_post), time-major fp32."""
+
+    def __init__(self, w, ops):
+        self.w, self.ops = w, ops
+
+    @torch.no_grad()
+    def __call__(self, mel, noise=None, noise_scale=0.1):
+        w, ops = self.w, self.ops
+        dev = w.lnp_g.device
+        mel = mel.to(dev, torch.float32).contiguous()
+        if noise is not None:
+            noise = noise.to(dev, torch.float32).contiguous()
+        x = ops.ncl_to_nlc(mel, noise, noise_scale if noise is not None else 0.0)          # [B, n, 80]
+        x = ops.conv(x, w.conv1_w, w.conv1_b, ksize=3, pad=1, act=ACT_GELU)               # model.py:150
+        n = x.shape[1]
+        tw = (n + 2 - 3) // 2 + 1
+        if tw > w.pos.shape[0]:
+            raise AssertionError("incorrect audio shape")                                   # model.py:156
+        x = ops.conv(x, w.conv2_w, w.conv2_b, ksize=3, stride=2, pad=1, act=ACT_GELU, res=w.pos[:tw])  # :151-158
+        scale = float(w.S // w.heads) ** -0.5          # (d^-0.25 on q) * (d^-0.25 on k), model.py:90-92
+        for blk in w.blocks:                            # model.py:118-129
+            h = ops.layernorm(x, blk["ln1_g"], blk["ln1_b"])
+            qkv = ops.conv(h, blk["qkv_w"], blk["qkv_b"])
+            a = ops.attention(qkv, w.heads, scale)
+            ops.conv(a, blk["o_w"], blk["o_b"], res=x, out=x)
+            h = ops.layernorm(x, blk["ln2_g"], blk["ln2_b"], out=h)
+            m = ops.conv(h, blk["m1_w"], blk["m1_b"], act=ACT_GELU)
+            ops.conv(m, blk["m2_w"], blk["m2_b"], res=x, out=x)
+        return ops.layernorm(x, w.lnp_g, w.lnp_b)
+
+
+class WhisperEncoderModel:
+    """What ``load_model`` returns: the reference returns a ``Whisper`` whose decoder was deleted; callers
+    only touch ``.encoder`` (whisper/inference.py:47,59)."""
+
+    def __init__(self, ckpt, device, ops=None):
+        self.ops = ops if ops is not None else Ops()
+        self.weights = PW.WhisperWeights(ckpt, device)
+        self.dims = self.weights.dims
+        self.encoder = AudioEncoder(self.weights, self.ops)
+        self.device = torch.device(device)
+
+    def eval(self):
+        return self
+
+    def embed_audio(self, mel):
+        return self.encoder(mel)
+
+
+def load_model(path, device, ops=None):
+    """whisper/inference.py:11-29.  ``path`` may also be an already-loaded checkpoint dict."""
+    ckpt = torch.load(path, map_location="cpu") if isinstance(path, str) else path
+    return WhisperEncoderModel(ckpt, device, ops=ops)
+
+
+@torch.no_grad()
+def pred_ppg_from_mel(whisper, mels, kept_frames, mel_noises=None):
+    """The encoder half of whisper/inference.py:32-62 starting at the mel tensor (the hot-path contract
+    starts there): per 15 s window ``mel + 0.1*randn`` (:46,58) -> encoder -> first
+    ``len//320`` frames (:40,48).  Returns a device tensor [T50, state]."""
+    out = []
+    for i, (mel, keep) in enumerate(zip(mels, kept_frames)):
+        dev = whisper.device
+        mel = mel.to(dev, torch.float32)
+        nz = torch.randn_like(mel) if mel_noises is None else mel_noises[i]
+        ppg = whisper.encoder(mel.unsqueeze(0), nz.unsqueeze(0), 0.1)[0]
+        out.append(ppg[:keep])
+    return torch.cat(out, 0)
+
+
+def window_plan(n_samples, sr=16000, window_s=K.WHISPER_WINDOW_S):
+    """(start, stop, kept_frames) per window, whisper/inference.py:37-61: full 15 s windows while
+    ``idx + 15 s < len`` and one remainder window; kept frames = samples // 320."""
+    plan, idx = [], 0
+    step = window_s * sr
+    while idx + step < n_samples:
+        plan.append((idx, idx + step, step // 320))
+        idx += step
+    if idx < n_samples:
+        plan.append((idx, n_samples, (n_samples - idx) // 320))
+    return plan
+
+
+def pred_ppg(whisper, wavPath, ppgPath, device):
+    """whisper/inference.py:32-62.  Needs the 16 kHz loader + log-mel front-end (row N2 of SURVEY.md 8f,
+    svcmi.whisper.audio); writes the same float32 [T50, 1280] .npy."""
+    from . import audio
+    wav = audio.load_audio(wavPath)
+    plan = window_plan(wav.shape[0])
+    mels = [audio.log_mel_spectrogram(torch.from_numpy(wav[s:e])) for (s, e, _) in plan]
+    ppg = pred_ppg_from_mel(whisper, mels, [k for (_, _, k) in plan])
+    np.save(ppgPath, ppg.cpu().numpy(), allow_pickle=False)
