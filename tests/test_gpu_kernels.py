@@ -1,0 +1,58 @@
+"""Per-kernel parity on a real MI355X through the C ABI (same checks as the emulator tests, plus the
+full-size shapes of the 10 s configuration)."""
+import pytest
+import torch
+
+from tests import kernel_cases as K
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from svcmi import Ops
+    o = Ops()
+    assert o.build == "hip:gfx950" and o.on_gpu
+    return o
+
+
+@pytest.mark.parametrize("case", K.CONV_CASES_SMALL + K.CONV_CASES_LARGE, ids=lambda c: c["id"])
+def test_conv_gemm(ops, case):
+    K.check_conv(ops, case, device="cuda")
+
+
+@pytest.mark.parametrize("c", [32, 192, 1280])
+def test_layernorm(ops, c):
+    K.check_layernorm(ops, c, device="cuda")
+
+
+@pytest.mark.parametrize("case", K.ATTN_CASES_SMALL + K.ATTN_CASES_LARGE, ids=lambda c: c["id"])
+def test_attention(ops, case):
+    K.check_attention(ops, case, device="cuda")
+
+
+@pytest.mark.parametrize("n,c", [(3, 4), (7, 12), (23, 4), (61, 12), (130, 20), (5000, 160), (320000, 12)])
+def test_snake_alias(ops, n, c):
+    K.check_snake(ops, n, c, device="cuda")
+
+
+def test_flow_glue(ops):
+    K.check_flow_glue(ops, device="cuda")
+
+
+def test_prior_glue(ops):
+    K.check_prior_glue(ops, device="cuda")
+
+
+def test_layout_bridges(ops):
+    K.check_bridges(ops, device="cuda")
+
+
+@pytest.mark.parametrize("T,B", [(5, 2), (1000, 1), (2520, 2)])
+def test_pitch2source(ops, T, B):
+    K.check_pitch2source(ops, T, B, device="cuda")
+
+
+def test_source2wav(ops):
+    K.check_source2wav(ops, device="cuda")
+    torch.cuda.synchronize()

@@ -29,6 +29,7 @@ class Ops:
         if self.on_gpu and not torch.cuda.is_available():
             raise SvcmiError("libsvcmi.so is the gfx950 build but no GPU is visible; svcmi has no CPU fallback")
         self.launches = 0
+        self.timeline = None     # set to a list to record (kernel, work, start_event, end_event) per launch
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
@@ -41,8 +42,16 @@ class Ops:
             if t.is_cuda != self.on_gpu:
                 raise SvcmiError(f"tensor on {t.device} but library build is {self.build}")
 
-    def _call(self, name, *args):
-        rc = getattr(self.lib, name)(*args)
+    def _call(self, name, *args, work=None):
+        if self.timeline is not None and self.on_gpu:
+            # HIP events on the SAME stream the kernel is launched on (bench.py roofline leg)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = getattr(self.lib, name)(*args)
+            e1.record()
+            self.timeline.append((name, work or {}, e0, e1))
+        else:
+            rc = getattr(self.lib, name)(*args)
         self.launches += 1
         if rc != 0:
             raise SvcmiError(f"{name} failed with code {rc}")
@@ -82,7 +91,8 @@ class Ops:
         d.act = act
         d.flags = (CONV_ACCUMULATE if accumulate else 0) | (CONV_MASK_IN if mask_in else 0) | (CONV_MASK_OUT if mask_out else 0) | (tile << 8)
         d.alpha = alpha
-        self._call("svcmi_conv_gemm_f32", ctypes.byref(d), self._stream())
+        self._call("svcmi_conv_gemm_f32", ctypes.byref(d), self._stream(),
+                   work={"flops": 2.0 * B * t_out * N * ksize * c_in})
         return out
 
     # ------------------------------------------------------------------ norm / attention
@@ -107,7 +117,7 @@ class Ops:
         bs = qkv.stride(0)
         self._call("svcmi_attention_f32", base, base + 4 * Cc, base + 8 * Cc, _ptr(out), C3, C3, C3, out.stride(1),
                    bs, bs, bs, out.stride(0), B, T, heads, Cc // heads, scale, _ptr(rel_k), _ptr(rel_v), window,
-                   _ptr(lengths), self._stream())
+                   _ptr(lengths), self._stream(), work={"flops": 4.0 * B * T * T * Cc})
         return out
 
     # ------------------------------------------------------------------ generator pieces
@@ -117,7 +127,7 @@ class Ops:
         if out is None:
             out = torch.empty_like(x)
         self._call("svcmi_snake_alias_f32", _ptr(x), _ptr(out), _ptr(alpha_log), _ptr(beta_log), _ptr(filt),
-                   B, L, Cc, x.stride(1), self._stream())
+                   B, L, Cc, x.stride(1), self._stream(), work={"bytes": 8.0 * B * L * Cc})
         return out
 
     def pitch2source(self, f0, rand_ini, noise, merge_w, merge_b, hop, sr):

@@ -133,6 +133,20 @@ class SynthesizerInfer:
 
     __call__ = inference
 
+    @torch.no_grad()
+    def inference_ppg50(self, ppg50, vec, pit, spk, lengths, source, noise=None):
+        """Same as ``inference`` but takes the Whisper PPG at its native 50 fps ([B, T/2, ppg_dim]) and fuses
+        the ``np.repeat(ppg, 2, 0)`` of svc_inference.py:175-177 into the first conv's loads.  All arguments
+        must already be device tensors (fp32 / int32 lengths); nothing here synchronises, so the call can be
+        captured in a HIP graph."""
+        w, ops = self._weights(), self.ops
+        B, T = pit.shape
+        if noise is None:
+            noise = torch.randn(B, w.I, T, device=pit.device)
+        z_p = self._prior_encoder(w, ops, ppg50, vec, pit, lengths, noise, ppg_row_shift=1)
+        z = self._flow_reverse(w, ops, z_p, spk, lengths)
+        return self._generator(w, ops, z, spk, source.view(B, T * w.hop))
+
     # ------------------------------------------------------------------ stages (time-major)
     def _prior_encoder(self, w, ops, ppg, vec, pit, lengths, noise, ppg_row_shift=0):
         """TextEncoder.forward, vits/models.py:39-52 + attentions.Encoder.forward, attentions.py:60-72."""
