@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SVCMI_ABI_VERSION 1
+#define SVCMI_ABI_VERSION 2
 
 enum svcmi_status { SVCMI_OK = 0, SVCMI_EINVAL = -1, SVCMI_EUNSUPPORTED = -2, SVCMI_EALIGN = -3 };
 
@@ -66,6 +66,11 @@ const char* svcmi_build_info(void);
  * repeated length).  w is [n_out][ldw] with ldw >= ksize*c_in, ldw % 4 == 0, zero padded.
  * c_in % 4 == 0 and ldx % 4 == 0 select 16-byte loads; any other c_in/ldx uses scalar loads.
  * y may alias res (in-place residual).  bias / res / lengths may be NULL.
+ * Split-K: when the (time x channel) tile grid is too small to fill the GPU the K range can be cut into
+ * `split_k` slices whose partial tiles go through `workspace` (caller-owned, >= batch*split_k*t_out*n_out
+ * floats, any contents) and are summed in fixed order by a second kernel -- deterministic, no atomics.
+ * split_k = 0 lets the library choose (never more than the workspace allows), 1 disables, workspace = NULL
+ * disables.
  */
 typedef struct svcmi_conv_desc {
     const float* x;
@@ -80,6 +85,9 @@ typedef struct svcmi_conv_desc {
     int32_t act;   /* enum svcmi_act */
     int32_t flags; /* enum svcmi_conv_flags */
     float alpha;
+    int32_t split_k;
+    float* workspace;
+    int64_t workspace_floats;
 } svcmi_conv_desc;
 
 int svcmi_conv_gemm_f32(const svcmi_conv_desc* d, void* stream);

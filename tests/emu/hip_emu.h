@@ -112,8 +112,13 @@ static inline svcmi_f32x16 svcmi_mfma_32x32x2(float a, float b, svcmi_f32x16 c) 
 }
 
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 
 #define SVCMI_LAUNCH(kernel, grid, block, shmem, stream, ...) \
     emu::launch(grid, block, [=]() { kernel(__VA_ARGS__); })
 #define SVCMI_LAST_ERROR() (emu::g_last_error)
 #define SVCMI_UNIFORM(x) (x)
+// LDS-DMA emulation: lane l copies its 16 (4) bytes to lds_wave_base + 16*l (4*l); synchronous here.
+static inline void svcmi_glds16(const float* g, float* lds_wave_base) { memcpy(lds_wave_base + 4 * emu::cur_lane(), g, 16); }
+static inline void svcmi_glds4(const float* g, float* lds_wave_base) { memcpy(lds_wave_base + emu::cur_lane(), g, 4); }
+static inline void svcmi_dma_wait() {}

@@ -40,6 +40,10 @@ CONV_CASES_SMALL = [
     dict(id="cin1_scalar_path", B=2, T=64, cin=1, n=6, k=8, stride=4, pad=2),
     dict(id="accumulate_alpha", B=1, T=33, cin=8, n=8, k=7, pad=3, res=True, alpha=1.0 / 3.0, accumulate=True),
     dict(id="n1_tanh_nobias", B=1, T=50, cin=12, n=1, k=7, pad=3, act=ACT_TANH, bias=False),
+    dict(id="splitk3_chunk", B=2, T=40, cin=64, n=70, k=5, pad=2, act=ACT_GELU, res=True, split_k=3),
+    dict(id="splitk_auto_vec_masks", B=2, T=29, cin=12, n=24, k=25, pad=12, lengths=[29, 17], mask_in=True, mask_out=True, split_k=0),
+    dict(id="splitk2_accumulate", B=1, T=33, cin=8, n=8, k=31, pad=15, res=True, alpha=1.0 / 3.0, accumulate=True, split_k=2),
+    dict(id="vec_cin20_k11_d5", B=1, T=90, cin=20, n=20, k=11, dil=5, pad=25, res=True),
     dict(id="tile_128x64", B=1, T=150, cin=16, n=70, k=3, pad=1, tile=2),
     dict(id="tile_128x128", B=1, T=150, cin=16, n=140, k=1, tile=3),
 ]
@@ -89,7 +93,7 @@ def check_conv(ops, c, device):
     y = ops.conv(xd, wp, dev(bias), ksize=k, stride=stride, dilation=dil, pad=pad, act=act, res=dev(res),
                  alpha=c.get("alpha", 1.0), accumulate=c.get("accumulate", False), lengths=dev(lengths),
                  mask_in=c.get("mask_in", False), mask_out=c.get("mask_out", False), out=out,
-                 x_row_shift=1 if rep else 0, c_in=cin, ldx=cin, n_out=n, tile=c.get("tile", 0),
+                 x_row_shift=1 if rep else 0, c_in=cin, ldx=cin, n_out=n, tile=c.get("tile", 0), split_k=c.get("split_k", 1),
                  t_in=Tl, x_bstride=t_phys * cin)
     assert y.shape == ref.shape
     _close(y, ref, 2e-5 if cin * k < 4096 else 1e-4, c["id"])

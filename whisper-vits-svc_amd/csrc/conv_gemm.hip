@@ -1,33 +1,48 @@
 // conv_gemm.hip -- implicit-GEMM 1-D convolution / linear layer on the gfx950 fp32 matrix cores.
 //
-// One kernel serves every Conv1d / Linear / (polyphase) ConvTranspose1d of the path (see svcmi.h).
+// One kernel family serves every Conv1d / Linear / (polyphase) ConvTranspose1d of the path (svcmi.h).
 // Time-major activations make the im2col matrix free: row t of the A operand is the contiguous
-// span x[t*stride - pad ... ][0:c_in] for dilation 1, and a gather of `ksize` row segments otherwise.
+// span x[t*stride - pad ...][0:c_in] for dilation 1, and a gather of `ksize` row segments otherwise.
 //
 // Tiling (wave64, 256 threads = 2x2 waves):  block tile (64*WM) x (64*WN), wave tile (32*WM) x (32*WN)
 // as WM x WN accumulators of v_mfma_f32_32x32x2_f32 (16 VGPR each).  K is walked in steps of 32:
-// both operands are K-contiguous in HBM, fetched with 16-byte loads, staged in LDS as [row][32+4]
-// (the +4 pad makes the 16-lane groups of ds_read_b128 hit 16 distinct 4-bank slots) and double
-// buffered so the next tile's global loads fly under the current tile's MFMAs.
+// both operands are K-contiguous in HBM and go straight to LDS with 16-byte LDS-DMA
+// (global_load_lds_dwordx4: no VGPR round trip, nothing to wait for until the tile is consumed), double
+// buffered so the next tile's DMA flies under the current tile's MFMAs.  The LDS image is [row][32]
+// with the eight 16-byte chunks of a row XOR-swizzled by (row & 7) -- applied on the SOURCE address of the
+// DMA and again on the fragment read -- so the 16-lane groups of ds_read_b128 hit 16 distinct 4-bank slots.
 // K-order trick: a lane's ds_read_b128 returns 4 consecutive k; lanes 0-31 take k = 8s+0..3 and
 // lanes 32-63 take k = 8s+4..7, so MFMA #j of sub-step s multiplies k-pairs (8s+j, 8s+4+j) -- a
 // permutation of the K summation shared by A and B, i.e. the same dot product.
+//
+// Zero fill (padding taps, masked rows, ragged tile edges) is done by pointing the lane's DMA at a 16-byte
+// zero constant: the staging code has no branches and no selects on loaded data.
+// Three instantiations of the A-gather keep the loop free of per-element integer division:
+//   CHUNK : c_in % 32 == 0 -- a K-step lies inside one tap (scalar tap/channel bookkeeping);
+//   VEC   : c_in % 4 == 0  -- one magic-number division per thread per K-step;
+//   SCALAR: anything else (the 1-channel source convolutions) -- 4-byte loads.
+//
+// Split-K (deterministic): when the tile grid cannot fill the 256 CUs (M = 500 Whisper rows against
+// N = 1280, or the N = 192 prior-encoder convs with K = 6400) blockIdx.z also enumerates S slices of the
+// K range; slices write raw partial tiles to a caller-provided workspace and a second small kernel adds
+// them in fixed order and applies the epilogue.  No atomics anywhere: results are run-to-run identical.
 #include "svcmi_rt.h"
 #include "../../include/svcmi.h"
 
 namespace {
 
 constexpr int BK = 32;
-constexpr int LDS_LD = BK + 4;
+enum { MODE_CHUNK = 0, MODE_VEC = 1, MODE_SCALAR = 2 };
 
 struct ConvArgs {
     const float* x; const float* w; const float* bias; const float* res; float* y; const int32_t* lengths;
+    float* ws;                   // split-K partials [batch][split][t_out][n_out]
     long long x_bs, y_bs, r_bs;
     int t_in, t_out, c_in, ldx, n_out, ldw, ldy, ldr;
     int ksize, stride, dil, pad, rshift, act, flags;
-    int ktot;        // ksize * c_in
-    int vec;         // 16-byte A loads legal
-    int chunk_tap;   // c_in % BK == 0: a K-step never straddles taps
+    int ktot;                    // ksize * c_in
+    int split;                   // K slices (1 = none)
+    unsigned magic;              // ceil(2^32 / c_in) for the VEC / SCALAR gathers (0 when c_in == 1)
     float alpha;
 };
 
@@ -44,52 +59,70 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     }
 }
 
-// One 4-wide slice of the implicit im2col matrix: row t, flat K index kk..kk+3.
-__device__ __forceinline__ float4 load_a4(const ConvArgs& p, const float* xb, int t, int kk, int t_lim,
-                                          int tap_u, int ci_u) {
-    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (t >= p.t_out) return r;
-    if (p.vec) {
-        if (kk >= p.ktot) return r;
-        int k, ci;
-        if (p.chunk_tap) { k = tap_u; ci = ci_u; }
-        else { k = kk / p.c_in; ci = kk - k * p.c_in; }
-        int tin = t * p.stride + k * p.dil - p.pad;
-        if (tin < 0 || tin >= t_lim) return r;
-        return *reinterpret_cast<const float4*>(xb + (long long)(tin >> p.rshift) * p.ldx + ci);
-    }
-    float v[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        int q = kk + e;
-        float val = 0.f;
-        if (q < p.ktot) {
-            int k = q / p.c_in, ci = q - k * p.c_in;
-            int tin = t * p.stride + k * p.dil - p.pad;
-            if (tin >= 0 && tin < t_lim) val = xb[(long long)(tin >> p.rshift) * p.ldx + ci];
-        }
-        v[e] = val;
-    }
-    return make_float4(v[0], v[1], v[2], v[3]);
+__device__ __forceinline__ float epilogue(const ConvArgs& p, float v, float bias, const float* res_row, float* dst,
+                                          int n, bool masked) {
+    v = act_apply(v + bias, p.act);
+    if (res_row) v += res_row[n];
+    v *= p.alpha;
+    if (p.flags & SVCMI_CONV_ACCUMULATE) v += *dst;
+    return masked ? 0.f : v;
 }
 
-template <int WM, int WN>
+__device__ __forceinline__ int div_magic(int q, unsigned magic) {   // q / c_in for 0 <= q < 2^20, c_in < 2^12
+    return magic ? (int)__umulhi((unsigned)q, magic) : q;
+}
+
+// Source of the zero fill: lanes whose (row, k) falls outside the tensor point their LDS-DMA here.
+__device__ const float svcmi_zeros[4] = {0.f, 0.f, 0.f, 0.f};
+
+template <int WM, int WN, int MODE>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
-    constexpr int A_PER = BM / 32, B_PER = BN / 32;   // float4 loads per thread per K-step
-    __shared__ float As[2][BM * LDS_LD];
-    __shared__ float Bs[2][BN * LDS_LD];
+    constexpr int A_PER = BM / 32, B_PER = BN / 32;   // 1-KiB LDS-DMA pieces (8 rows x 32 k) per wave per K-step
+    constexpr int CLD = BN;                           // epilogue staging tile [BM][BN] reuses the operand buffers
+    static_assert(BM * CLD <= 2 * (BM + BN) * BK, "C tile must fit in the operand buffers");
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * BK];
+    float* const As0 = smem;                          // As[buf] = As0 + buf*BM*BK, rows of 32 floats, chunk-swizzled
+    float* const Bs0 = smem + 2 * BM * BK;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = SVCMI_UNIFORM((int)(tid >> 6));
     const int wm = wave >> 1, wn = wave & 1;
-    const int b = blockIdx.z;
+    const int b = blockIdx.z / p.split, slice = blockIdx.z - b * p.split;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const float* xb = p.x + (long long)b * p.x_bs;
     const int len = p.lengths ? p.lengths[b] : 0x7fffffff;
     const int t_lim = (p.flags & SVCMI_CONV_MASK_IN) ? (len < p.t_in ? len : p.t_in) : p.t_in;
 
-    const int lrow = tid >> 3, lkq = (tid & 7) * 4;   // this thread's (row, k-offset) in a 32-row slab
-    const int nk = (p.ktot + BK - 1) / BK;
+    const int nk_all = (p.ktot + BK - 1) / BK;
+    const int it_beg = (int)((long long)nk_all * slice / p.split);
+    const int it_end = (int)((long long)nk_all * (slice + 1) / p.split);
+
+    // LDS image: row r holds its 32 k-values as 8 chunks of 16 B, chunk c stored at position c ^ (r & 7).
+    // A 1-KiB piece = 8 consecutive rows; the DMA writes lane l at byte 16*l of the piece, i.e. row l>>3,
+    // position l&7, so lane l must FETCH logical chunk (l&7) ^ (l>>3) of that row (swizzle on the source).
+    const int prow = lane >> 3;                        // row within a piece
+    const int lkq = ((lane & 7) ^ prow) * 4;           // this lane's k offset within the K-step
+    // K-invariant per-piece state: piece i of this wave covers rows (wave + 4*i)*8 .. +8
+    int a_tb[A_PER];                  // t*stride - pad, or a sentinel that keeps every tap out of range
+    const float* w_row[B_PER];
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+        const int t = m0 + (wave + 4 * i) * 8 + prow;
+        a_tb[i] = t < p.t_out ? t * p.stride - p.pad : -0x40000000;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+        const int n = n0 + (wave + 4 * i) * 8 + prow;
+        w_row[i] = n < p.n_out ? p.w + (long long)n * p.ldw : nullptr;
+    }
+    // CHUNK mode: wave-uniform (tap, first channel) of the K-step, advanced incrementally
+    int tap_u = 0, ci_u = 0;
+    if (MODE == MODE_CHUNK) {
+        const int k0 = it_beg * BK;
+        tap_u = k0 / p.c_in;
+        ci_u = k0 - tap_u * p.c_in;
+    }
 
     svcmi_f32x16 acc[WM][WN];
 #pragma unroll
@@ -99,42 +132,76 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[A_PER], rb[B_PER];
-    auto gload = [&](int it) {
-        const int k0 = it * BK;
-        int tap_u = 0, ci_u = 0;
-        if (p.chunk_tap) { tap_u = k0 / p.c_in; ci_u = k0 - tap_u * p.c_in + lkq; }
+    // Issue the LDS-DMA of K-step `it` into buffer `buf`.  Nothing lands in registers, nothing is waited for here.
+    auto stage = [&](int it, int buf) {
+        float* const Ab = As0 + buf * BM * BK;
+        float* const Bb = Bs0 + buf * BN * BK;
+        if (MODE == MODE_SCALAR) {
+            // 4-byte DMA: a wave-instruction fills 2 rows (64 floats); piece i needs 4 of them.
 #pragma unroll
-        for (int i = 0; i < A_PER; ++i) ra[i] = load_a4(p, xb, m0 + lrow + 32 * i, k0 + lkq, t_lim, tap_u, ci_u);
+            for (int i = 0; i < A_PER; ++i) {
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const int rr = 2 * h + (lane >> 5);                  // row within the piece
+                    const int pc = (lane & 31) >> 2, e = lane & 3;       // physical chunk, element
+                    const int q = it * BK + ((pc ^ rr) << 2) + e;        // logical k of this LDS word
+                    const int t = m0 + (wave + 4 * i) * 8 + rr;
+                    const int k = div_magic(q, p.magic), ci = q - k * p.c_in;
+                    const int tin = t * p.stride - p.pad + k * p.dil;
+                    const bool ok = t < p.t_out && q < p.ktot && (unsigned)tin < (unsigned)t_lim;
+                    const float* src = ok ? xb + (unsigned)((tin >> p.rshift) * p.ldx + ci) : svcmi_zeros;
+                    svcmi_glds4(src, Ab + ((wave + 4 * i) * 8 + 2 * h) * BK);
+                }
+            }
+        } else {
+            int k, ci;
+            bool kok = true;
+            if (MODE == MODE_CHUNK) {
+                k = tap_u; ci = ci_u + lkq;
+                ci_u += BK;
+                if (ci_u >= p.c_in) { ci_u -= p.c_in; ++tap_u; }
+            } else {
+                const int kk = it * BK + lkq;
+                k = div_magic(kk, p.magic); ci = kk - k * p.c_in;
+                kok = kk < p.ktot;
+            }
+            const int koff = k * p.dil;
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i) {
+                const int tin = a_tb[i] + koff;
+                const bool ok = kok && (unsigned)tin < (unsigned)t_lim;
+                const float* src = ok ? xb + (unsigned)((tin >> p.rshift) * p.ldx + ci) : svcmi_zeros;
+                svcmi_glds16(src, Ab + (wave + 4 * i) * 8 * BK);
+            }
+        }
+        const int kk = it * BK + lkq;
+        const bool wk = kk < p.ldw;
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
-            int n = n0 + lrow + 32 * i, kk = k0 + lkq;
-            rb[i] = (n < p.n_out && kk < p.ldw) ? *reinterpret_cast<const float4*>(p.w + (long long)n * p.ldw + kk)
-                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float* src = (wk && w_row[i]) ? w_row[i] + kk : svcmi_zeros;
+            svcmi_glds16(src, Bb + (wave + 4 * i) * 8 * BK);
         }
     };
-    auto sstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < A_PER; ++i) *reinterpret_cast<float4*>(&As[buf][(lrow + 32 * i) * LDS_LD + lkq]) = ra[i];
-#pragma unroll
-        for (int i = 0; i < B_PER; ++i) *reinterpret_cast<float4*>(&Bs[buf][(lrow + 32 * i) * LDS_LD + lkq]) = rb[i];
-    };
 
-    gload(0);
-    sstore(0);
-    __syncthreads();
-    const int arow = (wm * 32 * WM + (lane & 31)) * LDS_LD + (lane >> 5) * 4;
-    const int brow = (wn * 32 * WN + (lane & 31)) * LDS_LD + (lane >> 5) * 4;
-    for (int it = 0; it < nk; ++it) {
-        const int cur = it & 1;
-        if (it + 1 < nk) gload(it + 1);
+    // fragment addresses: row (lane&31) of the wave tile, logical chunk 2s + (lane>>5) -> position ^ (row&7)
+    const int frow = lane & 31, fhi = lane >> 5;
+    const int a_off = (wm * 32 * WM + frow) * BK, b_off = (wn * 32 * WN + frow) * BK;
+    if (it_beg < it_end) stage(it_beg, 0);
+    for (int it = it_beg; it < it_end; ++it) {
+        const int cur = (it - it_beg) & 1;
+        svcmi_dma_wait();    // this wave's DMA for tile `it` has landed ...
+        __syncthreads();     // ... and every other wave's; also: all reads of buf[cur^1] are done
+        if (it + 1 < it_end) stage(it + 1, cur ^ 1);
+        const float* Ab = As0 + cur * BM * BK + a_off;
+        const float* Bb = Bs0 + cur * BN * BK + b_off;
 #pragma unroll
         for (int s = 0; s < BK / 8; ++s) {
+            const int pos = (((2 * s + fhi) ^ (frow & 7)) << 2);
             float4 a4[WM], b4[WN];
 #pragma unroll
-            for (int i = 0; i < WM; ++i) a4[i] = *reinterpret_cast<const float4*>(&As[cur][arow + i * 32 * LDS_LD + s * 8]);
+            for (int i = 0; i < WM; ++i) a4[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * BK + pos);
 #pragma unroll
-            for (int j = 0; j < WN; ++j) b4[j] = *reinterpret_cast<const float4*>(&Bs[cur][brow + j * 32 * LDS_LD + s * 8]);
+            for (int j = 0; j < WN; ++j) b4[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * BK + pos);
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -145,80 +212,140 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
                     acc[i][j] = svcmi_mfma_32x32x2(a4[i].w, b4[j].w, acc[i][j]);
                 }
         }
-        if (it + 1 < nk) sstore(cur ^ 1);
-        __syncthreads();
     }
+    __syncthreads();         // last tile fully consumed before the buffers are reused below
 
-    // epilogue: D layout col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (t)
-    float* yb = p.y + (long long)b * p.y_bs;
-    const float* rbp = p.res ? p.res + (long long)b * p.r_bs : nullptr;
-    const bool accum = (p.flags & SVCMI_CONV_ACCUMULATE) != 0;
-    const bool mask_out = (p.flags & SVCMI_CONV_MASK_OUT) != 0;
+    // Epilogue through LDS: the accumulators (D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) are
+    // laid out as a [BM][BN] tile so that the (rolled, single-copy) epilogue loop walks n fastest and
+    // every store instruction writes 256 contiguous bytes.  The loop's last barrier already retired all
+    // operand reads, so the buffers can be reused.
+    float* Cs = smem;
 #pragma unroll
-    for (int j = 0; j < WN; ++j) {
-        const int n = n0 + wn * 32 * WN + j * 32 + (lane & 31);
-        if (n >= p.n_out) continue;
-        const float bv = p.bias ? p.bias[n] : 0.f;
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int i = 0; i < WM; ++i) {
+        for (int j = 0; j < WN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int t = m0 + wm * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (t >= p.t_out) continue;
-                float v = act_apply(acc[i][j][r] + bv, p.act);
-                if (rbp) v += rbp[(long long)t * p.ldr + n];
-                v *= p.alpha;
-                float* dst = yb + (long long)t * p.ldy + n;
-                if (accum) v += *dst;
-                if (mask_out && t >= len) v = 0.f;
-                *dst = v;
+                const int ml = wm * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int nl = wn * 32 * WN + j * 32 + (lane & 31);
+                Cs[ml * CLD + nl] = acc[i][j][r];
             }
+    __syncthreads();
+    const int nvalid = (p.n_out - n0) < BN ? (p.n_out - n0) : BN;
+    const int mvalid = (p.t_out - m0) < BM ? (p.t_out - m0) : BM;
+    if (p.split > 1) {   // raw partial tile; the reduce kernel applies the epilogue
+        float* wsb = p.ws + ((long long)b * p.split + slice) * p.t_out * p.n_out;
+        for (int e = tid; e < BM * BN; e += 256) {
+            const int ml = e / BN, nl = e - ml * BN;
+            if (ml < mvalid && nl < nvalid) wsb[(long long)(m0 + ml) * p.n_out + n0 + nl] = Cs[ml * CLD + nl];
         }
+        return;
+    }
+    float* yb = p.y + (long long)b * p.y_bs;
+    const float* rbp = p.res ? p.res + (long long)b * p.r_bs : nullptr;
+    const bool mask_out = (p.flags & SVCMI_CONV_MASK_OUT) != 0;
+    for (int e = tid; e < BM * BN; e += 256) {
+        const int ml = e / BN, nl = e - ml * BN;
+        if (ml >= mvalid || nl >= nvalid) continue;
+        const int t = m0 + ml, n = n0 + nl;
+        float* dst = yb + (long long)t * p.ldy + n;
+        *dst = epilogue(p, Cs[ml * CLD + nl], p.bias ? p.bias[n] : 0.f, rbp ? rbp + (long long)t * p.ldr : nullptr, dst, n,
+                        mask_out && t >= len);
+    }
+}
+
+// y = epilogue(sum over slices, fixed order).  One thread per 4 consecutive n (n_out % 4 handled by a scalar tail).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs p, int batch) {
+    const long long total = (long long)batch * p.t_out * p.n_out;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int n = (int)(e % p.n_out);
+        const long long bt = e / p.n_out;
+        const int t = (int)(bt % p.t_out), b = (int)(bt / p.t_out);
+        const float* src = p.ws + ((long long)b * p.split * p.t_out + t) * p.n_out + n;
+        float v = 0.f;
+        for (int s = 0; s < p.split; ++s) v += src[(long long)s * p.t_out * p.n_out];
+        const int len = p.lengths ? p.lengths[b] : 0x7fffffff;
+        float* dst = p.y + (long long)b * p.y_bs + (long long)t * p.ldy + n;
+        const float* rr = p.res ? p.res + (long long)b * p.r_bs + (long long)t * p.ldr : nullptr;
+        *dst = epilogue(p, v, p.bias ? p.bias[n] : 0.f, rr, dst, n, (p.flags & SVCMI_CONV_MASK_OUT) && t >= len);
     }
 }
 
 template <int WM, int WN>
-int launch(const ConvArgs& a, int batch, void* stream) {
+int launch(const ConvArgs& a, int batch, int mode, void* stream) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
-    dim3 grid((a.t_out + BM - 1) / BM, (a.n_out + BN - 1) / BN, batch);
-    SVCMI_LAUNCH((conv_gemm_kernel<WM, WN>), grid, dim3(256), 0, stream, a);
-    return SVCMI_LAST_ERROR();
+    dim3 grid((a.t_out + BM - 1) / BM, (a.n_out + BN - 1) / BN, batch * a.split);
+    if (mode == MODE_CHUNK) SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_CHUNK>), grid, dim3(256), 0, stream, a);
+    else if (mode == MODE_VEC) SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_VEC>), grid, dim3(256), 0, stream, a);
+    else SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_SCALAR>), grid, dim3(256), 0, stream, a);
+    int rc = SVCMI_LAST_ERROR();
+    if (rc == 0 && a.split > 1) {
+        const long long total = (long long)batch * a.t_out * a.n_out;
+        long long nb = (total + 255) / 256;
+        if (nb > 2048) nb = 2048;
+        SVCMI_LAUNCH(splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream, a, batch);
+        rc = SVCMI_LAST_ERROR();
+    }
+    return rc;
 }
 
 }  // namespace
 
 extern "C" int svcmi_conv_gemm_f32(const svcmi_conv_desc* d, void* stream) {
     if (!d || !d->x || !d->w || !d->y) return SVCMI_EINVAL;
+    if ((long long)d->t_in * d->ldx >= 0x7fffffffLL) return SVCMI_EUNSUPPORTED;   /* 32-bit in-item offsets */
     if (d->batch <= 0 || d->t_in <= 0 || d->t_out <= 0 || d->c_in <= 0 || d->n_out <= 0 || d->ksize <= 0) return SVCMI_EINVAL;
     if (d->stride <= 0 || d->dilation <= 0 || d->x_row_shift < 0 || d->x_row_shift > 1) return SVCMI_EINVAL;
     if (d->ldw % 4 != 0 || d->ldw < d->ksize * d->c_in) return SVCMI_EINVAL;
     if (d->ldy < d->n_out || (d->res && d->ldr < d->n_out) || d->ldx < d->c_in) return SVCMI_EINVAL;
     if ((d->flags & (SVCMI_CONV_MASK_IN | SVCMI_CONV_MASK_OUT)) && !d->lengths) return SVCMI_EINVAL;
     if (d->act < SVCMI_ACT_NONE || d->act > SVCMI_ACT_TANH) return SVCMI_EINVAL;
+    if (d->split_k < 0 || (d->split_k > 1 && !d->workspace)) return SVCMI_EINVAL;
     if (((uintptr_t)d->w & 15) != 0) return SVCMI_EALIGN;
-    if (d->batch > 65535 || (d->n_out + 63) / 64 > 65535) return SVCMI_EUNSUPPORTED;
+    if ((long long)d->ksize * d->c_in >= (1 << 20) || d->c_in >= (1 << 12)) return SVCMI_EUNSUPPORTED;
+    if ((d->n_out + 63) / 64 > 65535) return SVCMI_EUNSUPPORTED;
 
     ConvArgs a;
     a.x = d->x; a.w = d->w; a.bias = d->bias; a.res = d->res; a.y = d->y; a.lengths = d->lengths;
+    a.ws = d->workspace;
     a.x_bs = d->x_bstride; a.y_bs = d->y_bstride; a.r_bs = d->res_bstride;
     a.t_in = d->t_in; a.t_out = d->t_out; a.c_in = d->c_in; a.ldx = d->ldx; a.n_out = d->n_out;
     a.ldw = d->ldw; a.ldy = d->ldy; a.ldr = d->ldr;
     a.ksize = d->ksize; a.stride = d->stride; a.dil = d->dilation; a.pad = d->pad; a.rshift = d->x_row_shift;
     a.act = d->act; a.flags = d->flags; a.alpha = d->alpha;
     a.ktot = d->ksize * d->c_in;
-    a.vec = (d->c_in % 4 == 0) && (d->ldx % 4 == 0) && (d->x_bstride % 4 == 0) && (((uintptr_t)d->x & 15) == 0);
-    a.chunk_tap = a.vec && (d->c_in % BK == 0);
+    a.magic = d->c_in == 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d->c_in - 1) / (unsigned)d->c_in);
+    const bool vec = (d->c_in % 4 == 0) && (d->ldx % 4 == 0) && (d->x_bstride % 4 == 0) && (((uintptr_t)d->x & 15) == 0);
+    const int mode = !vec ? MODE_SCALAR : (d->c_in % BK == 0 ? MODE_CHUNK : MODE_VEC);
 
-    // Tile choice: fill the 256 CUs first, then grow the tile for operand reuse (or honour the override).
-    switch (d->flags & SVCMI_CONV_TILE_MASK) {
-        case SVCMI_CONV_TILE_64x64: return launch<1, 1>(a, d->batch, stream);
-        case SVCMI_CONV_TILE_128x64: return launch<2, 1>(a, d->batch, stream);
-        case SVCMI_CONV_TILE_128x128: return launch<2, 2>(a, d->batch, stream);
-        default: break;
-    }
+    // Tile: fill the 256 CUs first, then grow the tile for operand reuse (or honour the override).
     const long long mt64 = (d->t_out + 63) / 64, nt64 = (d->n_out + 63) / 64;
     const long long blocks64 = mt64 * nt64 * d->batch;
-    if (d->n_out > 64 && blocks64 >= 4 * 1024 && d->t_out >= 128) return launch<2, 2>(a, d->batch, stream);
-    if (blocks64 >= 2 * 1024 && d->t_out >= 128) return launch<2, 1>(a, d->batch, stream);
-    return launch<1, 1>(a, d->batch, stream);
+    int tile = (d->flags & SVCMI_CONV_TILE_MASK);
+    if (!tile) {
+        if (d->n_out > 64 && blocks64 >= 4 * 1024 && d->t_out >= 128) tile = SVCMI_CONV_TILE_128x128;
+        else if (blocks64 >= 2 * 1024 && d->t_out >= 128) tile = SVCMI_CONV_TILE_128x64;
+        else tile = SVCMI_CONV_TILE_64x64;
+    }
+    // Split-K: only for 64x64 tiles that leave CUs idle; slices keep >= 4 K-steps each.
+    a.split = 1;
+    const int nk = (a.ktot + BK - 1) / BK;
+    if (tile == SVCMI_CONV_TILE_64x64 && d->workspace && d->split_k != 1) {
+        int s = d->split_k;
+        if (s == 0) {                                   // heuristic: aim at >= 2 blocks per CU
+            s = (int)((512 + blocks64 - 1) / blocks64);
+            if (s > nk / 4) s = nk / 4;
+            if (s > 16) s = 16;
+        }
+        if (s > nk) s = nk;
+        while (s > 1 && (long long)d->batch * s * d->t_out * d->n_out > d->workspace_floats) --s;
+        if (s > 1) a.split = s;
+    }
+    if ((long long)d->batch * a.split > 65535) return SVCMI_EUNSUPPORTED;
+
+    switch (tile) {
+        case SVCMI_CONV_TILE_128x128: return launch<2, 2>(a, d->batch, mode, stream);
+        case SVCMI_CONV_TILE_128x64: return launch<2, 1>(a, d->batch, mode, stream);
+        default: return launch<1, 1>(a, d->batch, mode, stream);
+    }
 }

@@ -24,6 +24,29 @@ __device__ __forceinline__ svcmi_f32x16 svcmi_mfma_32x32x2(float a, float b, svc
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// Asynchronous global -> LDS copy (LDS-DMA, global_load_lds_dword[x4]).  `lds_wave_base` is wave-uniform; lane
+// l's 16 (4) bytes land at lds_wave_base + 16*l (4*l) bytes.  Issued through inline asm ON PURPOSE: with the
+// builtin hipcc models the DMA as a pending LDS write and puts s_waitcnt vmcnt(0) in front of the next
+// ds_read whenever it cannot prove the buffers disjoint (runtime double-buffer index), which serialises copy
+// and compute.  The asm form is invisible to that bookkeeping, so the caller owns completion:
+// svcmi_dma_wait() then a barrier before any wave reads the data (cdna_hip_programming.md section 5.7).
+__device__ __forceinline__ unsigned svcmi_lds_addr(const float* lds_ptr) {
+    return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) float*)lds_ptr);
+}
+__device__ __forceinline__ void svcmi_glds16(const float* g, float* lds_wave_base) {
+    const unsigned dst = svcmi_lds_addr(lds_wave_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+}
+__device__ __forceinline__ void svcmi_glds4(const float* g, float* lds_wave_base) {
+    const unsigned dst = svcmi_lds_addr(lds_wave_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+}
+__device__ __forceinline__ void svcmi_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // Tell hipcc a threadIdx-derived value is wave-uniform (unlocks scalar loads / SGPR operands).
 #define SVCMI_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 

@@ -29,6 +29,8 @@ class Ops:
         if self.on_gpu and not torch.cuda.is_available():
             raise SvcmiError("libsvcmi.so is the gfx950 build but no GPU is visible; svcmi has no CPU fallback")
         self.launches = 0
+        self.workspace = None    # split-K scratch, allocated on first use (one per Ops / device)
+        self.workspace_floats = 16 * 1024 * 1024
         self.timeline = None     # set to a list to record (kernel, work, start_event, end_event) per launch
 
     # ------------------------------------------------------------------ plumbing
@@ -62,7 +64,7 @@ class Ops:
     # ------------------------------------------------------------------ conv / linear
     def conv(self, x, w, bias=None, *, ksize=1, stride=1, dilation=1, pad=0, t_out=None, act=ACT_NONE,
              res=None, alpha=1.0, accumulate=False, lengths=None, mask_in=False, mask_out=False, out=None,
-             x_row_shift=0, c_in=None, ldx=None, t_in=None, n_out=None, x_bstride=None, tile=0):
+             x_row_shift=0, c_in=None, ldx=None, t_in=None, n_out=None, x_bstride=None, tile=0, split_k=0):
         """y[b,t,n] = epilogue(sum_k sum_ci x[b, t*stride + k*dilation - pad, ci] * w[n, k*c_in + ci]).
         ``x`` is [B, T, C]; ``w`` is [N, ldw] packed (weights.pack_conv)."""
         self._chk(x, w, bias, res, out, lengths)
@@ -91,6 +93,12 @@ class Ops:
         d.act = act
         d.flags = (CONV_ACCUMULATE if accumulate else 0) | (CONV_MASK_IN if mask_in else 0) | (CONV_MASK_OUT if mask_out else 0) | (tile << 8)
         d.alpha = alpha
+        if split_k != 1:
+            if self.workspace is None or self.workspace.device != x.device:
+                self.workspace = torch.empty(self.workspace_floats, dtype=torch.float32, device=x.device)
+            d.split_k, d.workspace, d.workspace_floats = split_k, self.workspace.data_ptr(), self.workspace.numel()
+        else:
+            d.split_k, d.workspace, d.workspace_floats = 1, 0, 0
         self._call("svcmi_conv_gemm_f32", ctypes.byref(d), self._stream(),
                    work={"flops": 2.0 * B * t_out * N * ksize * c_in})
         return out
