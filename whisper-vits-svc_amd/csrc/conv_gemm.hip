@@ -68,7 +68,7 @@ __device__ __forceinline__ float epilogue(const ConvArgs& p, float v, float bias
     return masked ? 0.f : v;
 }
 
-__device__ __forceinline__ int div_magic(int q, unsigned magic) {   // q / c_in for 0 <= q < 2^20, c_in < 2^12
+__device__ __forceinline__ int div_magic(int q, unsigned magic) {   // q / c_in, exact while q * c_in < 2^32
     return magic ? (int)__umulhi((unsigned)q, magic) : q;
 }
 
@@ -302,7 +302,8 @@ extern "C" int svcmi_conv_gemm_f32(const svcmi_conv_desc* d, void* stream) {
     if (d->act < SVCMI_ACT_NONE || d->act > SVCMI_ACT_TANH) return SVCMI_EINVAL;
     if (d->split_k < 0 || (d->split_k > 1 && !d->workspace)) return SVCMI_EINVAL;
     if (((uintptr_t)d->w & 15) != 0) return SVCMI_EALIGN;
-    if ((long long)d->ksize * d->c_in >= (1 << 20) || d->c_in >= (1 << 12)) return SVCMI_EUNSUPPORTED;
+    // magic-number division q / c_in is exact while q * c_in < 2^32 (q < ksize*c_in)
+    if ((long long)d->ksize * d->c_in * d->c_in >= 0x100000000LL || (long long)d->ksize * d->c_in >= 0x7fffffffLL) return SVCMI_EUNSUPPORTED;
     if ((d->n_out + 63) / 64 > 65535) return SVCMI_EUNSUPPORTED;
 
     ConvArgs a;
