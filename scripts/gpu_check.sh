@@ -21,7 +21,7 @@ timeout 900 python bench.py --steps ${STEPS:-20} --warmup 3 > $OUT/bench.json 2>
 if [ "$SKIP_PROF" != "1" ]; then
 echo "== rocprofv3 kernel trace"
 cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o trace -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/prof_bench.json 2> $OUT/prof.err; echo "rocprof rc=$?"
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/prof_bench.json 2> $OUT/prof.err; echo "rocprof rc=$?"
 cd $ROOT
 find $OUT/prof -name "*stats*" | head; 
 F=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && head -25 "$F"

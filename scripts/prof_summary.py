@@ -1,0 +1,52 @@
+#!/usr/bin/env python
+"""Summarise a rocprofv3 `--kernel-trace --stats --output-format csv` run into one small CSV for profiles/:
+per-kernel calls / total / average (names shortened), then a per-(kernel, grid, block) breakdown with register
+counts.  Usage: prof_summary.py <dir with *_kernel_trace.csv> <out.csv> [traced_steps]"""
+import csv
+import glob
+import os
+import re
+import sys
+
+
+def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    if "distribution_elementwise" in name:
+        return "torch::randn/rand"
+    m = re.match(r"([A-Za-z0-9_:]+)(<[^>(]*>)?", name)
+    return (m.group(1) + (m.group(2) or "").replace(" ", "")) if m else name[:60]
+
+
+def main():
+    src, out = sys.argv[1], sys.argv[2]
+    steps = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
+    f = glob.glob(os.path.join(src, "**", "*kernel_trace.csv"), recursive=True)[0]
+    agg, by_grid = {}, {}
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"])
+        dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        a = agg.setdefault(k, [0, 0.0])
+        a[0] += 1
+        a[1] += dur
+        wx = max(int(r["Workgroup_Size_X"]), 1)
+        key = (k, int(r["Grid_Size_X"]) // wx, int(r["Grid_Size_Y"]), int(r["Grid_Size_Z"]), wx,
+               r["VGPR_Count"], r["Accum_VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"])
+        g = by_grid.setdefault(key, [0, 0.0])
+        g[0] += 1
+        g[1] += dur
+    total = sum(a[1] for k, a in agg.items() if "spin_kernel" not in k)
+    with open(out, "w") as o:
+        o.write(f"# rocprofv3 --kernel-trace --stats summary; durations in us; {steps:g} traced steps; "
+                f"total kernel time per step {total / steps / 1e3:.3f} ms (spin_kernel excluded)\n")
+        o.write("kernel,calls,calls_per_step,total_us,avg_us,percent\n")
+        for k, (n, d) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            o.write(f"{k},{n},{n / steps:.1f},{d:.1f},{d / n:.2f},{100 * d / total:.2f}\n")
+        o.write("\n# per (kernel, grid in workgroups, block) -- top 50 by time\n")
+        o.write("kernel,grid_x,grid_y,grid_z,block,vgpr,agpr,sgpr,lds,calls_per_step,avg_us,ms_per_step\n")
+        for key, (n, d) in sorted(by_grid.items(), key=lambda kv: -kv[1][1])[:50]:
+            o.write(",".join(str(x) for x in key) + f",{n / steps:.1f},{d / n:.2f},{d / steps / 1e3:.3f}\n")
+    print(open(out).read()[:6000])
+
+
+if __name__ == "__main__":
+    main()
