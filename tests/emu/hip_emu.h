@@ -111,6 +111,22 @@ static inline svcmi_f32x16 svcmi_mfma_32x32x2(float a, float b, svcmi_f32x16 c) 
     return c;
 }
 
+// v_mfma_f32_16x16x4_f32: lane l holds A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; D: col=l&15, row=4*(l>>4)+r.
+static inline svcmi_f32x4 svcmi_mfma_16x16x4(float a, float b, svcmi_f32x4 c) {
+    float ab[2] = {a, b};
+    float all[64][2];
+    emu::wave_exchange(ab, sizeof(ab), all);
+    int l = emu::cur_lane();
+    int j = l & 15;
+    for (int r = 0; r < 4; ++r) {
+        int i = 4 * (l >> 4) + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) acc = fmaf(all[i + 16 * k][0], all[j + 16 * k][1], acc);
+        c[r] = acc;
+    }
+    return c;
+}
+
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 

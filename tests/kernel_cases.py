@@ -118,6 +118,8 @@ ATTN_CASES_SMALL = [
     dict(id="d64_plain_T130", B=1, T=130, H=2, D=64),
     dict(id="d96_rel_short_T3", B=1, T=3, H=2, D=96, rel=True, W=4),
     dict(id="d96_rel_T67", B=1, T=67, H=2, D=96, rel=True, W=4, lengths=[60]),
+    dict(id="d32_rel_w2_T140_keysplit2", B=1, T=140, H=2, D=32, rel=True, W=2, lengths=[133]),
+    dict(id="d96_rel_T260_keysplit4", B=2, T=260, H=2, D=96, rel=True, W=4, lengths=[260, 201]),
 ]
 ATTN_CASES_LARGE = [
     dict(id="whisper_T500", B=1, T=500, H=20, D=64),

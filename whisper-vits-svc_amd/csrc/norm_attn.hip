@@ -1,5 +1,5 @@
-// norm_attn.hip -- row LayerNorm and fp32 multi-head attention (online softmax, optional
-// relative-position band), both on time-major rows.  Reductions use wavefront shuffles (64 lanes).
+// norm_attn.hip -- row LayerNorm (wavefront-shuffle reductions) and fp32 multi-head attention on the
+// exact-fp32 matrix cores (online softmax, optional relative-position band), both on time-major rows.
 #include "svcmi_rt.h"
 #include "../../include/svcmi.h"
 
@@ -72,154 +72,289 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
 }
 
 // ------------------------------------------------------------------------------------ attention
-// lane = query.  q and the output accumulator of one head (D floats each) live in registers; K and V
-// rows are addressed wave-uniformly, so hipcc fetches them with scalar loads and the FMAs take them as
-// SGPR operands -- no LDS staging, no barrier in the key loop, 2*D FMAs per (query, key) with no
-// redundancy.  The NW waves of a block share 64 queries and split the key range; their partial
-// (max, sum, acc) states are merged through LDS at the end (flash-decoding style).  Softmax is the
-// online form, rescaled once per chunk of CH keys.  The relative-position band (|j-i| <= window) only
-// touches <= 2*window+1 keys per query and is handled by a divergent side branch.
+// Flash-style attention on the exact-fp32 matrix cores (v_mfma_f32_16x16x4_f32), both products "swapped" so
+// that a lane always owns ONE query column:
+//     S^T[key][query] = K Q^T        A = K rows (i = key),  B = Q^T (j = query)
+//     O^T[d][query]   = V^T P^T      A = V^T   (i = d),     B = P^T (j = query)
+// The D layout of the first product (lane (query, quarter g) holds keys 4g..4g+3 of a 16-key tile) is exactly
+// the B-operand layout the second one needs -- MFMA step r contracts keys {r, 4+r, 8+r, 12+r} -- so P never
+// moves between lanes, softmax statistics are per-lane scalars (max: 7 fmax + 2 shuffles per 32 keys), and the
+// online rescale of O^T is a lane-local multiply.  A wave owns 16 queries; the NS waves of a block split the
+// key range (flash-decoding style) and merge their (max, sum, O) states through LDS, which also turns the
+// per-lane O^T columns into coalesced 16-byte row stores.  K and V fragments are read straight from global
+// memory (a head's K/V is <= 1 MB and L2-resident; waves of a block read different keys, so LDS staging would
+// buy no reuse).  The relative-position band (|j-i| <= window, vits/attentions.py:225-347) adds q.E_k[j-i+w]
+// to the <= 2w+1 in-band scores -- only tiles touching the diagonal pay for it -- and accumulates the in-band
+// probabilities per query so that sum_r Pband[r] E_v[r] is added once, in the merge.
+// Blocks are enumerated so that consecutive (head, q-tile) work lands on one XCD (block b runs on XCD b % 8):
+// each XCD's L2 then holds ~1/8 of the heads instead of all of them.
 struct AttnArgs {
     const float* q; const float* k; const float* v; float* o;
     int ldq, ldk, ldv, ldo;
     long long q_bs, k_bs, v_bs, o_bs;
-    int t, heads;
+    int t, heads, nq;
     float scale;
     const float* rel_k; const float* rel_v;
     int window;
     const int32_t* lengths;
 };
 
-constexpr int CH = 4;    // keys per softmax rescale chunk
-constexpr int NW = 4;    // waves per block = key-range splits
-constexpr int MAXW = 4;  // largest relative window
+constexpr int MAXW = 4;            // largest relative window
+constexpr int NREL = 2 * MAXW + 1;
+constexpr int BST = 12;            // row stride of the per-query band sums in LDS
+constexpr float NEG_BIG = -3.0e38f;
 
-template <int D>
-__global__ __launch_bounds__(64 * NW) void attention_kernel(AttnArgs p) {
-    __shared__ float part[(NW - 1) * (D + 2) * 64];   // states of waves 1..NW-1, [w-1][slot][lane]
+__device__ __forceinline__ float quarter_sum(float v) {    // sum over the 4 lane quarters (same lane & 15)
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
 
-    const int lane = threadIdx.x & 63;
-    const int w = SVCMI_UNIFORM((int)(threadIdx.x >> 6));
-    const int qi = blockIdx.x * 64 + lane;
-    const int h = blockIdx.y, b = blockIdx.z;
+template <int D, int NS>
+__global__ __launch_bounds__(64 * NS) void attention_kernel(AttnArgs p) {
+    constexpr int DS = D / 16;         // 16-wide d groups: float4 K/Q fragments per row and 16-row tiles of O^T
+    constexpr int OLD = D + 4;         // padded row of the partial-O tile: conflict-free ds_write_b128
+    __shared__ __attribute__((aligned(16))) float smem[NS * 16 * OLD + 2 * NS * 16 + NS * 16 * BST + 2 * NREL * D];
+    float* const Opart = smem;                         // [NS][16][OLD]
+    float* const Mpart = Opart + NS * 16 * OLD;        // [NS][16]
+    float* const Lpart = Mpart + NS * 16;              // [NS][16]
+    float* const Bpart = Lpart + NS * 16;              // [NS][16][BST]
+    float* const Ek = Bpart + NS * 16 * BST;           // [NREL][D]
+    float* const Ev = Ek + NREL * D;                   // [NREL][D]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = SVCMI_UNIFORM((int)(tid >> 6));
+    const int lq = lane & 15, g4 = lane >> 4;
+    // XCD-aware, bijective enumeration of (batch*head, q-tile) pairs
+    int L;
+    {
+        const int total = (int)gridDim.x, id = (int)blockIdx.x;
+        const int q8 = total >> 3, r8 = total & 7, xcd = id & 7, slot = id >> 3;
+        L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    }
+    const int qt = L % p.nq, hb = L / p.nq;
+    const int h = hb % p.heads, b = hb / p.heads;
     const int T = p.t;
     const int len = p.lengths ? p.lengths[b] : T;
-    const bool qvalid = qi < T;
     const bool has_rel = p.rel_k != nullptr;
     const int W = p.window;
+    const int nrel = has_rel ? 2 * W + 1 : 0;
 
-    float qreg[D], oacc[D];
-    {
-        const float* qp = p.q + (long long)b * p.q_bs + (long long)(qvalid ? qi : 0) * p.ldq + h * D;
-#pragma unroll
-        for (int d = 0; d < D; d += 4) {
-            float4 t4 = *reinterpret_cast<const float4*>(qp + d);
-            qreg[d] = t4.x; qreg[d + 1] = t4.y; qreg[d + 2] = t4.z; qreg[d + 3] = t4.w;
-        }
-#pragma unroll
-        for (int d = 0; d < D; ++d) oacc[d] = 0.f;
+    if (has_rel) {
+        for (int i = tid; i < nrel * D; i += 64 * NS) { Ek[i] = p.rel_k[i]; Ev[i] = p.rel_v[i]; }
+        __syncthreads();
     }
-    float mrun = -3.0e38f, lrun = 0.f;
-    const float* kb = p.k + (long long)b * p.k_bs + h * D;
-    const float* vb = p.v + (long long)b * p.v_bs + h * D;
 
-    // this wave's key range, CH-aligned
-    const int per = ((T + NW - 1) / NW + CH - 1) / CH * CH;
+    const int q0 = qt * 16, qi = q0 + lq;
+    float qf[DS][4];
+    {
+        const float* qp = p.q + (long long)b * p.q_bs + (long long)(qi < T ? qi : T - 1) * p.ldq + h * D + 4 * g4;
+#pragma unroll
+        for (int s = 0; s < DS; ++s) {
+            const float4 t4 = *reinterpret_cast<const float4*>(qp + 16 * s);
+            qf[s][0] = t4.x; qf[s][1] = t4.y; qf[s][2] = t4.z; qf[s][3] = t4.w;
+        }
+    }
+    float R[NREL], Pb[NREL];
+#pragma unroll
+    for (int e = 0; e < NREL; ++e) { R[e] = 0.f; Pb[e] = 0.f; }
+    if (has_rel) {
+#pragma unroll
+        for (int e = 0; e < NREL; ++e) {
+            if (e < nrel) {           // wave-uniform
+                float a = 0.f;
+#pragma unroll
+                for (int s = 0; s < DS; ++s)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a = fmaf(qf[s][j], Ek[e * D + 16 * s + 4 * g4 + j], a);
+                R[e] = quarter_sum(a);
+            }
+        }
+    }
+
+    svcmi_f32x4 oacc[DS];
+#pragma unroll
+    for (int dt = 0; dt < DS; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) oacc[dt][r] = 0.f;
+    float mrun = NEG_BIG, lrun = 0.f;
+
+    const float* kb = p.k + (long long)b * p.k_bs + h * D + 4 * g4;
+    const float* vb = p.v + (long long)b * p.v_bs + h * D + lq;
+    const int per = ((T + NS - 1) / NS + 31) / 32 * 32;     // keys per wave, a multiple of the 32-key step
     const int jbeg = w * per;
     const int jend = (jbeg + per) < T ? (jbeg + per) : T;
 
-    for (int j0 = jbeg; j0 < jend; j0 += CH) {
-        float s[CH];
-        float cmax = -3.0e38f;
+    for (int kt = jbeg; kt < jend; kt += 32) {
+        // ---- S^T = K Q^T for two 16-key tiles (two independent accumulators hide the 40-cycle MFMA latency)
+        svcmi_f32x4 sacc[2];
 #pragma unroll
-        for (int u = 0; u < CH; ++u) {
-            const int j = j0 + u;
-            const int jc = j < T ? j : T - 1;              // uniform clamp keeps the address valid
-            const float* kr = kb + (long long)jc * p.ldk;  // wave-uniform -> scalar loads
-            float a = 0.f;
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int d = 0; d < D; ++d) a = fmaf(qreg[d], kr[d], a);
-            if (has_rel) {
-                const int rel = j - qi + W;
-                if (rel >= 0 && rel <= 2 * W) {            // divergent: <= 2W+1 keys per query
-                    const float* e = p.rel_k + rel * D;
-                    float ae = 0.f;
+            for (int r = 0; r < 4; ++r) sacc[u][r] = 0.f;
+        {
+            const int k0 = kt + lq, k1 = kt + 16 + lq;
+            const float* kr0 = kb + (long long)(k0 < T ? k0 : T - 1) * p.ldk;
+            const float* kr1 = kb + (long long)(k1 < T ? k1 : T - 1) * p.ldk;
 #pragma unroll
-                    for (int d = 0; d < D; ++d) ae = fmaf(qreg[d], e[d], ae);
-                    a += ae;
-                }
+            for (int s = 0; s < DS; ++s) {
+                const float4 a0 = *reinterpret_cast<const float4*>(kr0 + 16 * s);
+                const float4 a1 = *reinterpret_cast<const float4*>(kr1 + 16 * s);
+                sacc[0] = svcmi_mfma_16x16x4(a0.x, qf[s][0], sacc[0]);
+                sacc[1] = svcmi_mfma_16x16x4(a1.x, qf[s][0], sacc[1]);
+                sacc[0] = svcmi_mfma_16x16x4(a0.y, qf[s][1], sacc[0]);
+                sacc[1] = svcmi_mfma_16x16x4(a1.y, qf[s][1], sacc[1]);
+                sacc[0] = svcmi_mfma_16x16x4(a0.z, qf[s][2], sacc[0]);
+                sacc[1] = svcmi_mfma_16x16x4(a1.z, qf[s][2], sacc[1]);
+                sacc[0] = svcmi_mfma_16x16x4(a0.w, qf[s][3], sacc[0]);
+                sacc[1] = svcmi_mfma_16x16x4(a1.w, qf[s][3], sacc[1]);
             }
-            a *= p.scale;
-            if (qi >= len || j >= len) a = -1.0e4f;         // masked_fill(mask == 0, -1e4)
-            if (j >= T) a = -3.0e38f;                       // beyond the sequence: weight 0
-            s[u] = a;
-            cmax = fmaxf(cmax, a);
         }
-        const float mnew = fmaxf(mrun, cmax);
+        // ---- scores of this lane: keys kt + 16u + 4*g4 + r, query qi
+        const bool diag = has_rel && (kt + 31 >= q0 - W) && (kt <= q0 + 15 + W);    // wave-uniform
+        float sv[2][4];
+        float mt = NEG_BIG;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt + 16 * u + 4 * g4 + r;
+                float a = sacc[u][r];
+                if (diag) {
+                    const int rel = key - qi + W;
+                    float add = 0.f;
+#pragma unroll
+                    for (int e = 0; e < NREL; ++e) add = (rel == e && e < nrel) ? R[e] : add;
+                    a += add;
+                }
+                a *= p.scale;
+                if (qi >= len || key >= len) a = -1.0e4f;       // masked_fill(mask == 0, -1e4)
+                if (key >= T) a = NEG_BIG;                      // beyond the sequence: weight 0
+                sv[u][r] = a;
+                mt = fmaxf(mt, a);
+            }
+        mt = fmaxf(mt, __shfl_xor(mt, 16));
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float mnew = fmaxf(mrun, mt);
         const float corr = expf(mrun - mnew);
+        mrun = mnew;
         lrun *= corr;
 #pragma unroll
-        for (int d = 0; d < D; ++d) oacc[d] *= corr;
+        for (int dt = 0; dt < DS; ++dt)
 #pragma unroll
-        for (int u = 0; u < CH; ++u) {
-            const int j = j0 + u;
-            const int jc = j < T ? j : T - 1;
-            const float pj = (j < T) ? expf(s[u] - mnew) : 0.f;
-            lrun += pj;
-            const float* vr = vb + (long long)jc * p.ldv;   // wave-uniform
+            for (int r = 0; r < 4; ++r) oacc[dt][r] *= corr;
+        float pv[2][4];
 #pragma unroll
-            for (int d = 0; d < D; ++d) oacc[d] = fmaf(pj, vr[d], oacc[d]);
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pv[u][r] = expf(sv[u][r] - mnew);               // exp(NEG_BIG - finite) == 0 for keys >= T
+                lrun += pv[u][r];
+            }
+        if (diag) {
+#pragma unroll
+            for (int e = 0; e < NREL; ++e) Pb[e] *= corr;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rel = kt + 16 * u + 4 * g4 + r - qi + W;
+#pragma unroll
+                    for (int e = 0; e < NREL; ++e) Pb[e] += (rel == e && e < nrel) ? pv[u][r] : 0.f;
+                }
+        } else if (has_rel) {
+#pragma unroll
+            for (int e = 0; e < NREL; ++e) Pb[e] *= corr;
+        }
+        // ---- O^T += V^T P^T : step (u, r) contracts keys kt + 16u + {r, 4+r, 8+r, 12+r}
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt + 16 * u + 4 * g4 + r;
+                const float* vr = vb + (long long)(key < T ? key : T - 1) * p.ldv;
+#pragma unroll
+                for (int dt = 0; dt < DS; ++dt) oacc[dt] = svcmi_mfma_16x16x4(vr[16 * dt], pv[u][r], oacc[dt]);
+            }
+    }
+
+    // ---- publish this wave's state: O^T columns become rows of Opart
+    lrun = quarter_sum(lrun);
+    if (has_rel) {
+#pragma unroll
+        for (int e = 0; e < NREL; ++e) Pb[e] = quarter_sum(Pb[e]);
+    }
+    {
+        float* orow = Opart + (w * 16 + lq) * OLD + 4 * g4;
+#pragma unroll
+        for (int dt = 0; dt < DS; ++dt)
+            *reinterpret_cast<float4*>(orow + 16 * dt) = make_float4(oacc[dt][0], oacc[dt][1], oacc[dt][2], oacc[dt][3]);
+        if (g4 == 0) {
+            Mpart[w * 16 + lq] = mrun;
+            Lpart[w * 16 + lq] = lrun;
             if (has_rel) {
-                const int rel = j - qi + W;
-                if (rel >= 0 && rel <= 2 * W && j < T) {
-                    const float* e = p.rel_v + rel * D;
 #pragma unroll
-                    for (int d = 0; d < D; ++d) oacc[d] = fmaf(pj, e[d], oacc[d]);
+                for (int e = 0; e < NREL; ++e) Bpart[(w * 16 + lq) * BST + e] = Pb[e];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- merge the NS partial states; one thread per (query, 4 channels)
+    float* ob = p.o + (long long)b * p.o_bs + h * D;
+    for (int item = tid; item < 16 * (D / 4); item += 64 * NS) {
+        const int ql = item / (D / 4), c4 = (item - ql * (D / 4)) * 4;
+        float mall = Mpart[ql];
+#pragma unroll
+        for (int ww = 1; ww < NS; ++ww) mall = fmaxf(mall, Mpart[ww * 16 + ql]);
+        float den = 0.f;
+        float4 num = make_float4(0.f, 0.f, 0.f, 0.f);
+        float bs[NREL];
+#pragma unroll
+        for (int e = 0; e < NREL; ++e) bs[e] = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < NS; ++ww) {
+            const float cw = expf(Mpart[ww * 16 + ql] - mall);
+            den = fmaf(cw, Lpart[ww * 16 + ql], den);
+            const float4 ov = *reinterpret_cast<const float4*>(Opart + (ww * 16 + ql) * OLD + c4);
+            num.x = fmaf(cw, ov.x, num.x); num.y = fmaf(cw, ov.y, num.y);
+            num.z = fmaf(cw, ov.z, num.z); num.w = fmaf(cw, ov.w, num.w);
+            if (has_rel) {
+#pragma unroll
+                for (int e = 0; e < NREL; ++e) bs[e] = fmaf(cw, Bpart[(ww * 16 + ql) * BST + e], bs[e]);
+            }
+        }
+        if (has_rel) {
+#pragma unroll
+            for (int e = 0; e < NREL; ++e) {
+                if (e < nrel) {
+                    const float4 ev = *reinterpret_cast<const float4*>(Ev + e * D + c4);
+                    num.x = fmaf(bs[e], ev.x, num.x); num.y = fmaf(bs[e], ev.y, num.y);
+                    num.z = fmaf(bs[e], ev.z, num.z); num.w = fmaf(bs[e], ev.w, num.w);
                 }
             }
         }
-        mrun = mnew;
-    }
-
-    // merge the NW partial states (wave 0 owns the result)
-    if (w > 0) {
-        float* pw = part + (w - 1) * (D + 2) * 64 + lane;
-        pw[0] = mrun;
-        pw[64] = lrun;
-#pragma unroll
-        for (int d = 0; d < D; ++d) pw[(2 + d) * 64] = oacc[d];
-    }
-    __syncthreads();
-    if (w == 0) {
-        float mall = mrun;
-#pragma unroll
-        for (int ww = 1; ww < NW; ++ww) mall = fmaxf(mall, part[(ww - 1) * (D + 2) * 64 + lane]);
-        float c0 = expf(mrun - mall);
-        float lall = lrun * c0;
-#pragma unroll
-        for (int d = 0; d < D; ++d) oacc[d] *= c0;
-#pragma unroll
-        for (int ww = 1; ww < NW; ++ww) {
-            const float* pw = part + (ww - 1) * (D + 2) * 64 + lane;
-            const float cw = expf(pw[0] - mall);
-            lall += pw[64] * cw;
-#pragma unroll
-            for (int d = 0; d < D; ++d) oacc[d] = fmaf(pw[(2 + d) * 64], cw, oacc[d]);
-        }
-        if (qvalid) {
-            const float inv = 1.0f / lall;
-            float* op = p.o + (long long)b * p.o_bs + (long long)qi * p.ldo + h * D;
-#pragma unroll
-            for (int d = 0; d < D; d += 4)
-                *reinterpret_cast<float4*>(op + d) = make_float4(oacc[d] * inv, oacc[d + 1] * inv, oacc[d + 2] * inv, oacc[d + 3] * inv);
+        const int qrow = q0 + ql;
+        if (qrow < T) {
+            const float inv = 1.0f / den;
+            *reinterpret_cast<float4*>(ob + (long long)qrow * p.ldo + c4) = make_float4(num.x * inv, num.y * inv, num.z * inv, num.w * inv);
         }
     }
 }
 
 template <int D>
 int launch_attn(const AttnArgs& a, int batch, void* stream) {
-    dim3 grid((a.t + 63) / 64, a.heads, batch);
-    SVCMI_LAUNCH((attention_kernel<D>), grid, dim3(64 * NW), 0, stream, a);
+    // key-split NS: ~2 waves per SIMD (1024 SIMDs), but keep >= 64 keys per wave
+    const long long blocks = (long long)a.nq * a.heads * batch;
+    int ns = 1;
+    while (ns < 8 && blocks * ns < 2048 && a.t >= 128 * ns) ns *= 2;
+    dim3 grid((unsigned)blocks);
+    switch (ns) {
+        case 1: SVCMI_LAUNCH((attention_kernel<D, 1>), grid, dim3(64), 0, stream, a); break;
+        case 2: SVCMI_LAUNCH((attention_kernel<D, 2>), grid, dim3(128), 0, stream, a); break;
+        case 4: SVCMI_LAUNCH((attention_kernel<D, 4>), grid, dim3(256), 0, stream, a); break;
+        default: SVCMI_LAUNCH((attention_kernel<D, 8>), grid, dim3(512), 0, stream, a); break;
+    }
     return SVCMI_LAST_ERROR();
 }
 
@@ -252,11 +387,11 @@ extern "C" int svcmi_attention_f32(const float* q, const float* k, const float* 
     if (ldq % 4 || ldk % 4 || ldv % 4 || ldo % 4 || q_bstride % 4 || k_bstride % 4 || v_bstride % 4 || o_bstride % 4)
         return SVCMI_EALIGN;
     if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)o & 15)) return SVCMI_EALIGN;
-    if (batch > 65535 || heads > 65535) return SVCMI_EUNSUPPORTED;
+    if ((long long)batch * heads * ((t + 15) / 16) > 0x7fffffffLL) return SVCMI_EUNSUPPORTED;
     AttnArgs a;
     a.q = q; a.k = k; a.v = v; a.o = o; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
     a.q_bs = q_bstride; a.k_bs = k_bstride; a.v_bs = v_bstride; a.o_bs = o_bstride;
-    a.t = t; a.heads = heads; a.scale = scale; a.rel_k = rel_k; a.rel_v = rel_v; a.window = window; a.lengths = lengths;
+    a.t = t; a.heads = heads; a.nq = (t + 15) / 16; a.scale = scale; a.rel_k = rel_k; a.rel_v = rel_v; a.window = window; a.lengths = lengths;
     switch (head_dim) {
         case 16: return launch_attn<16>(a, batch, stream);
         case 32: return launch_attn<32>(a, batch, stream);

@@ -24,6 +24,13 @@ __device__ __forceinline__ svcmi_f32x16 svcmi_mfma_32x32x2(float a, float b, svc
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// D = A(16x4) * B(4x16) + C, exact fp32 (v_mfma_f32_16x16x4_f32; 32-cycle issue, 40-cycle dependent latency, so
+// keep >= 2 independent accumulators in flight).  Lane l supplies A[i=l&15][k=l>>4] and B[k=l>>4][j=l&15];
+// C/D: col = l&15, row = 4*(l>>4) + r.
+__device__ __forceinline__ svcmi_f32x4 svcmi_mfma_16x16x4(float a, float b, svcmi_f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
 // Asynchronous global -> LDS copy (LDS-DMA, global_load_lds_dword[x4]).  `lds_wave_base` is wave-uniform; lane
 // l's 16 (4) bytes land at lds_wave_base + 16*l (4*l) bytes.  Issued through inline asm ON PURPOSE: with the
 // builtin hipcc models the DMA as a pending LDS write and puts s_waitcnt vmcnt(0) in front of the next
