@@ -1,0 +1,82 @@
+#!/usr/bin/env python
+"""Kernel microbenchmarks on the GPU box (tuning aid, not the judged bench):
+    python scripts/microbench.py gemm|snake|dec|attn [...]
+Times single kernels through the C ABI on the launch stream with HIP events, prints TFLOP/s or GB/s."""
+import math
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "whisper-vits-svc_amd")):
+    sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+from svcmi import Ops  # noqa: E402
+from svcmi import weights as PW  # noqa: E402
+
+
+def timeit(fn, iters=30, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters      # us
+
+
+def gemm(ops, tag, T, cin, n, k=1, dil=1, res=False, tiles=(0, 1, 2, 3), splits=(1, 0), B=1):
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, T, cin, generator=g).cuda()
+    w = PW.pack_conv(torch.randn(n, cin, k, generator=g) / math.sqrt(cin * k)).cuda()
+    bias = torch.randn(n, generator=g).cuda()
+    r = torch.randn(B, T, n, generator=g).cuda() if res else None
+    out = torch.empty(B, T, n, device="cuda")
+    fl = 2.0 * B * T * n * k * cin
+    for tile in tiles:
+        for sk in splits:
+            try:
+                us = timeit(lambda: ops.conv(x, w, bias, ksize=k, dilation=dil, pad=(k - 1) * dil // 2, res=r, out=out, tile=tile, split_k=sk, n_out=n))
+                print(f"gemm {tag:18s} T={T} cin={cin} n={n} k={k} d={dil} tile={tile} split={sk}: {us:8.1f} us  {fl / us / 1e6:7.1f} TF/s", flush=True)
+            except Exception as e:      # noqa: BLE001
+                print(f"gemm {tag} tile={tile} split={sk}: {e}")
+
+
+def main():
+    what = sys.argv[1:] or ["gemm", "snake", "dec", "attn"]
+    ops = Ops()
+    if "gemm" in what:
+        gemm(ops, "whisper_qkv", 500, 1280, 3840)
+        gemm(ops, "whisper_o", 500, 1280, 1280, res=True, splits=(1, 0, 2, 4))
+        gemm(ops, "whisper_mlp1", 500, 1280, 5120)
+        gemm(ops, "whisper_mlp2", 500, 5120, 1280, res=True, splits=(1, 0, 4, 8))
+    if "dec" in what:
+        for (C, n) in ((160, 5000), (80, 20000), (40, 80000), (20, 160000), (10, 320000)):
+            for k, d in ((3, 1), (7, 3), (11, 5), (11, 1)):
+                gemm(ops, f"amp_C{C}", n, (C + 3) // 4 * 4, C, k=k, dil=d, res=True, tiles=(0,), splits=(0,))
+    if "snake" in what:
+        filt = torch.tensor([0.00202896, 0.00938947, -0.02554346, -0.05765738, 0.12857258, 0.44320980, 0.44320980,
+                             0.12857258, -0.05765738, -0.02554346, 0.00938947, 0.00202896], device="cuda")
+        for (C, n) in ((160, 5000), (80, 20000), (40, 80000), (20, 160000), (10, 320000)):
+            ld = (C + 3) // 4 * 4
+            x = torch.randn(1, n, ld, device="cuda")
+            al, be = torch.randn(ld, device="cuda") * 0.3, torch.randn(ld, device="cuda") * 0.3
+            y = torch.empty_like(x)
+            us = timeit(lambda: ops.snake_alias(x, al, be, filt, out=y))
+            print(f"snake C={C} n={n}: {us:8.1f} us  {8.0 * C * n / us / 1e3:7.1f} GB/s", flush=True)
+    if "attn" in what:
+        for (T, H, D, rel) in ((500, 20, 64, False), (1000, 2, 96, True), (1500, 20, 64, False), (2520, 2, 96, True)):
+            qkv = torch.randn(1, T, 3 * H * D, device="cuda")
+            rk = torch.randn(9, D, device="cuda") * 0.1 if rel else None
+            rv = torch.randn(9, D, device="cuda") * 0.1 if rel else None
+            out = torch.empty(1, T, H * D, device="cuda")
+            us = timeit(lambda: ops.attention(qkv, H, D ** -0.5, rel_k=rk, rel_v=rv, window=4 if rel else 0, out=out))
+            print(f"attn T={T} H={H} D={D} rel={rel}: {us:8.1f} us  {4.0 * T * T * H * D / us / 1e6:7.1f} TF/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
