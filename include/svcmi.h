@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SVCMI_ABI_VERSION 2
+#define SVCMI_ABI_VERSION 3
 
 enum svcmi_status { SVCMI_OK = 0, SVCMI_EINVAL = -1, SVCMI_EUNSUPPORTED = -2, SVCMI_EALIGN = -3 };
 
@@ -126,6 +126,21 @@ int svcmi_attention_f32(const float* q, const float* k, const float* v, float* o
  * alpha_log/beta_log: [c]; filt: the 12 taps (filter.py:28-57).  SURVEY.md A.5. */
 int svcmi_snake_alias_f32(const float* x, float* y, const float* alpha_log, const float* beta_log,
                           const float* filt, int32_t batch, int32_t len, int32_t c, int32_t ld, void* stream);
+
+/* Fused AMP half-step for the narrow generator stages (vits_decoder/bigv.py:50-58: `xt = act(x); xt = conv(xt)`):
+ *   y[b,t,n] = alpha * ( bias[n] + sum_{k<ksize} sum_{ci<c} w[n, k*ld + ci] * S[b, t + (k - (ksize-1)/2)*dilation, ci]
+ *                        + res[b,t,n] )  (+ y_old[b,t,n] when accumulate != 0),      n < c
+ * with S = SnakeAlias(x) exactly as svcmi_snake_alias_f32 computes it and S rows outside [0, len) read as zero
+ * (the convolution's 'same' zero padding, stride 1).  x, y, res: [batch][len][ld] time-major; channels c..ld-1
+ * of y are written as zero.  w: [ld][ldw] packed like svcmi_conv_gemm_f32's (tap-major, ld channels per tap).
+ * res may alias y; x must not.  Supported shapes: (c, ld) in {(10,12), (20,20), (40,40)}, ksize in {3,7,11},
+ * dilation 1..5 -- svcmi_snake_conv_supported() tells; other shapes return SVCMI_EUNSUPPORTED and the caller
+ * uses svcmi_snake_alias_f32 + svcmi_conv_gemm_f32. */
+int svcmi_snake_conv_supported(int32_t c, int32_t ld, int32_t ksize, int32_t dilation);
+int svcmi_snake_conv_f32(const float* x, const float* w, const float* bias, const float* res, float* y,
+                         const float* alpha_log, const float* beta_log, const float* filt,
+                         int32_t batch, int32_t len, int32_t c, int32_t ld, int32_t ldw, int32_t ksize,
+                         int32_t dilation, float alpha, int32_t accumulate, void* stream);
 
 /* WaveNet gate, vits/commons.py:126-133 with input_b == 0 (vits/modules.py:190-193):
  *   out[r, c] = tanh(a[r, c]) * sigmoid(a[r, h + c]),  c < h. */

@@ -54,6 +54,13 @@ def main():
         gemm(ops, "whisper_o", 500, 1280, 1280, res=True, splits=(1, 0, 2, 4))
         gemm(ops, "whisper_mlp1", 500, 1280, 5120)
         gemm(ops, "whisper_mlp2", 500, 5120, 1280, res=True, splits=(1, 0, 4, 8))
+    if "gemmpmc" in what:     # few launches, for counter collection
+        global timeit
+        _t = timeit
+        timeit = lambda fn, iters=3, warm=1: _t(fn, iters, warm)
+        gemm(ops, "whisper_mlp1", 500, 1280, 5120, tiles=(1, 2, 3), splits=(1,))
+        gemm(ops, "whisper_mlp2", 500, 5120, 1280, res=True, tiles=(1, 3), splits=(8, 1))
+        gemm(ops, "square4096", 4096, 4096, 4096, tiles=(1, 2, 3), splits=(1,))
     if "dec" in what:
         for (C, n) in ((160, 5000), (80, 20000), (40, 80000), (20, 160000), (10, 320000)):
             for k, d in ((3, 1), (7, 3), (11, 5), (11, 1)):
@@ -68,6 +75,20 @@ def main():
             y = torch.empty_like(x)
             us = timeit(lambda: ops.snake_alias(x, al, be, filt, out=y))
             print(f"snake C={C} n={n}: {us:8.1f} us  {8.0 * C * n / us / 1e3:7.1f} GB/s", flush=True)
+    if "amp" in what:
+        filt = torch.tensor([0.00202896, 0.00938947, -0.02554346, -0.05765738, 0.12857258, 0.44320980, 0.44320980,
+                             0.12857258, -0.05765738, -0.02554346, 0.00938947, 0.00202896], device="cuda")
+        for (C, n) in ((40, 80000), (20, 160000), (10, 320000)):
+            ld = (C + 3) // 4 * 4
+            x = torch.randn(1, n, ld, device="cuda")
+            r = torch.randn(1, n, ld, device="cuda")
+            al, be = torch.randn(ld, device="cuda") * 0.3, torch.randn(ld, device="cuda") * 0.3
+            y = torch.empty_like(x)
+            for k, d in ((3, 1), (7, 3), (11, 5), (11, 1)):
+                w = PW.pack_conv(torch.randn(C, C, k) / math.sqrt(C * k), ld, ld).cuda()
+                bias = torch.randn(ld, device="cuda")
+                us = timeit(lambda: ops.snake_conv(x, al, be, filt, w, bias, c=C, ksize=k, dilation=d, res=r, out=y))
+                print(f"amp C={C} n={n} k={k} d={d}: {us:8.1f} us  conv {2.0 * C * C * k * n / us / 1e6:6.1f} TF/s", flush=True)
     if "attn" in what:
         for (T, H, D, rel) in ((500, 20, 64, False), (1000, 2, 96, True), (1500, 20, 64, False), (2520, 2, 96, True)):
             qkv = torch.randn(1, T, 3 * H * D, device="cuda")

@@ -134,7 +134,20 @@ static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((un
     emu::launch(grid, block, [=]() { kernel(__VA_ARGS__); })
 #define SVCMI_LAST_ERROR() (emu::g_last_error)
 #define SVCMI_UNIFORM(x) (x)
-// LDS-DMA emulation: lane l copies its 16 (4) bytes to lds_wave_base + 16*l (4*l); synchronous here.
-static inline void svcmi_glds16(const float* g, float* lds_wave_base) { memcpy(lds_wave_base + 4 * emu::cur_lane(), g, 16); }
-static inline void svcmi_glds4(const float* g, float* lds_wave_base) { memcpy(lds_wave_base + emu::cur_lane(), g, 4); }
+// LDS-DMA emulation (buffer form): lane l copies its 16 (4) bytes from rsrc.base + voff to lds_wave_base + 16*l
+// (4*l); an out-of-range lane writes zeros, like the hardware.  Synchronous here.  `lds_wave_base` is the LDS
+// "address" svcmi_lds_addr() returned -- in the emulator simply the pointer.
+struct svcmi_rsrc { const char* base; unsigned bytes; };
+static inline svcmi_rsrc svcmi_make_rsrc(const void* base, unsigned bytes) { return svcmi_rsrc{(const char*)base, bytes}; }
+typedef float* svcmi_ldsaddr;
+static inline svcmi_ldsaddr svcmi_lds_addr(float* lds_ptr) { return lds_ptr; }
+static inline svcmi_ldsaddr svcmi_lds_advance(svcmi_ldsaddr a, int floats) { return a + floats; }
+static inline void svcmi_bdma16(unsigned voff, float* lds_wave_base, svcmi_rsrc r) {
+    float* dst = lds_wave_base + 4 * emu::cur_lane();
+    if ((unsigned long long)voff + 16 <= r.bytes) memcpy(dst, r.base + voff, 16); else memset(dst, 0, 16);
+}
+static inline void svcmi_bdma4(unsigned voff, float* lds_wave_base, svcmi_rsrc r) {
+    float* dst = lds_wave_base + emu::cur_lane();
+    if ((unsigned long long)voff + 4 <= r.bytes) memcpy(dst, r.base + voff, 4); else memset(dst, 0, 4);
+}
 static inline void svcmi_dma_wait() {}

@@ -183,6 +183,51 @@ def check_snake(ops, n, c, device):
     _close(got, want, 1e-5, f"snake n={n} c={c}")
 
 
+SNAKE_CONV_CASES = [
+    dict(id="c10_k3_d1_short", B=2, n=37, c=10, ld=12, k=3, d=1),
+    dict(id="c10_k11_d5_res_acc", B=1, n=1100, c=10, ld=12, k=11, d=5, res=True, alpha=1.0 / 3.0, accumulate=True),
+    dict(id="c20_k7_d3_res", B=1, n=530, c=20, ld=20, k=7, d=3, res=True),
+    dict(id="c20_k11_d1", B=2, n=70, c=20, ld=20, k=11, d=1),
+    dict(id="c40_k11_d5_res", B=1, n=300, c=40, ld=40, k=11, d=5, res=True),
+    dict(id="c40_k3_d1_tiny", B=1, n=5, c=40, ld=40, k=3, d=1, res=True),
+]
+
+
+def check_snake_conv(ops, c_, device):
+    """Fused SnakeAlias -> conv half-step vs oracle SnakeAlias + torch conv1d."""
+    g = _g(hash(c_["id"]) % 10000)
+    B, n, c, ld, k, d = c_["B"], c_["n"], c_["c"], c_["ld"], c_["k"], c_["d"]
+    x = torch.zeros(B, n, ld)
+    x[..., :c] = torch.randn(B, n, c, generator=g) * 1.5
+    al, be = torch.zeros(ld), torch.zeros(ld)
+    al[:c], be[:c] = torch.randn(c, generator=g) * 0.3, torch.randn(c, generator=g) * 0.3
+    filt = W.kaiser_sinc_filter().view(-1)
+    w = torch.randn(c, c, k, generator=g) / math.sqrt(c * k)
+    bias = torch.randn(c, generator=g)
+    s = O.snake_alias(x[..., :c].transpose(1, 2), al[:c], be[:c], filt)
+    ref = F.conv1d(s, w, bias, dilation=d, padding=(k - 1) * d // 2).transpose(1, 2)
+    res = None
+    if c_.get("res"):
+        res = torch.zeros(B, n, ld)
+        res[..., :c] = torch.randn(B, n, c, generator=g)
+        ref = ref + res[..., :c]
+    alpha = c_.get("alpha", 1.0)
+    ref = ref * alpha
+    y0 = None
+    if c_.get("accumulate"):
+        y0 = torch.zeros(B, n, ld)
+        y0[..., :c] = torch.randn(B, n, c, generator=g)
+        ref = ref + y0[..., :c]
+    dev = lambda t: None if t is None else t.to(device)
+    wp = PW.pack_conv(w, ld, ld).to(device)
+    assert ops.snake_conv_supported(c, ld, k, d)
+    out = dev(y0.clone()) if y0 is not None else torch.full((B, n, ld), 7.0).to(device)
+    got = ops.snake_conv(dev(x), dev(al), dev(be), dev(filt), wp, dev(PW.pad_vec(bias, ld)), c=c, ksize=k, dilation=d,
+                         res=dev(res), alpha=alpha, accumulate=c_.get("accumulate", False), out=out)
+    _close(got[..., :c], ref, 2e-5, c_["id"])
+    assert float(got[..., c:].abs().max()) == 0.0 if ld > c else True
+
+
 def check_flow_glue(ops, device):
     g = _g(11)
     B, T, H = 2, 13, 8

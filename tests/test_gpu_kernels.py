@@ -36,6 +36,18 @@ def test_snake_alias(ops, n, c):
     K.check_snake(ops, n, c, device="cuda")
 
 
+SNAKE_CONV_LARGE = [
+    dict(id="stage4_c10_k11_d5", B=1, n=320000, c=10, ld=12, k=11, d=5, res=True),
+    dict(id="stage3_c20_k7_d3", B=1, n=160000, c=20, ld=20, k=7, d=3, res=True, alpha=1.0 / 3.0, accumulate=True),
+    dict(id="stage2_c40_k3_d1", B=2, n=80000, c=40, ld=40, k=3, d=1, res=True),
+]
+
+
+@pytest.mark.parametrize("case", K.SNAKE_CONV_CASES + SNAKE_CONV_LARGE, ids=lambda c: c["id"])
+def test_snake_conv_fused(ops, case):
+    K.check_snake_conv(ops, case, device="cuda")
+
+
 def test_flow_glue(ops):
     K.check_flow_glue(ops, device="cuda")
 

@@ -39,6 +39,11 @@ def test_snake_alias(ops, n, c):
     K.check_snake(ops, n, c, device="cpu")
 
 
+@pytest.mark.parametrize("case", K.SNAKE_CONV_CASES, ids=lambda c: c["id"])
+def test_snake_conv_fused(ops, case):
+    K.check_snake_conv(ops, case, device="cpu")
+
+
 def test_flow_glue(ops):
     K.check_flow_glue(ops, device="cpu")
 

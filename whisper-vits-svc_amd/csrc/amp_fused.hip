@@ -1,0 +1,244 @@
+// amp_fused.hip -- the AMP half-step of the narrow BigVGAN stages as ONE kernel:
+//     y = alpha * ( conv_{k,d}( SnakeAlias(x) ) + bias + res )  (+ y_old)
+// (vits_decoder/bigv.py:50-58: `xt = act(x); xt = conv(xt)` twice per iteration; generator.py:188-194).
+//
+// Why not the matrix cores here: the stages with 40 / 20 / 10 channels are 1.4 / 0.7 / 0.35 GMAC per k=11
+// convolution, and the fp32 MFMA runs at exactly the fp32 VALU rate (MI355X_MICROARCH.md) -- an MFMA tile padded
+// from 10 to 16/32 output channels and from k*C to a multiple of 4 simply wastes that fraction, while a direct
+// convolution on the vector ALUs wastes nothing.  What the VALU formulation needs is operand delivery that
+// does not cost VALU issue slots:
+//   * weights are wave-uniform (all 64 lanes of a wave compute the same output channels), so they arrive
+//     through the scalar cache as SGPR operands of v_fmac (s_load_dwordx4, no LDS, no VGPR);
+//   * the activated input S = SnakeAlias(x) of a time tile (+ conv halo) is computed once per block into LDS
+//     (each up-sampled SnakeBeta value evaluated 1.6x instead of 6x), rows outside the sequence are zero (the
+//     convolution's zero padding), and a lane reads its row as ds_read_b128 -- row stride = 4*odd floats, so the
+//     16-lane groups are bank-conflict free;
+//   * a thread keeps TT time steps x CO output channels of accumulators (40 VGPRs): every weight SGPR feeds TT
+//     FMAs, every input VGPR feeds CO FMAs.
+// The G waves-groups of a block split the output channels (G = 1, 2, 4 for 10, 20, 40 channels); the other
+// 4/G wave-groups take further time sub-tiles.  Launch-wise this replaces two kernels (activation, convolution)
+// and one HBM round trip of the activation tensor per half-step.
+#include "svcmi_rt.h"
+#include "../../include/svcmi.h"
+
+namespace {
+
+constexpr int TPB = 256;
+constexpr int RT = 8;        // SnakeAlias outputs per work item (run along time)
+constexpr int TT = 4;        // time steps per thread in the convolution
+constexpr int CO = 10;       // output channels per thread
+constexpr int DMAX = 5;      // largest dilation (bigv.py dilations 1, 3, 5)
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// sin^2 by range reduction to [-pi/2, pi/2] + degree-11 minimax polynomial (see generator.hip: sin_sq)
+__device__ __forceinline__ float sin_sq(float x) {
+    if (fabsf(x) > 1.0e5f) { const float sl = sinf(x); return sl * sl; }
+    const float n = rintf(x * 0.31830987f);
+    float r = fmaf(-n, 3.1415927f, x);
+    r = fmaf(-n, -8.742278e-08f, r);
+    const float u = r * r;
+    float p = -2.3840804885821854e-08f;
+    p = fmaf(p, u, 2.7522235086507862e-06f);
+    p = fmaf(p, u, -0.00019840795721393079f);
+    p = fmaf(p, u, 0.008333330042660236f);
+    p = fmaf(p, u, -0.1666666716337204f);
+    const float sn = fmaf(r * u, p, r);
+    return sn * sn;
+}
+__device__ __forceinline__ float snake_fn(float y, float a, float inv_b) { return fmaf(inv_b, sin_sq(y * a), y); }
+
+__device__ __forceinline__ float snake_s_at(const float* xc, int ld, int n, int u, const float* f, float a, float inv_b) {
+    const int tq = u >> 1, odd = u & 1;
+    float y = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) y = fmaf(f[2 * j + 1 - odd], xc[(long long)clampi(tq + 2 + odd - j, 0, n - 1) * ld], y);
+    return snake_fn(2.f * y, a, inv_b);
+}
+
+struct AmpArgs {
+    const float* x; const float* w; const float* bias; const float* res; float* y;
+    const float* alpha_log; const float* beta_log; const float* filt;
+    int n, ld, ldw, dil, accumulate;
+    float alpha;
+};
+
+// CP = padded channels (row length of x / y / res and of a weight tap), CR = real channels, KS = taps, G = channel groups.
+template <int CP, int CR, int KS, int G>
+__global__ __launch_bounds__(TPB) void snake_conv_kernel(AmpArgs p) {
+    constexpr int TSUB = 4 / G;                       // time sub-tiles per block
+    constexpr int TB = TSUB * 64 * TT;                // output rows per block
+    constexpr int LS = (CP / 4) % 2 ? CP : CP + 4;    // LDS row stride: 4 * odd floats
+    constexpr int ROWS = TB + (KS - 1) * DMAX;
+    static_assert(G * CO >= CR && CP % 4 == 0 && CP >= CR, "channel split");
+    __shared__ __attribute__((aligned(16))) float S[ROWS * LS];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = SVCMI_UNIFORM((int)(tid >> 6));
+    const int b = blockIdx.y;
+    const int n = p.n, ld = p.ld, d = p.dil;
+    const int halo = (KS - 1) * d / 2;
+    const int t_blk = blockIdx.x * TB;                // first output row of the block
+    const int rows = TB + 2 * halo;                   // S rows used: S row r <-> time t_blk - halo + r
+    const float* xb = p.x + (long long)b * n * ld;
+
+    // ---- phase A: S = SnakeAlias(x) for the tile + halo; zero outside [0, n) and in the pad channels
+    {
+        float f[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) f[k] = p.filt[k];
+        const int runs = (rows + RT - 1) / RT;
+        for (int item = tid; item < runs * CP; item += TPB) {
+            const int ch = item % CP, run = item / CP;
+            const int r0 = run * RT;                  // S row of the run
+            const int t0 = t_blk - halo + r0;         // its time
+            float out[RT];
+            if (ch >= CR || t0 + RT <= 0 || t0 >= n) {
+#pragma unroll
+                for (int r = 0; r < RT; ++r) out[r] = 0.f;
+            } else {
+                const float a = expf(p.alpha_log[ch]);
+                const float inv_b = 1.0f / (expf(p.beta_log[ch]) + 1e-9f);
+                const float* xc = xb + ch;
+                float xw[RT + 10];
+#pragma unroll
+                for (int i = 0; i < RT + 10; ++i) xw[i] = xc[(long long)clampi(t0 - 5 + i, 0, n - 1) * ld];
+                float s[2 * RT + 10];
+#pragma unroll
+                for (int m = 0; m < RT + 5; ++m) {
+                    float yo = 0.f, ye = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        yo = fmaf(f[2 * j], xw[5 - j + m], yo);
+                        ye = fmaf(f[2 * j + 1], xw[5 - j + m], ye);
+                    }
+                    s[2 * m] = snake_fn(2.f * yo, a, inv_b);
+                    s[2 * m + 1] = snake_fn(2.f * ye, a, inv_b);
+                }
+                const int u0 = 2 * t0 - 5;
+                if (u0 < 0 || u0 + 2 * RT + 9 > 2 * n - 1) {
+                    const float s_first = snake_s_at(xc, ld, n, 0, f, a, inv_b);
+                    const float s_last = snake_s_at(xc, ld, n, 2 * n - 1, f, a, inv_b);
+#pragma unroll
+                    for (int j = 0; j < 2 * RT + 10; ++j) {
+                        const int u = u0 + j;
+                        s[j] = u < 0 ? s_first : (u > 2 * n - 1 ? s_last : s[j]);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < RT; ++r) {
+                    float z = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) z = fmaf(f[k], s[2 * r + k], z);
+                    const int t = t0 + r;
+                    out[r] = (t >= 0 && t < n) ? z : 0.f;      // the convolution's zero padding
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+                if (r0 + r < rows) S[(r0 + r) * LS + ch] = out[r];
+        }
+    }
+    __syncthreads();
+
+    // ---- phase B: direct convolution from LDS with SGPR weights
+    const int g = wave % G, tsub = wave / G;           // wave-uniform
+    const int co0 = g * CO;
+    constexpr int NCO = CO;                            // channels of this group (the last group may own fewer real ones)
+    float acc[TT][NCO];
+#pragma unroll
+    for (int c = 0; c < NCO; ++c) {
+        const float bv = (co0 + c < CR && p.bias) ? p.bias[co0 + c] : 0.f;
+#pragma unroll
+        for (int j = 0; j < TT; ++j) acc[j][c] = bv;
+    }
+    const int tl0 = tsub * 64 * TT + lane;             // tile-local time of this lane's first step; steps are 64 apart
+    const float* wg = p.w + (long long)co0 * p.ldw;
+    for (int tap = 0; tap < KS; ++tap) {
+        const float* srow = S + (tl0 + tap * d) * LS;  // S row of output tl0 at this tap: tl0 + halo + (tap - (KS-1)/2)*d
+        const float* wt = wg + tap * CP;
+#pragma unroll
+        for (int c4 = 0; c4 < (CR + 3) / 4; ++c4) {
+            float4 xin[TT];
+#pragma unroll
+            for (int j = 0; j < TT; ++j) xin[j] = *reinterpret_cast<const float4*>(srow + j * 64 * LS + 4 * c4);
+#pragma unroll
+            for (int c = 0; c < NCO; ++c) {
+                if (co0 + c < CR) {                    // wave-uniform
+                    const float4 wv = *reinterpret_cast<const float4*>(wt + (long long)c * p.ldw + 4 * c4);   // uniform address: scalar load
+#pragma unroll
+                    for (int j = 0; j < TT; ++j) {
+                        acc[j][c] = fmaf(wv.x, xin[j].x, acc[j][c]);
+                        if (4 * c4 + 1 < CR) acc[j][c] = fmaf(wv.y, xin[j].y, acc[j][c]);
+                        if (4 * c4 + 2 < CR) acc[j][c] = fmaf(wv.z, xin[j].z, acc[j][c]);
+                        if (4 * c4 + 3 < CR) acc[j][c] = fmaf(wv.w, xin[j].w, acc[j][c]);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: + res, * alpha, (+ y_old); pad channels of the last group are written as zero
+    float* yb = p.y + (long long)b * n * ld;
+    const float* rb = p.res ? p.res + (long long)b * n * ld : nullptr;
+#pragma unroll
+    for (int j = 0; j < TT; ++j) {
+        const int t = t_blk + tl0 + 64 * j;
+        if (t >= n) continue;
+        float* yr = yb + (long long)t * ld + co0;
+        const float* rr = rb ? rb + (long long)t * ld + co0 : nullptr;
+#pragma unroll
+        for (int c = 0; c < NCO; c += 2) {
+            float v0 = acc[j][c], v1 = acc[j][c + 1];
+            if (co0 + c >= CR) { v0 = 0.f; v1 = 0.f; }
+            else {
+                if (rr) { const float2 r2 = *reinterpret_cast<const float2*>(rr + c); v0 += r2.x; v1 += r2.y; }
+                v0 *= p.alpha; v1 *= p.alpha;
+                if (p.accumulate) { const float2 o2 = *reinterpret_cast<const float2*>(yr + c); v0 += o2.x; v1 += o2.y; }
+            }
+            *reinterpret_cast<float2*>(yr + c) = make_float2(v0, v1);
+        }
+        if (g == G - 1) {                              // pad channels [G*CO, CP) stay exactly zero
+#pragma unroll
+            for (int c = G * CO; c < CP; c += 2) *reinterpret_cast<float2*>(yb + (long long)t * ld + c) = make_float2(0.f, 0.f);
+        }
+    }
+}
+
+template <int CP, int CR, int G>
+int launch_amp(const AmpArgs& a, int batch, int ksize, void* stream) {
+    constexpr int TB = (4 / G) * 64 * TT;
+    dim3 grid((unsigned)((a.n + TB - 1) / TB), (unsigned)batch);
+    switch (ksize) {
+        case 3: SVCMI_LAUNCH((snake_conv_kernel<CP, CR, 3, G>), grid, dim3(TPB), 0, stream, a); break;
+        case 7: SVCMI_LAUNCH((snake_conv_kernel<CP, CR, 7, G>), grid, dim3(TPB), 0, stream, a); break;
+        case 11: SVCMI_LAUNCH((snake_conv_kernel<CP, CR, 11, G>), grid, dim3(TPB), 0, stream, a); break;
+        default: return SVCMI_EUNSUPPORTED;
+    }
+    return SVCMI_LAST_ERROR();
+}
+
+}  // namespace
+
+extern "C" int svcmi_snake_conv_supported(int32_t c, int32_t ld, int32_t ksize, int32_t dilation) {
+    const bool shape = (c == 10 && ld == 12) || (c == 20 && ld == 20) || (c == 40 && ld == 40);
+    return shape && (ksize == 3 || ksize == 7 || ksize == 11) && dilation >= 1 && dilation <= DMAX;
+}
+
+extern "C" int svcmi_snake_conv_f32(const float* x, const float* w, const float* bias, const float* res, float* y,
+                                    const float* alpha_log, const float* beta_log, const float* filt,
+                                    int32_t batch, int32_t len, int32_t c, int32_t ld, int32_t ldw, int32_t ksize,
+                                    int32_t dilation, float alpha, int32_t accumulate, void* stream) {
+    if (!x || !w || !y || !alpha_log || !beta_log || !filt || batch <= 0 || len <= 0) return SVCMI_EINVAL;
+    if (x == y) return SVCMI_EINVAL;                  // halo reads: not an in-place op (res may alias y)
+    if (!svcmi_snake_conv_supported(c, ld, ksize, dilation)) return SVCMI_EUNSUPPORTED;
+    if (ldw < ksize * ld || ldw % 4 != 0) return SVCMI_EINVAL;
+    if (((uintptr_t)w & 15) || ((uintptr_t)x & 7) || ((uintptr_t)y & 7) || ((uintptr_t)res & 7)) return SVCMI_EALIGN;
+    if (batch > 65535) return SVCMI_EUNSUPPORTED;
+    AmpArgs a;
+    a.x = x; a.w = w; a.bias = bias; a.res = res; a.y = y; a.alpha_log = alpha_log; a.beta_log = beta_log; a.filt = filt;
+    a.n = len; a.ld = ld; a.ldw = ldw; a.dil = dilation; a.accumulate = accumulate; a.alpha = alpha;
+    if (c == 10) return launch_amp<12, 10, 1>(a, batch, ksize, stream);
+    if (c == 20) return launch_amp<20, 20, 2>(a, batch, ksize, stream);
+    return launch_amp<40, 40, 4>(a, batch, ksize, stream);
+}

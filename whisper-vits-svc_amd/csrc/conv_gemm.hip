@@ -7,32 +7,43 @@
 // Tiling (wave64, 256 threads = 2x2 waves):  block tile (64*WM) x (64*WN), wave tile (32*WM) x (32*WN)
 // as WM x WN accumulators of v_mfma_f32_32x32x2_f32 (16 VGPR each).  K is walked in steps of 32:
 // both operands are K-contiguous in HBM and go straight to LDS with 16-byte LDS-DMA
-// (global_load_lds_dwordx4: no VGPR round trip, nothing to wait for until the tile is consumed), double
+// (buffer_load_dwordx4 ... lds: no VGPR round trip, nothing to wait for until the tile is consumed), double
 // buffered so the next tile's DMA flies under the current tile's MFMAs.  The LDS image is [row][32]
-// with the eight 16-byte chunks of a row XOR-swizzled by (row & 7) -- applied on the SOURCE address of the
+// with the eight 16-byte chunks of a row XOR-swizzled by ((row >> 1) & 7) -- applied on the SOURCE offset of the
 // DMA and again on the fragment read -- so the 16-lane groups of ds_read_b128 hit 16 distinct 4-bank slots.
 // K-order trick: a lane's ds_read_b128 returns 4 consecutive k; lanes 0-31 take k = 8s+0..3 and
 // lanes 32-63 take k = 8s+4..7, so MFMA #j of sub-step s multiplies k-pairs (8s+j, 8s+4+j) -- a
 // permutation of the K summation shared by A and B, i.e. the same dot product.
 //
-// Zero fill (padding taps, masked rows, ragged tile edges) is done by pointing the lane's DMA at a 16-byte
-// zero constant: the staging code has no branches and no selects on loaded data.
+// Addressing: each operand is a raw buffer (x of this batch item, bounded at the first masked row; the weight
+// matrix) and a lane's source is a 32-bit byte offset = row part (hoisted out of the K loop) + K part (wave
+// uniform in CHUNK mode) -- one v_add per 1-KiB DMA piece per K-step.  Zero fill (padding taps, masked rows,
+// ragged tile edges, the K tail) is the hardware's buffer range check: rows before the tensor give a negative
+// (huge unsigned) offset, rows past its end run over num_records, and everything else that must read as zero
+// adds a 2^30 sentinel; an out-of-range DMA lane writes zeros to LDS.  The staging code has no branches and no
+// selects on loaded data, and its issue slots are spread over the sub-steps of the previous tile's MFMAs.
 // Three instantiations of the A-gather keep the loop free of per-element integer division:
 //   CHUNK : c_in % 32 == 0 -- a K-step lies inside one tap (scalar tap/channel bookkeeping);
 //   VEC   : c_in % 4 == 0  -- one magic-number division per thread per K-step;
-//   SCALAR: anything else (the 1-channel source convolutions) -- 4-byte loads.
+//   SCALAR: anything else (the 1-channel source convolutions) -- 4-byte DMA.
+// (CHUNK_RS is CHUNK with the np.repeat(x, 2, 0) row shift fused into the gather; it recomputes rows per piece.)
+//
+// Blocks are enumerated M-tile fastest inside contiguous per-XCD ranges (block b runs on XCD b % 8), so all the
+// M tiles that consume one weight tile share an L2 instead of pulling it into all eight.
 //
 // Split-K (deterministic): when the tile grid cannot fill the 256 CUs (M = 500 Whisper rows against
-// N = 1280, or the N = 192 prior-encoder convs with K = 6400) blockIdx.z also enumerates S slices of the
+// N = 1280, or the N = 192 prior-encoder convs with K = 6400) the grid also enumerates S slices of the
 // K range; slices write raw partial tiles to a caller-provided workspace and a second small kernel adds
 // them in fixed order and applies the epilogue.  No atomics anywhere: results are run-to-run identical.
+#include <type_traits>
+
 #include "svcmi_rt.h"
 #include "../../include/svcmi.h"
 
 namespace {
 
 constexpr int BK = 32;
-enum { MODE_CHUNK = 0, MODE_VEC = 1, MODE_SCALAR = 2 };
+enum { MODE_CHUNK = 0, MODE_VEC = 1, MODE_SCALAR = 2, MODE_CHUNK_RS = 3 };   // _RS: CHUNK with x_row_shift != 0
 
 struct ConvArgs {
     const float* x; const float* w; const float* bias; const float* res; float* y; const int32_t* lengths;
@@ -42,6 +53,7 @@ struct ConvArgs {
     int ksize, stride, dil, pad, rshift, act, flags;
     int ktot;                    // ksize * c_in
     int split;                   // K slices (1 = none)
+    int mt, nt;                  // tile grid (time x channels)
     unsigned magic;              // ceil(2^32 / c_in) for the VEC / SCALAR gathers (0 when c_in == 1)
     float alpha;
 };
@@ -72,8 +84,13 @@ __device__ __forceinline__ int div_magic(int q, unsigned magic) {   // q / c_in,
     return magic ? (int)__umulhi((unsigned)q, magic) : q;
 }
 
-// Source of the zero fill: lanes whose (row, k) falls outside the tensor point their LDS-DMA here.
-__device__ const float svcmi_zeros[4] = {0.f, 0.f, 0.f, 0.f};
+// LDS swizzle: the 16-byte chunk c of tile row r is stored at position c ^ swz(r).  A 16-lane ds_read_b128 group
+// reads one chunk column from 16 rows {4 consecutive, 4 consecutive, 8 consecutive}; a 256-byte bank row holds 2
+// tile rows x 8 positions, so the group is conflict-free iff rows of equal parity get distinct positions:
+// swz(r) = (r >> 1) & 7 does that for every group (r & 7 left 2-way conflicts: PMC SQ_LDS_BANK_CONFLICT ~ 50 %).
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+
+constexpr unsigned OOB = 0x40000000u;   // added to an offset that must read as zero; buffers are < 2^29 bytes
 
 template <int WM, int WN, int MODE>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
@@ -88,41 +105,60 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = SVCMI_UNIFORM((int)(tid >> 6));
     const int wm = wave >> 1, wn = wave & 1;
-    const int b = blockIdx.z / p.split, slice = blockIdx.z - b * p.split;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const float* xb = p.x + (long long)b * p.x_bs;
+    // XCD-aware bijective enumeration: XCD g owns a contiguous range of the (z, n-tile, m-tile) order, m fastest
+    int bx, by, bz;
+    {
+        const int total = (int)gridDim.x, id = (int)blockIdx.x;
+        const int q8 = total >> 3, r8 = total & 7, xcd = id & 7, slot = id >> 3;
+        const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+        bx = L % p.mt;
+        const int rest = L / p.mt;
+        by = rest % p.nt;
+        bz = rest / p.nt;
+    }
+    const int b = bz / p.split, slice = bz - b * p.split;
+    const int m0 = bx * BM, n0 = by * BN;
     const int len = p.lengths ? p.lengths[b] : 0x7fffffff;
     const int t_lim = (p.flags & SVCMI_CONV_MASK_IN) ? (len < p.t_in ? len : p.t_in) : p.t_in;
+    // operand buffers: x of this batch item up to the first row that must read as zero; the whole weight matrix
+    const int x_rows = (t_lim + (1 << p.rshift) - 1) >> p.rshift;
+    const svcmi_rsrc xr = svcmi_make_rsrc(p.x + (long long)b * p.x_bs, (unsigned)x_rows * (unsigned)p.ldx * 4u);
+    const svcmi_rsrc wr = svcmi_make_rsrc(p.w, (unsigned)p.n_out * (unsigned)p.ldw * 4u);
 
     const int nk_all = (p.ktot + BK - 1) / BK;
     const int it_beg = (int)((long long)nk_all * slice / p.split);
     const int it_end = (int)((long long)nk_all * (slice + 1) / p.split);
 
-    // LDS image: row r holds its 32 k-values as 8 chunks of 16 B, chunk c stored at position c ^ (r & 7).
+    // LDS image: row r holds its 32 k-values as 8 chunks of 16 B, chunk c stored at position c ^ swz(r).
     // A 1-KiB piece = 8 consecutive rows; the DMA writes lane l at byte 16*l of the piece, i.e. row l>>3,
-    // position l&7, so lane l must FETCH logical chunk (l&7) ^ (l>>3) of that row (swizzle on the source).
+    // position l&7, so lane l must FETCH logical chunk (l&7) ^ swz(row) of that row (swizzle on the source).
     const int prow = lane >> 3;                        // row within a piece
-    const int lkq = ((lane & 7) ^ prow) * 4;           // this lane's k offset within the K-step
+    const int lkq = ((lane & 7) ^ swz(prow + 8 * wave)) * 4;   // this lane's k offset within the K-step (pieces start at multiples of 8 rows: swz(row) only needs row mod 16)
     // K-invariant per-piece state: piece i of this wave covers rows (wave + 4*i)*8 .. +8
-    int a_tb[A_PER];                  // t*stride - pad, or a sentinel that keeps every tap out of range
-    const float* w_row[B_PER];
+    int a_tb[A_PER];                  // first input row of the piece's output row: t*stride - pad
+    unsigned a_row[A_PER];            // its byte offset (x_row_shift == 0), or the OOB sentinel past t_out
+    unsigned b_row[B_PER];
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
         const int t = m0 + (wave + 4 * i) * 8 + prow;
-        a_tb[i] = t < p.t_out ? t * p.stride - p.pad : -0x40000000;
+        a_tb[i] = t * p.stride - p.pad;
+        a_row[i] = t < p.t_out ? (unsigned)a_tb[i] * (unsigned)p.ldx * 4u : OOB;
+        if (t >= p.t_out) a_tb[i] = -0x40000000;
     }
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
         const int n = n0 + (wave + 4 * i) * 8 + prow;
-        w_row[i] = n < p.n_out ? p.w + (long long)n * p.ldw : nullptr;
+        b_row[i] = n < p.n_out ? (unsigned)(n * p.ldw) * 4u : OOB;
     }
     // CHUNK mode: wave-uniform (tap, first channel) of the K-step, advanced incrementally
     int tap_u = 0, ci_u = 0;
-    if (MODE == MODE_CHUNK) {
+    if (MODE == MODE_CHUNK || MODE == MODE_CHUNK_RS) {
         const int k0 = it_beg * BK;
         tap_u = k0 / p.c_in;
         ci_u = k0 - tap_u * p.c_in;
     }
+    const svcmi_ldsaddr lds_a = svcmi_lds_advance(svcmi_lds_addr(As0), wave * 8 * BK);
+    const svcmi_ldsaddr lds_b = svcmi_lds_advance(svcmi_lds_addr(Bs0), wave * 8 * BK);
 
     svcmi_f32x16 acc[WM][WN];
 #pragma unroll
@@ -132,87 +168,113 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // Issue the LDS-DMA of K-step `it` into buffer `buf`.  Nothing lands in registers, nothing is waited for here.
-    auto stage = [&](int it, int buf) {
-        float* const Ab = As0 + buf * BM * BK;
-        float* const Bb = Bs0 + buf * BN * BK;
-        if (MODE == MODE_SCALAR) {
-            // 4-byte DMA: a wave-instruction fills 2 rows (64 floats); piece i needs 4 of them.
-#pragma unroll
-            for (int i = 0; i < A_PER; ++i) {
-#pragma unroll
-                for (int h = 0; h < 4; ++h) {
-                    const int rr = 2 * h + (lane >> 5);                  // row within the piece
-                    const int pc = (lane & 31) >> 2, e = lane & 3;       // physical chunk, element
-                    const int q = it * BK + ((pc ^ rr) << 2) + e;        // logical k of this LDS word
-                    const int t = m0 + (wave + 4 * i) * 8 + rr;
-                    const int k = div_magic(q, p.magic), ci = q - k * p.c_in;
-                    const int tin = t * p.stride - p.pad + k * p.dil;
-                    const bool ok = t < p.t_out && q < p.ktot && (unsigned)tin < (unsigned)t_lim;
-                    const float* src = ok ? xb + (unsigned)((tin >> p.rshift) * p.ldx + ci) : svcmi_zeros;
-                    svcmi_glds4(src, Ab + ((wave + 4 * i) * 8 + 2 * h) * BK);
-                }
-            }
-        } else {
-            int k, ci;
-            bool kok = true;
-            if (MODE == MODE_CHUNK) {
-                k = tap_u; ci = ci_u + lkq;
-                ci_u += BK;
-                if (ci_u >= p.c_in) { ci_u -= p.c_in; ++tap_u; }
-            } else {
-                const int kk = it * BK + lkq;
-                k = div_magic(kk, p.magic); ci = kk - k * p.c_in;
-                kok = kk < p.ktot;
-            }
-            const int koff = k * p.dil;
-#pragma unroll
-            for (int i = 0; i < A_PER; ++i) {
-                const int tin = a_tb[i] + koff;
-                const bool ok = kok && (unsigned)tin < (unsigned)t_lim;
-                const float* src = ok ? xb + (unsigned)((tin >> p.rshift) * p.ldx + ci) : svcmi_zeros;
-                svcmi_glds16(src, Ab + (wave + 4 * i) * 8 * BK);
-            }
-        }
+    // Per-K-step source offsets of tile `it`, then the DMA pieces (none lands in registers, none is waited for here).
+    unsigned a_koff = 0, b_koff = 0;     // K part of this lane's byte offset (or OOB), valid between prep and issue
+    int tap_v = 0, ci_v = 0;             // x_row_shift path: this K-step's (tap, channel)
+    auto stage_prep = [&](int it) {
         const int kk = it * BK + lkq;
-        const bool wk = kk < p.ldw;
-#pragma unroll
-        for (int i = 0; i < B_PER; ++i) {
-            const float* src = (wk && w_row[i]) ? w_row[i] + kk : svcmi_zeros;
-            svcmi_glds16(src, Bb + (wave + 4 * i) * 8 * BK);
+        b_koff = kk < p.ldw ? (unsigned)kk * 4u : OOB;
+        if (MODE == MODE_CHUNK || MODE == MODE_CHUNK_RS) {
+            tap_v = tap_u; ci_v = ci_u + lkq;
+            a_koff = (unsigned)(tap_u * p.dil * p.ldx + ci_u + lkq) * 4u;
+            ci_u += BK;
+            if (ci_u >= p.c_in) { ci_u -= p.c_in; ++tap_u; }
+        } else if (MODE == MODE_VEC) {
+            tap_v = div_magic(kk, p.magic); ci_v = kk - tap_v * p.c_in;
+            a_koff = kk < p.ktot ? (unsigned)(tap_v * p.dil * p.ldx + ci_v) * 4u : OOB;
         }
+    };
+    auto stage_a = [&](int it, int buf, int i) {          // piece i of the A tile
+        const svcmi_ldsaddr dst = svcmi_lds_advance(lds_a, buf * BM * BK + 4 * i * 8 * BK);
+        if (MODE == MODE_SCALAR) {
+            // 4-byte DMA: a wave-instruction fills 2 rows (64 floats); the piece needs 4 of them.
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const int rr = 2 * h + (lane >> 5);                  // row within the piece
+                const int pc = (lane & 31) >> 2, e = lane & 3;       // physical chunk, element
+                const int q = it * BK + ((pc ^ swz(rr + 8 * wave)) << 2) + e;   // logical k of this LDS word
+                const int t = m0 + (wave + 4 * i) * 8 + rr;
+                const int k = div_magic(q, p.magic), ci = q - k * p.c_in;
+                const int tin = t * p.stride - p.pad + k * p.dil;
+                const bool ok = t < p.t_out && q < p.ktot && (unsigned)tin < (unsigned)t_lim;
+                svcmi_bdma4(ok ? (unsigned)((tin >> p.rshift) * p.ldx + ci) * 4u : OOB, svcmi_lds_advance(dst, 2 * h * BK), xr);
+            }
+        } else if (MODE == MODE_CHUNK_RS) {               // fused np.repeat(x, 2, 0): rows are tin >> 1
+            const int tin = a_tb[i] + tap_v * p.dil;
+            const bool ok = (unsigned)tin < (unsigned)t_lim;
+            svcmi_bdma16(ok ? (unsigned)((tin >> p.rshift) * p.ldx + ci_v) * 4u : OOB, dst, xr);
+        } else {
+            svcmi_bdma16(a_row[i] + a_koff, dst, xr);
+        }
+    };
+    auto stage_b = [&](int buf, int i) {
+        svcmi_bdma16(b_row[i] + b_koff, svcmi_lds_advance(lds_b, buf * BN * BK + 4 * i * 8 * BK), wr);
     };
 
     // fragment addresses: row (lane&31) of the wave tile, logical chunk 2s + (lane>>5) -> position ^ (row&7)
     const int frow = lane & 31, fhi = lane >> 5;
     const int a_off = (wm * 32 * WM + frow) * BK, b_off = (wn * 32 * WN + frow) * BK;
-    if (it_beg < it_end) stage(it_beg, 0);
-    for (int it = it_beg; it < it_end; ++it) {
+    auto load_frags = [&](const float* Ab, const float* Bb, int s, float4 (&a4)[WM], float4 (&b4)[WN]) {
+        const int pos = (((2 * s + fhi) ^ swz(frow)) << 2);
+#pragma unroll
+        for (int i = 0; i < WM; ++i) a4[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * BK + pos);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) b4[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * BK + pos);
+    };
+
+    if (it_beg < it_end) {
+        stage_prep(it_beg);
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) stage_a(it_beg, 0, i);
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) stage_b(0, i);
+    }
+    constexpr int NSUB = BK / 8;                          // 4 sub-steps of 8 k per tile
+    constexpr int PIECES = A_PER + B_PER;
+    // One K-step.  MORE (compile time) = another tile follows: its DMA pieces are issued here, spread over the
+    // sub-steps so that their issue slots sit between this tile's MFMAs.
+    auto k_step = [&](int it, auto more_tag) {
+        constexpr bool MORE = decltype(more_tag)::value;
         const int cur = (it - it_beg) & 1;
         svcmi_dma_wait();    // this wave's DMA for tile `it` has landed ...
         __syncthreads();     // ... and every other wave's; also: all reads of buf[cur^1] are done
-        if (it + 1 < it_end) stage(it + 1, cur ^ 1);
+        if (MORE) stage_prep(it + 1);
         const float* Ab = As0 + cur * BM * BK + a_off;
         const float* Bb = Bs0 + cur * BN * BK + b_off;
+        float4 a4[2][WM], b4[2][WN];
+        load_frags(Ab, Bb, 0, a4[0], b4[0]);
 #pragma unroll
-        for (int s = 0; s < BK / 8; ++s) {
-            const int pos = (((2 * s + fhi) ^ (frow & 7)) << 2);
-            float4 a4[WM], b4[WN];
+        for (int s = 0; s < NSUB; ++s) {
+            if (MORE) {
 #pragma unroll
-            for (int i = 0; i < WM; ++i) a4[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * BK + pos);
-#pragma unroll
-            for (int j = 0; j < WN; ++j) b4[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * BK + pos);
+                for (int q = s * PIECES / NSUB; q < (s + 1) * PIECES / NSUB; ++q) {
+                    if (q < A_PER) stage_a(it + 1, cur ^ 1, q);
+                    else stage_b(cur ^ 1, q - A_PER);
+                }
+            }
+            if (s + 1 < NSUB) load_frags(Ab, Bb, s + 1, a4[(s + 1) & 1], b4[(s + 1) & 1]);
+            const float4(&af)[WM] = a4[s & 1];
+            const float4(&bf)[WN] = b4[s & 1];
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int j = 0; j < WN; ++j) {
-                    acc[i][j] = svcmi_mfma_32x32x2(a4[i].x, b4[j].x, acc[i][j]);
-                    acc[i][j] = svcmi_mfma_32x32x2(a4[i].y, b4[j].y, acc[i][j]);
-                    acc[i][j] = svcmi_mfma_32x32x2(a4[i].z, b4[j].z, acc[i][j]);
-                    acc[i][j] = svcmi_mfma_32x32x2(a4[i].w, b4[j].w, acc[i][j]);
-                }
+                for (int j = 0; j < WN; ++j) acc[i][j] = svcmi_mfma_32x32x2(af[i].x, bf[j].x, acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) acc[i][j] = svcmi_mfma_32x32x2(af[i].y, bf[j].y, acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) acc[i][j] = svcmi_mfma_32x32x2(af[i].z, bf[j].z, acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) acc[i][j] = svcmi_mfma_32x32x2(af[i].w, bf[j].w, acc[i][j]);
         }
-    }
+    };
+    for (int it = it_beg; it + 1 < it_end; ++it) k_step(it, std::true_type());
+    if (it_beg < it_end) k_step(it_end - 1, std::false_type());
     __syncthreads();         // last tile fully consumed before the buffers are reused below
 
     // Epilogue through LDS: the accumulators (D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) are
@@ -272,10 +334,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs p, int batc
 }
 
 template <int WM, int WN>
-int launch(const ConvArgs& a, int batch, int mode, void* stream) {
+int launch(const ConvArgs& a_in, int batch, int mode, void* stream) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
-    dim3 grid((a.t_out + BM - 1) / BM, (a.n_out + BN - 1) / BN, batch * a.split);
+    ConvArgs a = a_in;
+    a.mt = (a.t_out + BM - 1) / BM;
+    a.nt = (a.n_out + BN - 1) / BN;
+    const long long blocks = (long long)a.mt * a.nt * batch * a.split;
+    if (blocks > 0x7fffffffLL) return SVCMI_EUNSUPPORTED;
+    dim3 grid((unsigned)blocks);
     if (mode == MODE_CHUNK) SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_CHUNK>), grid, dim3(256), 0, stream, a);
+    else if (mode == MODE_CHUNK_RS) SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_CHUNK_RS>), grid, dim3(256), 0, stream, a);
     else if (mode == MODE_VEC) SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_VEC>), grid, dim3(256), 0, stream, a);
     else SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_SCALAR>), grid, dim3(256), 0, stream, a);
     int rc = SVCMI_LAST_ERROR();
@@ -293,7 +361,9 @@ int launch(const ConvArgs& a, int batch, int mode, void* stream) {
 
 extern "C" int svcmi_conv_gemm_f32(const svcmi_conv_desc* d, void* stream) {
     if (!d || !d->x || !d->w || !d->y) return SVCMI_EINVAL;
-    if ((long long)d->t_in * d->ldx >= 0x7fffffffLL) return SVCMI_EUNSUPPORTED;   /* 32-bit in-item offsets */
+    /* 32-bit buffer offsets with a 2^30 out-of-range sentinel: each operand buffer stays below 2^29 bytes */
+    if ((long long)d->t_in * d->ldx >= (1LL << 27) || (long long)d->n_out * d->ldw >= (1LL << 27)) return SVCMI_EUNSUPPORTED;
+    if (((long long)d->ksize * d->dilation + d->pad) * d->ldx >= (1LL << 27)) return SVCMI_EUNSUPPORTED;
     if (d->batch <= 0 || d->t_in <= 0 || d->t_out <= 0 || d->c_in <= 0 || d->n_out <= 0 || d->ksize <= 0) return SVCMI_EINVAL;
     if (d->stride <= 0 || d->dilation <= 0 || d->x_row_shift < 0 || d->x_row_shift > 1) return SVCMI_EINVAL;
     if (d->ldw % 4 != 0 || d->ldw < d->ksize * d->c_in) return SVCMI_EINVAL;
@@ -304,7 +374,6 @@ extern "C" int svcmi_conv_gemm_f32(const svcmi_conv_desc* d, void* stream) {
     if (((uintptr_t)d->w & 15) != 0) return SVCMI_EALIGN;
     // magic-number division q / c_in is exact while q * c_in < 2^32 (q < ksize*c_in)
     if ((long long)d->ksize * d->c_in * d->c_in >= 0x100000000LL || (long long)d->ksize * d->c_in >= 0x7fffffffLL) return SVCMI_EUNSUPPORTED;
-    if ((d->n_out + 63) / 64 > 65535) return SVCMI_EUNSUPPORTED;
 
     ConvArgs a;
     a.x = d->x; a.w = d->w; a.bias = d->bias; a.res = d->res; a.y = d->y; a.lengths = d->lengths;
@@ -317,7 +386,8 @@ extern "C" int svcmi_conv_gemm_f32(const svcmi_conv_desc* d, void* stream) {
     a.ktot = d->ksize * d->c_in;
     a.magic = d->c_in == 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d->c_in - 1) / (unsigned)d->c_in);
     const bool vec = (d->c_in % 4 == 0) && (d->ldx % 4 == 0) && (d->x_bstride % 4 == 0) && (((uintptr_t)d->x & 15) == 0);
-    const int mode = !vec ? MODE_SCALAR : (d->c_in % BK == 0 ? MODE_CHUNK : MODE_VEC);
+    int mode = !vec ? MODE_SCALAR : (d->c_in % BK == 0 ? MODE_CHUNK : MODE_VEC);
+    if (d->x_row_shift) mode = mode == MODE_CHUNK ? MODE_CHUNK_RS : MODE_SCALAR;   // the fused row repeat: CHUNK_RS or per-element
 
     // Tile: fill the 256 CUs first, then grow the tile for operand reuse (or honour the override).
     const long long mt64 = (d->t_out + 63) / 64, nt64 = (d->n_out + 63) / 64;
@@ -333,8 +403,8 @@ extern "C" int svcmi_conv_gemm_f32(const svcmi_conv_desc* d, void* stream) {
     const int nk = (a.ktot + BK - 1) / BK;
     if (tile == SVCMI_CONV_TILE_64x64 && d->workspace && d->split_k != 1) {
         int s = d->split_k;
-        if (s == 0) {                                   // heuristic: aim at >= 2 blocks per CU
-            s = (int)((512 + blocks64 - 1) / blocks64);
+        if (s == 0) {                                   // heuristic: aim at ~5 blocks per CU (measured: scripts/microbench.py)
+            s = (int)((1280 + blocks64 - 1) / blocks64);
             if (s > nk / 4) s = nk / 4;
             if (s > 16) s = 16;
         }
@@ -342,7 +412,6 @@ extern "C" int svcmi_conv_gemm_f32(const svcmi_conv_desc* d, void* stream) {
         while (s > 1 && (long long)d->batch * s * d->t_out * d->n_out > d->workspace_floats) --s;
         if (s > 1) a.split = s;
     }
-    if ((long long)d->batch * a.split > 65535) return SVCMI_EUNSUPPORTED;
 
     switch (tile) {
         case SVCMI_CONV_TILE_128x128: return launch<2, 2>(a, d->batch, mode, stream);

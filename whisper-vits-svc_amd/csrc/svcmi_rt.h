@@ -31,26 +31,40 @@ __device__ __forceinline__ svcmi_f32x4 svcmi_mfma_16x16x4(float a, float b, svcm
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// Asynchronous global -> LDS copy (LDS-DMA, global_load_lds_dword[x4]).  `lds_wave_base` is wave-uniform; lane
-// l's 16 (4) bytes land at lds_wave_base + 16*l (4*l) bytes.  Issued through inline asm ON PURPOSE: with the
-// builtin hipcc models the DMA as a pending LDS write and puts s_waitcnt vmcnt(0) in front of the next
-// ds_read whenever it cannot prove the buffers disjoint (runtime double-buffer index), which serialises copy
-// and compute.  The asm form is invisible to that bookkeeping, so the caller owns completion:
-// svcmi_dma_wait() then a barrier before any wave reads the data (cdna_hip_programming.md section 5.7).
-__device__ __forceinline__ unsigned svcmi_lds_addr(const float* lds_ptr) {
+// Asynchronous global -> LDS copy (LDS-DMA) through a buffer descriptor: `buffer_load_dword[x4] voff, rsrc, 0 offen lds`.
+// Lane l fetches 16 (4) bytes at rsrc.base + voff[l]; they land at lds_wave_base + 16*l (4*l) bytes, where
+// `lds_wave_base` is wave-uniform (it travels in M0).  The hardware range-checks voff against rsrc.num_records
+// and an out-of-range lane writes ZEROS to its LDS slot (probe: scripts/probes/oob_lds_dma.hip) -- that is how
+// padding taps, masked rows and ragged tile edges are zero-filled without a branch or a select on data.
+// Issued through inline asm ON PURPOSE: with the builtin hipcc models the DMA as a pending LDS write and puts
+// s_waitcnt vmcnt(0) in front of the next ds_read whenever it cannot prove the buffers disjoint (runtime
+// double-buffer index), which serialises copy and compute.  The asm form is invisible to that bookkeeping, so
+// the caller owns completion: svcmi_dma_wait() then a barrier before any wave reads the data
+// (cdna_hip_programming.md section 5.7).
+typedef int svcmi_rsrc __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ svcmi_rsrc svcmi_make_rsrc(const void* base, unsigned bytes) {   // wave-uniform inputs only
+    const size_t a = (size_t)base;
+    svcmi_rsrc r;
+    r.x = (int)(unsigned)a;
+    r.y = (int)(unsigned)(a >> 32);      // stride 0: raw buffer
+    r.z = (int)bytes;                    // num_records, in bytes
+    r.w = 0x00020000;
+    return r;
+}
+typedef unsigned svcmi_ldsaddr;          // wave-uniform LDS byte address (what M0 takes)
+__device__ __forceinline__ svcmi_ldsaddr svcmi_lds_addr(const float* lds_ptr) {
     return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) float*)lds_ptr);
 }
-__device__ __forceinline__ void svcmi_glds16(const float* g, float* lds_wave_base) {
-    const unsigned dst = svcmi_lds_addr(lds_wave_base);
+__device__ __forceinline__ svcmi_ldsaddr svcmi_lds_advance(svcmi_ldsaddr a, int floats) { return a + 4u * (unsigned)floats; }
+__device__ __forceinline__ void svcmi_bdma16(unsigned voff, svcmi_ldsaddr lds_wave_base, svcmi_rsrc rsrc) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_wave_base), "s"(rsrc) : "memory");
 }
-__device__ __forceinline__ void svcmi_glds4(const float* g, float* lds_wave_base) {
-    const unsigned dst = svcmi_lds_addr(lds_wave_base);
+__device__ __forceinline__ void svcmi_bdma4(unsigned voff, svcmi_ldsaddr lds_wave_base, svcmi_rsrc rsrc) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_wave_base), "s"(rsrc) : "memory");
 }
 __device__ __forceinline__ void svcmi_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 

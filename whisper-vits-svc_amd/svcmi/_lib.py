@@ -8,7 +8,7 @@ DEFAULT_LIB = os.path.join(HERE, "libsvcmi.so")
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_MISH, ACT_TANH = 0, 1, 2, 3, 4
 CONV_ACCUMULATE, CONV_MASK_IN, CONV_MASK_OUT = 1, 2, 4
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class ConvDesc(Structure):
@@ -31,6 +31,8 @@ SIGNATURES = {
     "svcmi_layernorm_f32": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
     "svcmi_attention_f32": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _I, _I, _I, _I, _F, _P, _P, _I, _P, _P]),
     "svcmi_snake_alias_f32": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "svcmi_snake_conv_supported": (c_int, [_I, _I, _I, _I]),
+    "svcmi_snake_conv_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
     "svcmi_wn_gate_f32": (c_int, [_P, _P, _L, _I, _I, _I, _P]),
     "svcmi_wn_update_f32": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "svcmi_coupling_pre_f32": (c_int, [_P, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P]),

@@ -138,6 +138,21 @@ class Ops:
                    B, L, Cc, x.stride(1), self._stream(), work={"bytes": 8.0 * B * L * Cc})
         return out
 
+    def snake_conv_supported(self, c, ld, ksize, dilation):
+        return bool(self.lib.svcmi_snake_conv_supported(c, ld, ksize, dilation))
+
+    def snake_conv(self, x, alpha_log, beta_log, filt, w, bias, *, c, ksize, dilation=1, res=None, alpha=1.0,
+                   accumulate=False, out=None):
+        """Fused SnakeAlias -> 'same' Conv1d (+ bias + res) * alpha (+= out) for the narrow stages; x [B, L, ld]."""
+        self._chk(x, alpha_log, beta_log, filt, w, bias, res, out)
+        B, L, ld = x.shape
+        if out is None:
+            out = torch.empty_like(x)
+        self._call("svcmi_snake_conv_f32", _ptr(x), _ptr(w), _ptr(bias), _ptr(res), _ptr(out), _ptr(alpha_log),
+                   _ptr(beta_log), _ptr(filt), B, L, c, ld, w.shape[1], ksize, dilation, float(alpha), int(accumulate),
+                   self._stream(), work={"flops": 2.0 * B * L * c * c * ksize, "bytes": 8.0 * B * L * c})
+        return out
+
     def pitch2source(self, f0, rand_ini, noise, merge_w, merge_b, hop, sr):
         """f0 [B,T], rand_ini [B,11], noise [B,T*hop,11] -> source [B, T*hop]."""
         self._chk(f0, rand_ini, noise, merge_w)

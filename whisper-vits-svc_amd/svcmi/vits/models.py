@@ -203,15 +203,31 @@ class SynthesizerInfer:
                      x_bstride=source.stride(0))
             acc = torch.empty_like(y)
             xj = torch.empty_like(y)
+            tmp = torch.empty_like(y)
+            tmp2 = torch.empty_like(y)
             nb = len(st["blocks"])
             for j, blk in enumerate(st["blocks"]):
                 k = blk["k"]
                 xc = y
+                # narrow stages: SnakeAlias + conv as one kernel (csrc/amp_fused.hip); wide stages: two kernels
+                fused = all(ops.snake_conv_supported(st["c"], st["cp"], k, d) for d in blk["d"])
                 for q, d in enumerate(blk["d"]):
-                    a = ops.snake_alias(xc, blk["a1"][q][0], blk["a1"][q][1], w.filt)
-                    b = ops.conv(a, blk["c1"][q][0], blk["c1"][q][1], ksize=k, dilation=d, pad=(k * d - d) // 2)
+                    last = q == len(blk["d"]) - 1
+                    if fused:
+                        b = ops.snake_conv(xc, blk["a1"][q][0], blk["a1"][q][1], w.filt, blk["c1"][q][0], blk["c1"][q][1],
+                                           c=st["c"], ksize=k, dilation=d, out=tmp)
+                        if not last:
+                            ops.snake_conv(b, blk["a2"][q][0], blk["a2"][q][1], w.filt, blk["c2"][q][0], blk["c2"][q][1],
+                                           c=st["c"], ksize=k, res=xc, out=xj)
+                            xc = xj
+                        else:   # (conv + x)/3 accumulated into the stage output (generator.py:188-194)
+                            ops.snake_conv(b, blk["a2"][q][0], blk["a2"][q][1], w.filt, blk["c2"][q][0], blk["c2"][q][1],
+                                           c=st["c"], ksize=k, res=xc, alpha=1.0 / nb, accumulate=(j > 0), out=acc)
+                        continue
+                    a = ops.snake_alias(xc, blk["a1"][q][0], blk["a1"][q][1], w.filt, out=tmp)
+                    b = ops.conv(a, blk["c1"][q][0], blk["c1"][q][1], ksize=k, dilation=d, pad=(k * d - d) // 2, out=tmp2)
                     a2 = ops.snake_alias(b, blk["a2"][q][0], blk["a2"][q][1], w.filt, out=a)
-                    if q < len(blk["d"]) - 1:
+                    if not last:
                         ops.conv(a2, blk["c2"][q][0], blk["c2"][q][1], ksize=k, pad=(k - 1) // 2, res=xc, out=xj)
                         xc = xj
                     else:   # last iteration: (conv + x)/3 accumulated into the stage output (generator.py:188-194)
