@@ -142,6 +142,10 @@ int svcmi_snake_conv_f32(const float* x, const float* w, const float* bias, cons
                          int32_t batch, int32_t len, int32_t c, int32_t ld, int32_t ldw, int32_t ksize,
                          int32_t dilation, float alpha, int32_t accumulate, void* stream);
 
+/* Development knob for the tuning scripts: "amp_tt" in {0 (default), 1, 2, 4} = time steps per thread of
+ * svcmi_snake_conv_f32.  Results never depend on it.  Returns 0, or SVCMI_EINVAL for an unknown name/value. */
+int svcmi_tune_set(const char* name, int32_t value);
+
 /* WaveNet gate, vits/commons.py:126-133 with input_b == 0 (vits/modules.py:190-193):
  *   out[r, c] = tanh(a[r, c]) * sigmoid(a[r, h + c]),  c < h. */
 int svcmi_wn_gate_f32(const float* a, float* out, int64_t rows, int32_t h, int32_t lda, int32_t ldo, void* stream);

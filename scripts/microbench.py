@@ -78,7 +78,8 @@ def main():
     if "amp" in what:
         filt = torch.tensor([0.00202896, 0.00938947, -0.02554346, -0.05765738, 0.12857258, 0.44320980, 0.44320980,
                              0.12857258, -0.05765738, -0.02554346, 0.00938947, 0.00202896], device="cuda")
-        for (C, n) in ((40, 80000), (20, 160000), (10, 320000)):
+        for tt, (C, n) in [(t, cn) for t in (1, 2, 4) for cn in ((40, 80000), (20, 160000), (10, 320000))]:
+            assert ops.lib.svcmi_tune_set(b"amp_tt", tt) == 0
             ld = (C + 3) // 4 * 4
             x = torch.randn(1, n, ld, device="cuda")
             r = torch.randn(1, n, ld, device="cuda")
@@ -88,7 +89,8 @@ def main():
                 w = PW.pack_conv(torch.randn(C, C, k) / math.sqrt(C * k), ld, ld).cuda()
                 bias = torch.randn(ld, device="cuda")
                 us = timeit(lambda: ops.snake_conv(x, al, be, filt, w, bias, c=C, ksize=k, dilation=d, res=r, out=y))
-                print(f"amp C={C} n={n} k={k} d={d}: {us:8.1f} us  conv {2.0 * C * C * k * n / us / 1e6:6.1f} TF/s", flush=True)
+                print(f"amp tt={tt} C={C} n={n} k={k} d={d}: {us:8.1f} us  conv {2.0 * C * C * k * n / us / 1e6:6.1f} TF/s", flush=True)
+        ops.lib.svcmi_tune_set(b"amp_tt", 0)
     if "attn" in what:
         for (T, H, D, rel) in ((500, 20, 64, False), (1000, 2, 96, True), (1500, 20, 64, False), (2520, 2, 96, True)):
             qkv = torch.randn(1, T, 3 * H * D, device="cuda")

@@ -25,7 +25,6 @@ namespace {
 
 constexpr int TPB = 256;
 constexpr int RT = 8;        // SnakeAlias outputs per work item (run along time)
-constexpr int TT = 4;        // time steps per thread in the convolution
 constexpr int CO = 10;       // output channels per thread
 constexpr int DMAX = 5;      // largest dilation (bigv.py dilations 1, 3, 5)
 
@@ -63,8 +62,10 @@ struct AmpArgs {
     float alpha;
 };
 
-// CP = padded channels (row length of x / y / res and of a weight tap), CR = real channels, KS = taps, G = channel groups.
-template <int CP, int CR, int KS, int G>
+// CP = padded channels (row length of x / y / res and of a weight tap), CR = real channels, KS = taps, G = channel
+// groups, TT = time steps per thread in the convolution (accumulators: TT x CO).  Small TT = small tiles = many
+// blocks: the activation phase is a long dependent chain per work item and needs >= 4 waves per SIMD to hide.
+template <int CP, int CR, int KS, int G, int TT>
 __global__ __launch_bounds__(TPB) void snake_conv_kernel(AmpArgs p) {
     constexpr int TSUB = 4 / G;                       // time sub-tiles per block
     constexpr int TB = TSUB * 64 * TT;                // output rows per block
@@ -205,18 +206,20 @@ __global__ __launch_bounds__(TPB) void snake_conv_kernel(AmpArgs p) {
     }
 }
 
-template <int CP, int CR, int G>
+template <int CP, int CR, int G, int TT>
 int launch_amp(const AmpArgs& a, int batch, int ksize, void* stream) {
     constexpr int TB = (4 / G) * 64 * TT;
     dim3 grid((unsigned)((a.n + TB - 1) / TB), (unsigned)batch);
     switch (ksize) {
-        case 3: SVCMI_LAUNCH((snake_conv_kernel<CP, CR, 3, G>), grid, dim3(TPB), 0, stream, a); break;
-        case 7: SVCMI_LAUNCH((snake_conv_kernel<CP, CR, 7, G>), grid, dim3(TPB), 0, stream, a); break;
-        case 11: SVCMI_LAUNCH((snake_conv_kernel<CP, CR, 11, G>), grid, dim3(TPB), 0, stream, a); break;
+        case 3: SVCMI_LAUNCH((snake_conv_kernel<CP, CR, 3, G, TT>), grid, dim3(TPB), 0, stream, a); break;
+        case 7: SVCMI_LAUNCH((snake_conv_kernel<CP, CR, 7, G, TT>), grid, dim3(TPB), 0, stream, a); break;
+        case 11: SVCMI_LAUNCH((snake_conv_kernel<CP, CR, 11, G, TT>), grid, dim3(TPB), 0, stream, a); break;
         default: return SVCMI_EUNSUPPORTED;
     }
     return SVCMI_LAST_ERROR();
 }
+
+int g_amp_tt = 0;      // tuning override (svcmi_tune_set("amp_tt", v)); 0 = per-shape default
 
 }  // namespace
 
@@ -238,7 +241,18 @@ extern "C" int svcmi_snake_conv_f32(const float* x, const float* w, const float*
     AmpArgs a;
     a.x = x; a.w = w; a.bias = bias; a.res = res; a.y = y; a.alpha_log = alpha_log; a.beta_log = beta_log; a.filt = filt;
     a.n = len; a.ld = ld; a.ldw = ldw; a.dil = dilation; a.accumulate = accumulate; a.alpha = alpha;
-    if (c == 10) return launch_amp<12, 10, 1>(a, batch, ksize, stream);
-    if (c == 20) return launch_amp<20, 20, 2>(a, batch, ksize, stream);
-    return launch_amp<40, 40, 4>(a, batch, ksize, stream);
+    const int tt = g_amp_tt ? g_amp_tt : 2;      // measured best of {1, 2, 4} on MI355X for all three widths (scripts/microbench.py amp)
+    if (c == 10) return tt == 1 ? launch_amp<12, 10, 1, 1>(a, batch, ksize, stream) : tt == 2 ? launch_amp<12, 10, 1, 2>(a, batch, ksize, stream) : launch_amp<12, 10, 1, 4>(a, batch, ksize, stream);
+    if (c == 20) return tt == 1 ? launch_amp<20, 20, 2, 1>(a, batch, ksize, stream) : tt == 2 ? launch_amp<20, 20, 2, 2>(a, batch, ksize, stream) : launch_amp<20, 20, 2, 4>(a, batch, ksize, stream);
+    return tt == 1 ? launch_amp<40, 40, 4, 1>(a, batch, ksize, stream) : tt == 2 ? launch_amp<40, 40, 4, 2>(a, batch, ksize, stream) : launch_amp<40, 40, 4, 4>(a, batch, ksize, stream);
+}
+
+// Development knob (scripts/microbench.py): returns 0 if the name is known.
+extern "C" int svcmi_tune_set(const char* name, int32_t value) {
+    if (!name) return SVCMI_EINVAL;
+    const char* k = "amp_tt";
+    int i = 0;
+    while (k[i] && name[i] == k[i]) ++i;
+    if (k[i] == 0 && name[i] == 0 && (value == 0 || value == 1 || value == 2 || value == 4)) { g_amp_tt = value; return 0; }
+    return SVCMI_EINVAL;
 }
