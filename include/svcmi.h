@@ -137,6 +137,8 @@ int svcmi_snake_alias_f32(const float* x, float* y, const float* alpha_log, cons
  * dilation 1..5 -- svcmi_snake_conv_supported() tells; other shapes return SVCMI_EUNSUPPORTED and the caller
  * uses svcmi_snake_alias_f32 + svcmi_conv_gemm_f32. */
 int svcmi_snake_conv_supported(int32_t c, int32_t ld, int32_t ksize, int32_t dilation);
+/* 1 where the fused kernel is also the FASTER choice on MI355X (narrowest stages); the facade follows it. */
+int svcmi_snake_conv_preferred(int32_t c, int32_t ld, int32_t ksize, int32_t dilation);
 int svcmi_snake_conv_f32(const float* x, const float* w, const float* bias, const float* res, float* y,
                          const float* alpha_log, const float* beta_log, const float* filt,
                          int32_t batch, int32_t len, int32_t c, int32_t ld, int32_t ldw, int32_t ksize,

@@ -151,3 +151,5 @@ static inline void svcmi_bdma4(unsigned voff, float* lds_wave_base, svcmi_rsrc r
     if ((unsigned long long)voff + 4 <= r.bytes) memcpy(dst, r.base + voff, 4); else memset(dst, 0, 4);
 }
 static inline void svcmi_dma_wait() {}
+template <int N>
+static inline void svcmi_dma_wait_n() {}

@@ -228,6 +228,12 @@ extern "C" int svcmi_snake_conv_supported(int32_t c, int32_t ld, int32_t ksize, 
     return shape && (ksize == 3 || ksize == 7 || ksize == 11) && dilation >= 1 && dilation <= DMAX;
 }
 
+// Where the fused kernel beats SnakeAlias + MFMA convolution on MI355X (measured in the 10 s pipeline): 10 and 20
+// channels (40 vs 111 us and 52 vs 76 us per half-step); at 40 channels the padded MFMA tile wins (62 vs 81 us).
+extern "C" int svcmi_snake_conv_preferred(int32_t c, int32_t ld, int32_t ksize, int32_t dilation) {
+    return svcmi_snake_conv_supported(c, ld, ksize, dilation) && c <= 20;
+}
+
 extern "C" int svcmi_snake_conv_f32(const float* x, const float* w, const float* bias, const float* res, float* y,
                                     const float* alpha_log, const float* beta_log, const float* filt,
                                     int32_t batch, int32_t len, int32_t c, int32_t ld, int32_t ldw, int32_t ksize,

@@ -97,10 +97,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int A_PER = BM / 32, B_PER = BN / 32;   // 1-KiB LDS-DMA pieces (8 rows x 32 k) per wave per K-step
     constexpr int CLD = BN;                           // epilogue staging tile [BM][BN] reuses the operand buffers
-    static_assert(BM * CLD <= 2 * (BM + BN) * BK, "C tile must fit in the operand buffers");
-    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * BK];
-    float* const As0 = smem;                          // As[buf] = As0 + buf*BM*BK, rows of 32 floats, chunk-swizzled
-    float* const Bs0 = smem + 2 * BM * BK;
+    // LDS ring of NST operand tiles (48 / 72 / 64 KiB per block): tile it+NST-1 is in flight while tile
+    // `it` is consumed, so a K-step never waits a full HBM/L2 round trip -- what short K ranges (split-K slices,
+    // the k=1 projections of the prior encoder / flow, k=3 convolutions) would otherwise pay on every step.
+    constexpr int NST = (WM * WN == 1) ? 3 : (WM * WN == 2 ? 3 : 2);
+    static_assert(BM * CLD <= NST * (BM + BN) * BK, "C tile must fit in the operand buffers");
+    __shared__ __attribute__((aligned(16))) float smem[NST * (BM + BN) * BK];
+    float* const As0 = smem;                          // As[slot] = As0 + slot*BM*BK, rows of 32 floats, chunk-swizzled
+    float* const Bs0 = smem + NST * BM * BK;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = SVCMI_UNIFORM((int)(tid >> 6));
@@ -222,34 +226,44 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
         for (int j = 0; j < WN; ++j) b4[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * BK + pos);
     };
 
-    if (it_beg < it_end) {
-        stage_prep(it_beg);
-#pragma unroll
-        for (int i = 0; i < A_PER; ++i) stage_a(it_beg, 0, i);
-#pragma unroll
-        for (int i = 0; i < B_PER; ++i) stage_b(0, i);
-    }
     constexpr int NSUB = BK / 8;                          // 4 sub-steps of 8 k per tile
-    constexpr int PIECES = A_PER + B_PER;
-    // One K-step.  MORE (compile time) = another tile follows: its DMA pieces are issued here, spread over the
-    // sub-steps so that their issue slots sit between this tile's MFMAs.
-    auto k_step = [&](int it, auto more_tag) {
-        constexpr bool MORE = decltype(more_tag)::value;
-        const int cur = (it - it_beg) & 1;
-        svcmi_dma_wait();    // this wave's DMA for tile `it` has landed ...
-        __syncthreads();     // ... and every other wave's; also: all reads of buf[cur^1] are done
-        if (MORE) stage_prep(it + 1);
-        const float* Ab = As0 + cur * BM * BK + a_off;
-        const float* Bb = Bs0 + cur * BN * BK + b_off;
+    constexpr int PIECES = A_PER + B_PER;                 // pieces per tile per wave ...
+    constexpr int DMAS = (MODE == MODE_SCALAR ? 4 * A_PER : A_PER) + B_PER;   // ... and the DMA instructions they take
+    // prologue: tiles it_beg .. it_beg+NST-2 into slots 0 .. NST-2
+#pragma unroll
+    for (int s0 = 0; s0 < NST - 1; ++s0) {
+        if (it_beg + s0 < it_end) {
+            stage_prep(it_beg + s0);
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i) stage_a(it_beg + s0, s0, i);
+#pragma unroll
+            for (int i = 0; i < B_PER; ++i) stage_b(s0, i);
+        }
+    }
+    // One K-step.  ISSUE (compile time) = tile it+NST-1 exists: its DMA pieces are issued here, spread over the
+    // sub-steps so that their issue slots sit between this tile's MFMAs.  `inflight` = tiles issued after `it`
+    // that may still be in flight when tile `it` is needed (vmcnt counts this wave's DMAs in issue order).
+    auto k_step = [&](int it, int slot, int inflight, auto issue_tag) {
+        constexpr bool ISSUE = decltype(issue_tag)::value;
+        if (ISSUE || inflight == NST - 2) svcmi_dma_wait_n<(NST - 2) * DMAS>();
+        else if (inflight == 0) svcmi_dma_wait_n<0>();
+        else if (inflight == 1) svcmi_dma_wait_n<DMAS>();
+        else svcmi_dma_wait_n<2 * DMAS>();
+        __syncthreads();     // tile `it` has landed for every wave; all reads of the slot refilled below are done
+        int nslot = slot + NST - 1;
+        if (nslot >= NST) nslot -= NST;
+        if (ISSUE) stage_prep(it + NST - 1);
+        const float* Ab = As0 + slot * BM * BK + a_off;
+        const float* Bb = Bs0 + slot * BN * BK + b_off;
         float4 a4[2][WM], b4[2][WN];
         load_frags(Ab, Bb, 0, a4[0], b4[0]);
 #pragma unroll
         for (int s = 0; s < NSUB; ++s) {
-            if (MORE) {
+            if (ISSUE) {
 #pragma unroll
                 for (int q = s * PIECES / NSUB; q < (s + 1) * PIECES / NSUB; ++q) {
-                    if (q < A_PER) stage_a(it + 1, cur ^ 1, q);
-                    else stage_b(cur ^ 1, q - A_PER);
+                    if (q < A_PER) stage_a(it + NST - 1, nslot, q);
+                    else stage_b(nslot, q - A_PER);
                 }
             }
             if (s + 1 < NSUB) load_frags(Ab, Bb, s + 1, a4[(s + 1) & 1], b4[(s + 1) & 1]);
@@ -273,8 +287,18 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
                 for (int j = 0; j < WN; ++j) acc[i][j] = svcmi_mfma_32x32x2(af[i].w, bf[j].w, acc[i][j]);
         }
     };
-    for (int it = it_beg; it + 1 < it_end; ++it) k_step(it, std::true_type());
-    if (it_beg < it_end) k_step(it_end - 1, std::false_type());
+    {
+        int it = it_beg, slot = 0;
+        for (; it + NST - 1 < it_end; ++it) {             // steady state: NST-2 later tiles in flight
+            k_step(it, slot, NST - 2, std::true_type());
+            if (++slot == NST) slot = 0;
+        }
+        for (; it < it_end; ++it) {                       // drain
+            const int rem = it_end - 1 - it;
+            k_step(it, slot, rem < NST - 2 ? rem : NST - 2, std::false_type());
+            if (++slot == NST) slot = 0;
+        }
+    }
     __syncthreads();         // last tile fully consumed before the buffers are reused below
 
     // Epilogue through LDS: the accumulators (D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) are

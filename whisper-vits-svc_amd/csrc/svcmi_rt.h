@@ -67,6 +67,12 @@ __device__ __forceinline__ void svcmi_bdma4(unsigned voff, svcmi_ldsaddr lds_wav
                  : "=&s"(keep) : "v"(voff), "s"(lds_wave_base), "s"(rsrc) : "memory");
 }
 __device__ __forceinline__ void svcmi_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Wait until at most N of this wave's VMEM operations (LDS-DMAs included, counted in issue order) are outstanding.
+template <int N>
+__device__ __forceinline__ void svcmi_dma_wait_n() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 
 // Tell hipcc a threadIdx-derived value is wave-uniform (unlocks scalar loads / SGPR operands).
 #define SVCMI_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)

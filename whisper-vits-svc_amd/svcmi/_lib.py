@@ -32,6 +32,7 @@ SIGNATURES = {
     "svcmi_attention_f32": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _I, _I, _I, _I, _F, _P, _P, _I, _P, _P]),
     "svcmi_snake_alias_f32": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "svcmi_snake_conv_supported": (c_int, [_I, _I, _I, _I]),
+    "svcmi_snake_conv_preferred": (c_int, [_I, _I, _I, _I]),
     "svcmi_snake_conv_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
     "svcmi_tune_set": (c_int, [c_char_p, _I]),
     "svcmi_wn_gate_f32": (c_int, [_P, _P, _L, _I, _I, _I, _P]),

@@ -141,6 +141,9 @@ class Ops:
     def snake_conv_supported(self, c, ld, ksize, dilation):
         return bool(self.lib.svcmi_snake_conv_supported(c, ld, ksize, dilation))
 
+    def snake_conv_preferred(self, c, ld, ksize, dilation):
+        return bool(self.lib.svcmi_snake_conv_preferred(c, ld, ksize, dilation))
+
     def snake_conv(self, x, alpha_log, beta_log, filt, w, bias, *, c, ksize, dilation=1, res=None, alpha=1.0,
                    accumulate=False, out=None):
         """Fused SnakeAlias -> 'same' Conv1d (+ bias + res) * alpha (+= out) for the narrow stages; x [B, L, ld]."""

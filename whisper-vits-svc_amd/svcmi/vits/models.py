@@ -210,7 +210,7 @@ class SynthesizerInfer:
                 k = blk["k"]
                 xc = y
                 # narrow stages: SnakeAlias + conv as one kernel (csrc/amp_fused.hip); wide stages: two kernels
-                fused = all(ops.snake_conv_supported(st["c"], st["cp"], k, d) for d in blk["d"])
+                fused = all(ops.snake_conv_preferred(st["c"], st["cp"], k, d) for d in blk["d"])
                 for q, d in enumerate(blk["d"]):
                     last = q == len(blk["d"]) - 1
                     if fused:
