@@ -134,6 +134,10 @@ static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((un
     emu::launch(grid, block, [=]() { kernel(__VA_ARGS__); })
 #define SVCMI_LAST_ERROR() (emu::g_last_error)
 #define SVCMI_UNIFORM(x) (x)
+#define SVCMI_SCHED_GROUP(mask, n) ((void)0)
+static inline void svcmi_lds_read16(svcmi_f32x4& dst, const float* p, svcmi_f32x4&) { memcpy(&dst, p, 16); }
+static inline void svcmi_lds_arrive(svcmi_f32x4&) {}
+static inline void svcmi_pin(svcmi_f32x16&) {}
 // LDS-DMA emulation (buffer form): lane l copies its 16 (4) bytes from rsrc.base + voff to lds_wave_base + 16*l
 // (4*l); an out-of-range lane writes zeros, like the hardware.  Synchronous here.  `lds_wave_base` is the LDS
 // "address" svcmi_lds_addr() returned -- in the emulator simply the pointer.

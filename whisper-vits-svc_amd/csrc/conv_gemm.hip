@@ -218,12 +218,19 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
     // fragment addresses: row (lane&31) of the wave tile, logical chunk 2s + (lane>>5) -> position ^ (row&7)
     const int frow = lane & 31, fhi = lane >> 5;
     const int a_off = (wm * 32 * WM + frow) * BK, b_off = (wn * 32 * WN + frow) * BK;
-    auto load_frags = [&](const float* Ab, const float* Bb, int s, float4 (&a4)[WM], float4 (&b4)[WN]) {
+    // Fragment reads of sub-step s into (a4, b4).  `tie` is a register the MFMAs issued next consume.
+    auto load_frags = [&](const float* Ab, const float* Bb, int s, svcmi_f32x4 (&a4)[WM], svcmi_f32x4 (&b4)[WN], svcmi_f32x4& tie) {
         const int pos = (((2 * s + fhi) ^ swz(frow)) << 2);
 #pragma unroll
-        for (int i = 0; i < WM; ++i) a4[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * BK + pos);
+        for (int i = 0; i < WM; ++i) svcmi_lds_read16(a4[i], Ab + i * 32 * BK + pos, tie);
 #pragma unroll
-        for (int j = 0; j < WN; ++j) b4[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * BK + pos);
+        for (int j = 0; j < WN; ++j) svcmi_lds_read16(b4[j], Bb + j * 32 * BK + pos, tie);
+    };
+    auto frags_arrive = [&](svcmi_f32x4 (&a4)[WM], svcmi_f32x4 (&b4)[WN]) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) svcmi_lds_arrive(a4[i]);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) svcmi_lds_arrive(b4[j]);
     };
 
     constexpr int NSUB = BK / 8;                          // 4 sub-steps of 8 k per tile
@@ -255,10 +262,16 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
         if (ISSUE) stage_prep(it + NST - 1);
         const float* Ab = As0 + slot * BM * BK + a_off;
         const float* Bb = Bs0 + slot * BN * BK + b_off;
-        float4 a4[2][WM], b4[2][WN];
-        load_frags(Ab, Bb, 0, a4[0], b4[0]);
+        svcmi_f32x4 a4[2][WM], b4[2][WN];
+        svcmi_f32x4 tie0 = {0.f, 0.f, 0.f, 0.f};
+        load_frags(Ab, Bb, 0, a4[0], b4[0], tie0);
+        frags_arrive(a4[0], b4[0]);
 #pragma unroll
         for (int s = 0; s < NSUB; ++s) {
+            svcmi_f32x4(&af)[WM] = a4[s & 1];
+            svcmi_f32x4(&bf)[WN] = b4[s & 1];
+            // next sub-step's fragments are requested before this sub-step's MFMAs are issued ...
+            if (s + 1 < NSUB) load_frags(Ab, Bb, s + 1, a4[(s + 1) & 1], b4[(s + 1) & 1], af[0]);
             if (ISSUE) {
 #pragma unroll
                 for (int q = s * PIECES / NSUB; q < (s + 1) * PIECES / NSUB; ++q) {
@@ -266,25 +279,30 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
                     else stage_b(nslot, q - A_PER);
                 }
             }
-            if (s + 1 < NSUB) load_frags(Ab, Bb, s + 1, a4[(s + 1) & 1], b4[(s + 1) & 1]);
-            const float4(&af)[WM] = a4[s & 1];
-            const float4(&bf)[WN] = b4[s & 1];
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int j = 0; j < WN; ++j) acc[i][j] = svcmi_mfma_32x32x2(af[i].x, bf[j].x, acc[i][j]);
+                for (int j = 0; j < WN; ++j) acc[i][j] = svcmi_mfma_32x32x2(af[i][0], bf[j][0], acc[i][j]);
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int j = 0; j < WN; ++j) acc[i][j] = svcmi_mfma_32x32x2(af[i].y, bf[j].y, acc[i][j]);
+                for (int j = 0; j < WN; ++j) acc[i][j] = svcmi_mfma_32x32x2(af[i][1], bf[j][1], acc[i][j]);
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int j = 0; j < WN; ++j) acc[i][j] = svcmi_mfma_32x32x2(af[i].z, bf[j].z, acc[i][j]);
+                for (int j = 0; j < WN; ++j) acc[i][j] = svcmi_mfma_32x32x2(af[i][2], bf[j][2], acc[i][j]);
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int j = 0; j < WN; ++j) acc[i][j] = svcmi_mfma_32x32x2(af[i].w, bf[j].w, acc[i][j]);
+                for (int j = 0; j < WN; ++j) acc[i][j] = svcmi_mfma_32x32x2(af[i][3], bf[j][3], acc[i][j]);
+            // ... and waited for after them (the pins keep this sub-step's MFMAs above the wait)
+            if (s + 1 < NSUB) {
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) svcmi_pin(acc[i][j]);
+                frags_arrive(a4[(s + 1) & 1], b4[(s + 1) & 1]);
+            }
         }
     };
     {

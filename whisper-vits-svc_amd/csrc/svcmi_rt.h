@@ -74,6 +74,26 @@ __device__ __forceinline__ void svcmi_dma_wait_n() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// Register-prefetched LDS fragment reads.  hipcc sinks a plain `ds_read` to just above its first use, i.e. BELOW the
+// MFMAs of the running sub-step, so each sub-step opens with an exposed LDS round trip.  These two statements pin
+// the software pipeline instead (cdna_hip_programming.md section 5.7, form ii):
+//   svcmi_lds_read16(dst, p, tie)  issues ds_read_b128 dst <- p; `tie` (a register of the fragment the MFMAs
+//                                  about to be issued consume) is marked read-write so those MFMAs stay below it;
+//   svcmi_lds_arrive(dst)          s_waitcnt lgkmcnt(0) naming dst read-write, so no consumer floats above it.
+// hipcc does not count asm LDS operations; extra ones in flight only make its own lgkmcnt waits stricter.
+__device__ __forceinline__ void svcmi_lds_read16(svcmi_f32x4& dst, const float* p, svcmi_f32x4& tie) {
+    const unsigned a = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)p;
+    asm volatile("ds_read_b128 %0, %2" : "=v"(dst), "+v"(tie) : "v"(a) : "memory");
+}
+__device__ __forceinline__ void svcmi_lds_arrive(svcmi_f32x4& d) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d)::"memory"); }
+
+// Order fence for a register-only value: nothing that produces `v` is scheduled below, nothing that consumes it above.
+__device__ __forceinline__ void svcmi_pin(svcmi_f32x16& v) { asm volatile("" : "+a"(v)); }   // "a": stays in the accumulator file
+
+// Scheduling hint: the next `n` instructions of class `mask` (0x008 MFMA, 0x100 DS read, 0x020 VMEM read, 0x002 VALU)
+// form a group, groups are emitted in source order (cdna_hip_programming.md T19).
+#define SVCMI_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+
 // Tell hipcc a threadIdx-derived value is wave-uniform (unlocks scalar loads / SGPR operands).
 #define SVCMI_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 
