@@ -116,6 +116,21 @@ def roofline_pass(wl):
     return agg
 
 
+def measured_traffic(kernel="conv_gemm_kernel"):
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary (profiles/r*_traffic.json,
+    made by scripts/pmc_traffic.sh + scripts/traffic_summary.py: rocprofv3 cannot be driven from inside this
+    process).  Returns (bytes_per_launch, source) or (None, None)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        k = json.load(open(files[-1]))["kernels"][kernel]
+        return int(k["hbm_read_bytes_per_launch"] + k["hbm_write_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
+    except Exception:       # noqa: BLE001
+        return None, None
+
+
 def cpu_baseline(wl, wsd, vsd, hp, gpu_step):
     """Oracle (CPU port of the reference path) on ONE clip of the same workload, on this host's cores; also the
     parity check of the GPU path against it with identical noise."""
@@ -227,9 +242,11 @@ def main():
         total_ms = sum(a["ms"] for a in agg.values())
         gm = agg["svcmi_conv_gemm_f32"]
         ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
+        traffic, traffic_src = measured_traffic()
         out["roofline"] = {"kernel": "conv_gemm_kernel (svcmi_conv_gemm_f32)", "bound": "mfma", "achieved": round(ach, 2),
                            "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                           "traffic": None, "launches_per_step": gm["launches"],
+                           "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
+                           "traffic_source": traffic_src, "launches_per_step": gm["launches"],
                            "avg_launch_us": round(1000.0 * gm["ms"] / gm["launches"], 2),
                            "algorithmic_gflop_per_step": round(gm["flops"] / 1e9, 1),
                            "share_of_step_kernel_time": round(gm["ms"] / total_ms, 3)}

@@ -110,22 +110,46 @@ __device__ __forceinline__ float rad_of(float f0, int k, float sr) {
     return fmodf((f0 * (float)(k + 1)) / sr, 1.0f);
 }
 
+// Phase prefix of every frame, fp64, as a three-level scan per (batch item, harmonic): each of the 23 lanes a
+// harmonic owns sums a contiguous chunk of frames, lane 0 of the harmonic scans the 23 chunk totals, then every
+// lane replays its chunk from its offset.  All sums are taken mod 1 (only the fractional phase matters), so the
+// re-association moves a prefix by ~1e-16.  One block per batch item; 11 harmonics x 23 lanes = 253 threads busy.
+constexpr int PL = 23;      // lanes per harmonic: 11 * 23 <= 256
+
 __global__ __launch_bounds__(TPB) void pitch_prefix_kernel(const float* f0, const float* rand_ini, double* prefix,
                                                            int t, int hop, float sr) {
-    __shared__ float f0s[1024];
+    __shared__ double tot[NH * PL];
     const int b = blockIdx.x, tid = threadIdx.x;
-    double acc = (tid > 0 && tid < NH) ? (double)rand_ini[b * NH + tid] : 0.0;   // column 0 forced to 0 (:235)
-    for (int base = 0; base < t; base += 1024) {
-        __syncthreads();
-        for (int i = tid; i < 1024; i += TPB) f0s[i] = (base + i < t) ? f0[(long long)b * t + base + i] : 0.f;
-        __syncthreads();
-        if (tid < NH) {
-            const int lim = (t - base) < 1024 ? (t - base) : 1024;
-            for (int i = 0; i < lim; ++i) {
-                prefix[((long long)b * t + base + i) * NH + tid] = acc;
-                acc += (double)hop * (double)rad_of(f0s[i], tid, sr);
-                acc -= floor(acc);
-            }
+    const int k = tid / PL, l = tid - k * PL;
+    const bool on = k < NH;
+    const int per = (t + PL - 1) / PL;
+    const int f_beg = l * per, f_end = (f_beg + per) < t ? (f_beg + per) : t;
+    const float* fb = f0 + (long long)b * t;
+    double sum = 0.0;
+    if (on) {
+        for (int f = f_beg; f < f_end; ++f) {
+            sum += (double)hop * (double)rad_of(fb[f], k, sr);
+            sum -= floor(sum);
+        }
+        tot[tid] = sum;
+    }
+    __syncthreads();
+    if (on && l == 0) {       // exclusive scan of the chunk totals, seeded with the initial phase (column 0 forced to 0, :235)
+        double acc = k > 0 ? (double)rand_ini[b * NH + k] : 0.0;
+        for (int i = 0; i < PL; ++i) {
+            const double v = tot[k * PL + i];
+            tot[k * PL + i] = acc;
+            acc += v;
+            acc -= floor(acc);
+        }
+    }
+    __syncthreads();
+    if (on) {
+        double acc = tot[tid];
+        for (int f = f_beg; f < f_end; ++f) {
+            prefix[((long long)b * t + f) * NH + k] = acc;
+            acc += (double)hop * (double)rad_of(fb[f], k, sr);
+            acc -= floor(acc);
         }
     }
 }
