@@ -61,6 +61,20 @@ def main():
         gemm(ops, "whisper_mlp1", 500, 1280, 5120, tiles=(1, 2, 3), splits=(1,))
         gemm(ops, "whisper_mlp2", 500, 5120, 1280, res=True, tiles=(1, 3), splits=(8, 1))
         gemm(ops, "square4096", 4096, 4096, 4096, tiles=(1, 2, 3), splits=(1,))
+    if "small" in what:       # the short-K / few-tile GEMMs of the prior encoder, flow and widest decoder stage
+        sp = (1, 0, 2, 3, 4)
+        for k, d in ((3, 1), (7, 3), (11, 5)):
+            gemm(ops, "stage0_C160", 5000, 160, 160, k=k, dil=d, res=True, tiles=(0,), splits=sp)
+        for k, d in ((3, 1), (11, 5)):
+            gemm(ops, "stage1_C80", 20000, 80, 80, k=k, dil=d, res=True, tiles=(0,), splits=(1, 0))
+        gemm(ops, "flow_in", 1000, 192, 384, k=5, tiles=(0,), splits=sp)
+        gemm(ops, "flow_rs", 1000, 192, 384, k=1, tiles=(0,), splits=sp)
+        gemm(ops, "encp_ffn1", 1000, 192, 640, k=3, tiles=(0,), splits=sp)
+        gemm(ops, "encp_ffn2", 1000, 640, 192, k=3, tiles=(0,), splits=sp)
+        gemm(ops, "encp_qkv", 1000, 192, 576, k=1, tiles=(0,), splits=sp)
+        gemm(ops, "encp_pre", 1000, 1280, 192, k=5, tiles=(0,), splits=(1, 0, 4, 8))
+        gemm(ops, "dec_pre", 1000, 192, 320, k=7, tiles=(0,), splits=sp)
+        gemm(ops, "up0", 1000, 320, 800, k=3, tiles=(0,), splits=sp)
     if "dec" in what:
         for (C, n) in ((160, 5000), (80, 20000), (40, 80000), (20, 160000), (10, 320000)):
             for k, d in ((3, 1), (7, 3), (11, 5), (11, 1)):

@@ -445,10 +445,12 @@ extern "C" int svcmi_conv_gemm_f32(const svcmi_conv_desc* d, void* stream) {
     const int nk = (a.ktot + BK - 1) / BK;
     if (tile == SVCMI_CONV_TILE_64x64 && d->workspace && d->split_k != 1) {
         int s = d->split_k;
-        if (s == 0) {   // heuristic (measured, scripts/microbench.py): grids of >= 1.5 blocks per CU are left alone --
-                        // the reduce pass costs more than the idle CUs; smaller ones are cut to ~5 blocks per CU
-            s = blocks64 >= 384 ? 1 : (int)((1280 + blocks64 - 1) / blocks64);
-            if (s > nk / 4) s = nk / 4;
+        if (s == 0) {   // heuristic fitted to sweeps on MI355X (scripts/microbench.py gemm / small): aim at ~5 blocks per CU, keep
+                        // >= 10 K-steps per slice (shorter slices are all prologue), and leave grids of >= 1.5 blocks per CU alone --
+                        // there the reduce pass costs more than the idle CUs
+            s = blocks64 >= 384 ? 1 : (int)(1280 / blocks64);
+            if (s > nk / 10) s = nk / 10;
+            if (blocks64 >= 200 && nk < 32) s = 1;
             if (s > 16) s = 16;
         }
         if (s > nk) s = nk;

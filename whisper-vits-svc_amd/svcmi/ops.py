@@ -29,7 +29,7 @@ class Ops:
         if self.on_gpu and not torch.cuda.is_available():
             raise SvcmiError("libsvcmi.so is the gfx950 build but no GPU is visible; svcmi has no CPU fallback")
         self.launches = 0
-        self.workspace = None    # split-K scratch, allocated on first use (one per Ops / device)
+        self.workspaces = {}     # split-K scratch, one per (device, stream): launches on parallel streams must not share it
         self.workspace_floats = 16 * 1024 * 1024
         self.timeline = None     # set to a list to record (kernel, work, start_event, end_event) per launch
 
@@ -94,9 +94,11 @@ class Ops:
         d.flags = (CONV_ACCUMULATE if accumulate else 0) | (CONV_MASK_IN if mask_in else 0) | (CONV_MASK_OUT if mask_out else 0) | (tile << 8)
         d.alpha = alpha
         if split_k != 1:
-            if self.workspace is None or self.workspace.device != x.device:
-                self.workspace = torch.empty(self.workspace_floats, dtype=torch.float32, device=x.device)
-            d.split_k, d.workspace, d.workspace_floats = split_k, self.workspace.data_ptr(), self.workspace.numel()
+            key = (x.device, self._stream())
+            ws = self.workspaces.get(key)
+            if ws is None:
+                ws = self.workspaces[key] = torch.empty(self.workspace_floats, dtype=torch.float32, device=x.device)
+            d.split_k, d.workspace, d.workspace_floats = split_k, ws.data_ptr(), ws.numel()
         else:
             d.split_k, d.workspace, d.workspace_floats = 1, 0, 0
         self._call("svcmi_conv_gemm_f32", ctypes.byref(d), self._stream(),

@@ -28,6 +28,8 @@ class SynthesizerInfer:
         self._w = None           # packed device weights
         self._device = None
         self.training = False
+        self.parallel_blocks = True      # run the AMP blocks of a generator stage on parallel HIP streams
+        self._streams, self._streams_dev = None, None
 
     # ------------------------------------------------------------------ nn.Module-like surface
     @property
@@ -187,6 +189,42 @@ class SynthesizerInfer:
             ops.coupling_post(x, Lr["x1_off"], m, msvs, lengths, half)
         return x
 
+    def _block_streams(self, n):
+        dev = self._device
+        if self._streams is None or len(self._streams) < n or self._streams_dev != dev:
+            self._streams = [torch.cuda.Stream(device=dev) for _ in range(n)]
+            self._streams_dev = dev
+        return self._streams[:n]
+
+    def _amp_block(self, w, ops, st, blk, y, acc, bufs, j, nb, wait_for=None):
+        """AMPBlock.forward (vits_decoder/bigv.py:50-58) + the (sum of blocks)/nb of generator.py:188-194:
+        for d in dilations: x = x + conv2(act(conv1_d(act(x)))); the last iteration lands in ``acc``."""
+        xj, tmp, tmp2 = bufs
+        k = blk["k"]
+        xc = y
+        # narrow stages: SnakeAlias + conv as one kernel (csrc/amp_fused.hip); wide stages: two kernels
+        fused = all(ops.snake_conv_preferred(st["c"], st["cp"], k, d) for d in blk["d"])
+        for q, d in enumerate(blk["d"]):
+            last = q == len(blk["d"]) - 1
+            if fused:
+                b = ops.snake_conv(xc, blk["a1"][q][0], blk["a1"][q][1], w.filt, blk["c1"][q][0], blk["c1"][q][1],
+                                   c=st["c"], ksize=k, dilation=d, out=tmp)
+                a2 = None
+            else:
+                a = ops.snake_alias(xc, blk["a1"][q][0], blk["a1"][q][1], w.filt, out=tmp)
+                b = ops.conv(a, blk["c1"][q][0], blk["c1"][q][1], ksize=k, dilation=d, pad=(k * d - d) // 2, out=tmp2)
+                a2 = ops.snake_alias(b, blk["a2"][q][0], blk["a2"][q][1], w.filt, out=a)
+            if last and wait_for is not None:
+                torch.cuda.current_stream().wait_event(wait_for)       # acc += ... in block order
+            out, alpha, accum = (acc, 1.0 / nb, j > 0) if last else (xj, 1.0, False)
+            if fused:
+                ops.snake_conv(b, blk["a2"][q][0], blk["a2"][q][1], w.filt, blk["c2"][q][0], blk["c2"][q][1],
+                               c=st["c"], ksize=k, res=xc, alpha=alpha, accumulate=accum, out=out)
+            else:
+                ops.conv(a2, blk["c2"][q][0], blk["c2"][q][1], ksize=k, pad=(k - 1) // 2, res=xc,
+                         alpha=alpha, accumulate=accum, out=out)
+            xc = xj
+
     def _generator(self, w, ops, z, spk, source):
         """Generator.inference, vits_decoder/generator.py:175-200 (+ SpeakerAdapter :36-47, AMPBlock bigv.py:50-58).
         z [B,T,U] time-major, source [B, hop*T] -> [B,1,hop*T]."""
@@ -202,37 +240,33 @@ class SynthesizerInfer:
                      c_in=1, ldx=1, t_in=source.shape[1], t_out=y.shape[1], accumulate=True, out=y,
                      x_bstride=source.stride(0))
             acc = torch.empty_like(y)
-            xj = torch.empty_like(y)
-            tmp = torch.empty_like(y)
-            tmp2 = torch.empty_like(y)
             nb = len(st["blocks"])
+            # The nb AMP blocks of a stage (generator.py:188-194) only share their input; each runs its 3 iterations as
+            # an independent chain.  On the GPU they go to separate HIP streams (forked from / joined to the current
+            # one, also under graph capture) so that the many medium-sized launches of a stage overlap; the
+            # `acc (+)= (conv + x)/nb` of block j waits for block j-1's, which keeps the summation order fixed.
+            streams = self._block_streams(nb) if (self.parallel_blocks and ops.on_gpu) else None
+            bufs = [tuple(torch.empty_like(y) for _ in range(3)) for _ in range(nb if streams else 1)]
+            main = torch.cuda.current_stream() if streams else None
+            done = []
             for j, blk in enumerate(st["blocks"]):
-                k = blk["k"]
-                xc = y
-                # narrow stages: SnakeAlias + conv as one kernel (csrc/amp_fused.hip); wide stages: two kernels
-                fused = all(ops.snake_conv_preferred(st["c"], st["cp"], k, d) for d in blk["d"])
-                for q, d in enumerate(blk["d"]):
-                    last = q == len(blk["d"]) - 1
-                    if fused:
-                        b = ops.snake_conv(xc, blk["a1"][q][0], blk["a1"][q][1], w.filt, blk["c1"][q][0], blk["c1"][q][1],
-                                           c=st["c"], ksize=k, dilation=d, out=tmp)
-                        if not last:
-                            ops.snake_conv(b, blk["a2"][q][0], blk["a2"][q][1], w.filt, blk["c2"][q][0], blk["c2"][q][1],
-                                           c=st["c"], ksize=k, res=xc, out=xj)
-                            xc = xj
-                        else:   # (conv + x)/3 accumulated into the stage output (generator.py:188-194)
-                            ops.snake_conv(b, blk["a2"][q][0], blk["a2"][q][1], w.filt, blk["c2"][q][0], blk["c2"][q][1],
-                                           c=st["c"], ksize=k, res=xc, alpha=1.0 / nb, accumulate=(j > 0), out=acc)
-                        continue
-                    a = ops.snake_alias(xc, blk["a1"][q][0], blk["a1"][q][1], w.filt, out=tmp)
-                    b = ops.conv(a, blk["c1"][q][0], blk["c1"][q][1], ksize=k, dilation=d, pad=(k * d - d) // 2, out=tmp2)
-                    a2 = ops.snake_alias(b, blk["a2"][q][0], blk["a2"][q][1], w.filt, out=a)
-                    if not last:
-                        ops.conv(a2, blk["c2"][q][0], blk["c2"][q][1], ksize=k, pad=(k - 1) // 2, res=xc, out=xj)
-                        xc = xj
-                    else:   # last iteration: (conv + x)/3 accumulated into the stage output (generator.py:188-194)
-                        ops.conv(a2, blk["c2"][q][0], blk["c2"][q][1], ksize=k, pad=(k - 1) // 2, res=xc,
-                                 alpha=1.0 / nb, accumulate=(j > 0), out=acc)
+                if streams:
+                    streams[j].wait_stream(main)
+                    ctx = torch.cuda.stream(streams[j])
+                    ctx.__enter__()
+                try:
+                    self._amp_block(w, ops, st, blk, y, acc, bufs[j if streams else 0], j, nb,
+                                    wait_for=done[-1] if (streams and done) else None)
+                    if streams:
+                        ev = torch.cuda.Event()
+                        ev.record(streams[j])
+                        done.append(ev)
+                finally:
+                    if streams:
+                        ctx.__exit__(None, None, None)
+            if streams:
+                for sj in streams:
+                    main.wait_stream(sj)
             x = acc
         a = ops.snake_alias(x, w.post_a[0], w.post_a[1], w.filt)
         o = ops.conv(a, w.post_w, None, ksize=7, pad=3, act=ACT_TANH, n_out=1)
