@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SVCMI_ABI_VERSION 3
+#define SVCMI_ABI_VERSION 4
 
 enum svcmi_status { SVCMI_OK = 0, SVCMI_EINVAL = -1, SVCMI_EUNSUPPORTED = -2, SVCMI_EALIGN = -3 };
 
@@ -195,6 +195,17 @@ int svcmi_pitch_prefix_f64(const float* f0, const float* rand_ini, double* prefi
                            int32_t batch, int32_t t, int32_t hop, float sr, void* stream);
 int svcmi_pitch_source_f32(const float* f0, const double* prefix, const float* noise, const float* merge_w,
                            float merge_b, float* out, int32_t batch, int32_t t, int32_t hop, float sr, void* stream);
+
+/* Whisper log-mel front-end (whisper/audio.py:68-100), the glue around two svcmi_conv_gemm_f32 launches (the windowed DFT
+ * is a stride-160 / 400-tap / 1-channel convolution with a [hann*cos | -hann*sin] basis, the mel projection a linear
+ * layer):
+ *   reflect_pad:     y[b, i] = x[b, reflect(i - pad)], i < n + 2*pad          (torch.stft center=True, pad_mode="reflect")
+ *   power_spectrum:  p[r, f] = ri[r, f]^2 + ri[r, half + f]^2, f < nbins; p[r, nbins..ldp) = 0
+ *   logmel_finish:   v = log10(max(mel_power, 1e-10)); v = max(v, max_b(v) - 8); out[b, c, t] = (v[b, t, c] + 4) / 4
+ *                    mel_power [batch][t][c] is overwritten; scratch >= 64*batch floats; out is NCL like the reference. */
+int svcmi_reflect_pad_f32(const float* x, float* y, int32_t batch, int64_t n, int32_t pad, void* stream);
+int svcmi_power_spectrum_f32(const float* ri, float* p, int64_t rows, int32_t nbins, int32_t half, int32_t ldri, int32_t ldp, void* stream);
+int svcmi_logmel_finish_f32(float* mel_power, float* scratch, float* out, int32_t batch, int32_t t, int32_t c, void* stream);
 
 /* int16 side output, vits_decoder/generator.py:167-173: clamp(32768*x, -32768, 32767) truncated to short. */
 int svcmi_source2wav_i16(const float* x, int16_t* y, int64_t n, void* stream);

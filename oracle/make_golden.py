@@ -141,6 +141,27 @@ def svc_infer_fixture(tag, hp, T):
                         weights_checksum=checksum(sd), inputs_checksum=checksum(d))
 
 
+def logmel_fixture(tag, n, seed):
+    """The reference's own log_mel_spectrogram (whisper/audio.py:68-100) on a seeded signal.  Its filterbank comes
+    from librosa (absent): the restated Slaney matrix is injected in its place, so the fixture pins everything
+    EXCEPT that matrix."""
+    print(f"[{tag}] n={n}")
+    from . import audio_oracle as A
+    R._prepare()
+    import whisper.audio as ref_audio
+    fb = A.slaney_mel_filterbank()
+    ref_audio.librosa_mel_fn = lambda **kw: fb
+    ref_audio.mel_filters.cache_clear()
+    x = A.synth_audio(n, seed)
+    with torch.no_grad():
+        ref = ref_audio.log_mel_spectrogram(x.numpy())
+        o = A.log_mel_spectrogram(x)
+    _agree("logmel", o, ref, 1e-6)
+    assert tuple(ref.shape) == (80, n // 160)
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), n=n, seed=seed, logmel=ref.numpy(),
+                        filterbank_checksum=checksum([torch.from_numpy(fb)]), audio_checksum=checksum([x]))
+
+
 def main():
     assert R.available(), "needs /root/reference"
     os.makedirs(OUT, exist_ok=True)
@@ -150,6 +171,7 @@ def main():
     whisper_fixture("whisper_tiny", C.WHISPER_TINY_TEST, n=301)
     whisper_fixture("whisper_large_v2_n200", C.WHISPER_LARGE_V2, n=200)
     svc_infer_fixture("svc_infer_tiny_2chunks", C.tiny_hp(), T=2600)
+    logmel_fixture("logmel_2p5s", n=40000, seed=21)
     print("golden fixtures written to", OUT)
 
 

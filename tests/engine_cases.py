@@ -85,3 +85,18 @@ def check_svc_infer_golden(ops, device, tol=TIGHT):
                 tail=float(np.abs(wav[-2000:] - g["wave_tail"]).max()))
     assert max(errs.values()) <= min(tol * 5, WAVE_TOL), errs
     return errs
+
+
+def check_logmel_golden(ops, device, tol=2e-4):
+    """GPU log-mel front-end (svcmi.whisper.audio) vs the reference's own log_mel_spectrogram (golden fixture)."""
+    from oracle import audio_oracle as A
+    from svcmi.whisper import audio as PA
+    g = golden("logmel_2p5s")
+    x = A.synth_audio(int(g["n"]), int(g["seed"]))
+    got = PA.log_mel_spectrogram(x, ops=ops, device=device)
+    assert tuple(got.shape) == tuple(g["logmel"].shape)
+    err = maxerr(got, _t(g["logmel"]))
+    # log10 of a bin at the (max - 8) floor amplifies fp32 round-off of the 400-point transform; the reference's own
+    # fp32 FFT has the same noise there, so the tolerance is on the log-mel value, not on the power
+    assert err <= tol, err
+    return err

@@ -20,3 +20,7 @@ def test_vits_tiny_ragged_matches_reference_golden(ops):
 
 def test_whisper_tiny_matches_reference_golden(ops):
     print(E.check_whisper_golden(ops, "cpu", "whisper_tiny", C.WHISPER_TINY_TEST))
+
+
+def test_logmel_frontend_matches_reference_golden(ops):
+    print(E.check_logmel_golden(ops, "cpu"))

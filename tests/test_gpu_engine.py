@@ -39,6 +39,21 @@ def test_whisper_large_v2_golden(ops):
     print(E.check_whisper_golden(ops, "cuda", "whisper_large_v2_n200", C.WHISPER_LARGE_V2))
 
 
+def test_logmel_frontend_golden(ops):
+    print(E.check_logmel_golden(ops, "cuda"))
+
+
+def test_logmel_15s_window_against_oracle(ops):
+    """One full 15 s Whisper window (whisper/inference.py:37): wav -> log-mel on the GPU vs the CPU oracle."""
+    from oracle import audio_oracle as A
+    from svcmi.whisper import audio as PA
+    x = A.synth_audio(15 * 16000, 5)
+    got = PA.log_mel_spectrogram(x, ops=ops, device="cuda")
+    ref = A.log_mel_spectrogram(x)
+    assert got.shape == (80, 1500)
+    assert E.maxerr(got, ref) <= 2e-4
+
+
 def test_svc_infer_two_chunks_golden(ops):
     print(E.check_svc_infer_golden(ops, "cuda"))
 
@@ -74,6 +89,55 @@ def test_equal_length_batch_reproduces_solo_runs(ops):
         assert E.maxerr(s1, src[b:b + 1]) == 0.0
         assert E.maxerr(w1, wav[b:b + 1]) <= 1e-5
     assert wav.shape[-1] == 320 * 200                      # out_len == hop * T
+
+
+def test_batch16_x_10s_items_equal_solo_runs(ops):
+    """BASELINE.json configs[2] shape (16 x 10 s clips, flow + decoder, pre-extracted PPG/F0) in fp32: every item of the
+    batch must reproduce its solo run -- the size-independent property that stands in for a 16-clip CPU oracle run --
+    and item 0 is the clip test_full_10s_clip_against_oracle checks against the oracle."""
+    hp = C.base_hp()
+    m, _ = E.make_model(hp, ops, "cuda")
+    B = 16
+    items = [I.synth_clip(T=1000, hp=hp, seed=s, B=1) for s in range(B)]
+    d = {k: torch.cat([it[k] for it in items], 0) for k in items[0]}
+    src = m.pitch2source(d["pit"], noise=(d["rand_ini"], d["src_noise"]))
+    wav = m.inference(d["ppg"], d["vec"], d["pit"], d["spk"], d["lengths"], src, noise=d["enc_noise"])
+    assert wav.shape == (B, 1, 320000) and bool(torch.isfinite(wav).all())
+    for b in (0, 7, 15):
+        it = items[b]
+        s1 = m.pitch2source(it["pit"], noise=(it["rand_ini"], it["src_noise"]))
+        w1 = m.inference(it["ppg"], it["vec"], it["pit"], it["spk"], it["lengths"], s1, noise=it["enc_noise"])
+        assert E.maxerr(s1, src[b:b + 1]) == 0.0
+        assert E.maxerr(w1, wav[b:b + 1]) <= 1e-5
+
+
+def test_30s_clip_second_chunk_against_oracle(ops):
+    """BASELINE.json configs[4] shape: a 30 s clip = synth chunks [0,2510) and [2490,3000) (svc_inference.py:101-131).
+    The whole clip runs through svc_infer on the GPU; the oracle recomputes the second chunk (5.1 s, so the CPU side
+    stays bounded) and the kept samples [2500*320, L-1) must match, as must the total length L-1."""
+    from svcmi import DummyRetrieval, svc_infer
+    hp = C.base_hp()
+    m, sd = E.make_model(hp, ops, "cuda")
+    T, hop = 3000, 320
+    d = I.synth_clip(T=T, hp=hp, seed=31, B=1)
+    plan = O.chunk_schedule(T, hop)
+    assert [(a, b) for (a, b, _, _) in plan] == [(0, 2510), (2490, 3000)]
+    gen = torch.Generator().manual_seed(3)
+    enc_noises = [torch.randn(1, hp.vits.inter_channels, ce - cs, generator=gen) for (cs, ce, _, _) in plan]
+    wav = svc_infer(m, DummyRetrieval(), d["spk"][0], d["pit"][0], d["ppg"][0], d["vec"][0], hp, "cuda",
+                    noise={"rand_ini": d["rand_ini"], "src_noise": d["src_noise"], "enc_noises": enc_noises}, write_pit_wav=False)
+    assert wav.shape[0] == T * hop - 1
+    cs, ce, cso, ceo = plan[1]
+    with torch.no_grad():
+        o_src = O.pitch2source(sd, hp, d["pit"], d["rand_ini"], d["src_noise"])
+        o = O.synth_inference(sd, hp, d["ppg"][:, cs:ce], d["vec"][:, cs:ce], d["pit"][:, cs:ce], d["spk"],
+                              torch.tensor([ce - cs]), o_src[:, :, cs * hop:ce * hop], enc_noises[1])
+    ref = o[0, 0, cso:ceo].numpy()
+    got = wav[2500 * hop:]
+    assert got.shape == ref.shape
+    err = float(np.abs(got - ref).max())
+    print(f"30 s clip, chunk 2: err {err:.2e}")
+    assert err <= E.WAVE_TOL
 
 
 def test_run_to_run_bit_equality(ops):

@@ -112,3 +112,27 @@ def test_oracle_equals_live_reference_on_fresh_seed():
         o = O.synth_inference(sd, hp, d["ppg"], d["vec"], d["pit"], d["spk"], d["lengths"],
                               O.pitch2source(sd, hp, d["pit"], d["rand_ini"], d["src_noise"]), d["enc_noise"])
     assert (o - wav).abs().max() <= TOL
+
+
+def test_logmel_oracle_matches_reference_golden(golden_dir):
+    from oracle import audio_oracle as A
+    g = _load(golden_dir, "logmel_2p5s")
+    x = A.synth_audio(int(g["n"]), int(g["seed"]))
+    assert abs(checksum([x]) - float(g["audio_checksum"])) <= 1e-6 * abs(float(g["audio_checksum"]))
+    assert abs(checksum([torch.from_numpy(A.slaney_mel_filterbank())]) - float(g["filterbank_checksum"])) <= 1e-9
+    got = A.log_mel_spectrogram(x)
+    assert float((got - _t(g["logmel"])).abs().max()) <= 1e-5
+
+
+def test_slaney_filterbank_properties():
+    """The one matrix that cannot be pinned against librosa here: structural checks of the published construction."""
+    from oracle import audio_oracle as A
+    fb = A.slaney_mel_filterbank()
+    assert fb.shape == (80, 201) and (fb >= 0).all()
+    peaks = fb.argmax(1)
+    assert (np.diff(peaks) >= 0).all() and peaks[0] >= 1 and peaks[-1] <= 199      # centres increase with the mel index
+    freqs = np.linspace(0, 8000, 201)
+    centres = (fb * freqs).sum(1) / fb.sum(1)
+    assert abs(centres[0] - 200.0 / 3.0) < 30.0                                    # first centre = 1 mel step = 66.7 Hz
+    # Slaney normalisation: each triangle has unit area in Hz
+    assert np.allclose(fb.sum(1) * 40.0, 1.0, atol=0.08)

@@ -8,7 +8,7 @@ DEFAULT_LIB = os.path.join(HERE, "libsvcmi.so")
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_MISH, ACT_TANH = 0, 1, 2, 3, 4
 CONV_ACCUMULATE, CONV_MASK_IN, CONV_MASK_OUT = 1, 2, 4
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class ConvDesc(Structure):
@@ -45,6 +45,9 @@ SIGNATURES = {
     "svcmi_nlc_to_ncl_f32": (c_int, [_P, _I, _P, _I, _I, _I, _P]),
     "svcmi_pitch_prefix_f64": (c_int, [_P, _P, _P, _I, _I, _I, _F, _P]),
     "svcmi_pitch_source_f32": (c_int, [_P, _P, _P, _P, _F, _P, _I, _I, _I, _F, _P]),
+    "svcmi_reflect_pad_f32": (c_int, [_P, _P, _I, _L, _I, _P]),
+    "svcmi_power_spectrum_f32": (c_int, [_P, _P, _L, _I, _I, _I, _I, _P]),
+    "svcmi_logmel_finish_f32": (c_int, [_P, _P, _P, _I, _I, _I, _P]),
     "svcmi_source2wav_i16": (c_int, [_P, _P, _L, _P]),
 }
 

@@ -169,6 +169,29 @@ class Ops:
                    _ptr(out), B, T, hop, float(sr), self._stream())
         return out
 
+    # ------------------------------------------------------------------ whisper log-mel front-end
+    def reflect_pad(self, x, pad):
+        self._chk(x)
+        B, n = x.shape
+        y = torch.empty(B, n + 2 * pad, dtype=torch.float32, device=x.device)
+        self._call("svcmi_reflect_pad_f32", _ptr(x), _ptr(y), B, n, pad, self._stream())
+        return y
+
+    def power_spectrum(self, ri, nbins, half):
+        self._chk(ri)
+        B, T, ld = ri.shape
+        p = torch.empty(B, T, half, dtype=torch.float32, device=ri.device)
+        self._call("svcmi_power_spectrum_f32", _ptr(ri), _ptr(p), B * T, nbins, half, ld, half, self._stream())
+        return p
+
+    def logmel_finish(self, mel_power):
+        self._chk(mel_power)
+        B, T, Cc = mel_power.shape
+        scratch = torch.empty(B * 64, dtype=torch.float32, device=mel_power.device)
+        out = torch.empty(B, Cc, T, dtype=torch.float32, device=mel_power.device)
+        self._call("svcmi_logmel_finish_f32", _ptr(mel_power), _ptr(scratch), _ptr(out), B, T, Cc, self._stream())
+        return out
+
     def source2wav(self, x):
         self._chk(x)
         x = x.contiguous()

@@ -99,11 +99,11 @@ def window_plan(n_samples, sr=16000, window_s=K.WHISPER_WINDOW_S):
 
 
 def pred_ppg(whisper, wavPath, ppgPath, device):
-    """whisper/inference.py:32-62.  Needs the 16 kHz loader + log-mel front-end (row N2 of SURVEY.md 8f,
-    svcmi.whisper.audio); writes the same float32 [T50, 1280] .npy."""
+    """whisper/inference.py:32-62 with the 16 kHz loader + GPU log-mel front-end of svcmi.whisper.audio (row N2 of
+    SURVEY.md 8f); writes the same float32 [T50, 1280] .npy."""
     from . import audio
     wav = audio.load_audio(wavPath)
     plan = window_plan(wav.shape[0])
-    mels = [audio.log_mel_spectrogram(torch.from_numpy(wav[s:e])) for (s, e, _) in plan]
+    mels = [audio.log_mel_spectrogram(torch.from_numpy(wav[s:e]), ops=whisper.ops, device=whisper.device) for (s, e, _) in plan]
     ppg = pred_ppg_from_mel(whisper, mels, [k for (_, _, k) in plan])
     np.save(ppgPath, ppg.cpu().numpy(), allow_pickle=False)
