@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SVCMI_ABI_VERSION 4
+#define SVCMI_ABI_VERSION 5
 
 enum svcmi_status { SVCMI_OK = 0, SVCMI_EINVAL = -1, SVCMI_EUNSUPPORTED = -2, SVCMI_EALIGN = -3 };
 
@@ -68,7 +68,8 @@ const char* svcmi_build_info(void);
  * y may alias res (in-place residual).  bias / res / lengths may be NULL.
  * Split-K: when the (time x channel) tile grid is too small to fill the GPU the K range can be cut into
  * `split_k` slices whose partial tiles go through `workspace` (caller-owned, >= batch*split_k*t_out*n_out
- * floats, any contents) and are summed in fixed order by a second kernel -- deterministic, no atomics.
+ * floats, any contents) and are summed in fixed slice order -- by the last block to finish each tile when `counters` is
+ * given, by a second kernel otherwise -- deterministic either way (the only atomic is the arrival ticket).
  * split_k = 0 lets the library choose (never more than the workspace allows), 1 disables, workspace = NULL
  * disables.
  */
@@ -88,6 +89,9 @@ typedef struct svcmi_conv_desc {
     int32_t split_k;
     float* workspace;
     int64_t workspace_floats;
+    int32_t* counters;     /* optional: >= one int32 per output tile, ALL ZERO on entry (the library leaves them zero).  With it   */
+    int64_t counters_len;  /* the slices are combined inside the GEMM launch by the last-arriving block of each tile (fixed slice */
+                           /* order: still deterministic); without it a second kernel does the reduction.                         */
 } svcmi_conv_desc;
 
 int svcmi_conv_gemm_f32(const svcmi_conv_desc* d, void* stream);

@@ -135,6 +135,9 @@ static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((un
 #define SVCMI_LAST_ERROR() (emu::g_last_error)
 #define SVCMI_UNIFORM(x) (x)
 #define SVCMI_SCHED_GROUP(mask, n) ((void)0)
+#define SVCMI_RELEASE_AGENT() ((void)0)
+#define SVCMI_ACQUIRE_AGENT() ((void)0)
+static inline int svcmi_ticket(int* counter) { return (*counter)++; }   // blocks run one after another in the emulator
 static inline void svcmi_lds_read16(svcmi_f32x4& dst, const float* p, svcmi_f32x4&) { memcpy(&dst, p, 16); }
 static inline void svcmi_lds_arrive(svcmi_f32x4&) {}
 static inline void svcmi_pin(svcmi_f32x16&) {}
@@ -157,3 +160,6 @@ static inline void svcmi_bdma4(unsigned voff, float* lds_wave_base, svcmi_rsrc r
 static inline void svcmi_dma_wait() {}
 template <int N>
 static inline void svcmi_dma_wait_n() {}
+static inline void svcmi_store16_sc1(svcmi_f32x4 v, svcmi_rsrc r, unsigned byte_off) {
+    if ((unsigned long long)byte_off + 16 <= r.bytes) memcpy(const_cast<char*>(r.base) + byte_off, &v, 16);
+}

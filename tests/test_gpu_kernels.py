@@ -68,3 +68,37 @@ def test_pitch2source(ops, T, B):
 def test_source2wav(ops):
     K.check_source2wav(ops, device="cuda")
     torch.cuda.synchronize()
+
+
+def test_inlaunch_splitk_combine_is_bit_identical_under_load(ops):
+    """The in-launch split-K combine (last-arriving block of a tile sums the slabs in slice order) must give exactly
+    the bits of the two-kernel reduction, every time, also while another stream keeps the chip unevenly busy --
+    a stale slab (missing agent-scope release/acquire) would show up here as a mismatch."""
+    import math
+    from svcmi import weights as PW
+    g = torch.Generator().manual_seed(3)
+    cases = [(500, 5120, 1280, 1, 8), (500, 1280, 1280, 1, 4), (1000, 192, 384, 5, 3), (5000, 160, 160, 11, 2)]
+    side = torch.cuda.Stream()
+    big_a = torch.randn(1, 4096, 2048, device="cuda")
+    big_w = PW.pack_conv(torch.randn(2048, 2048, 1) / 45.0).cuda()
+    for (T, cin, n, k, split) in cases:
+        x = torch.randn(2, T, cin, generator=g).cuda()
+        w = PW.pack_conv(torch.randn(n, cin, k, generator=g) / math.sqrt(cin * k)).cuda()
+        bias = torch.randn(n, generator=g).cuda()
+        res = torch.randn(2, T, n, generator=g).cuda()
+        kw = dict(ksize=k, pad=(k - 1) // 2, res=res, act=2, split_k=split)
+        ops.inlaunch_reduce = False
+        want = ops.conv(x, w, bias, **kw).clone()
+        ops.inlaunch_reduce = True
+        torch.cuda.synchronize()
+        try:
+          for it in range(12):
+            if it % 2:
+                with torch.cuda.stream(side):          # uneven background load on another stream
+                    for _ in range(3):
+                        ops.conv(big_a, big_w, None, split_k=1)
+            got = ops.conv(x, w, bias, **kw)
+            assert torch.equal(got, want), (T, cin, n, k, split, it, float((got - want).abs().max()))
+        finally:
+            ops.inlaunch_reduce = False
+        torch.cuda.synchronize()

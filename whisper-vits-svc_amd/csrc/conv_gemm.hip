@@ -48,6 +48,7 @@ enum { MODE_CHUNK = 0, MODE_VEC = 1, MODE_SCALAR = 2, MODE_CHUNK_RS = 3 };   // 
 struct ConvArgs {
     const float* x; const float* w; const float* bias; const float* res; float* y; const int32_t* lengths;
     float* ws;                   // split-K partials [batch][split][t_out][n_out]
+    int* cnt;                    // one arrival counter per (batch, n-tile, m-tile), all zero between launches; NULL = two-kernel reduce
     long long x_bs, y_bs, r_bs;
     int t_in, t_out, c_in, ldx, n_out, ldw, ldy, ldr;
     int ksize, stride, dil, pad, rshift, act, flags;
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
     // the k=1 projections of the prior encoder / flow, k=3 convolutions) would otherwise pay on every step.
     constexpr int NST = (WM * WN == 1) ? 3 : (WM * WN == 2 ? 3 : 2);
     static_assert(BM * CLD <= NST * (BM + BN) * BK, "C tile must fit in the operand buffers");
-    __shared__ __attribute__((aligned(16))) float smem[NST * (BM + BN) * BK];
+    __shared__ __attribute__((aligned(16))) float smem[NST * (BM + BN) * BK + 4];   // + the split-K ticket word
     float* const As0 = smem;                          // As[slot] = As0 + slot*BM*BK, rows of 32 floats, chunk-swizzled
     float* const Bs0 = smem + NST * BM * BK;
 
@@ -337,11 +338,55 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
     __syncthreads();
     const int nvalid = (p.n_out - n0) < BN ? (p.n_out - n0) : BN;
     const int mvalid = (p.t_out - m0) < BM ? (p.t_out - m0) : BM;
-    if (p.split > 1) {   // raw partial tile; the reduce kernel applies the epilogue
+    if (p.split > 1) {   // raw partial tile into this slice's slab
         float* wsb = p.ws + ((long long)b * p.split + slice) * p.t_out * p.n_out;
+        if (!p.cnt) {        // no ticket counters: splitk_reduce_kernel sums the slabs in a second launch
+            for (int e = tid; e < BM * BN; e += 256) {
+                const int ml = e / BN, nl = e - ml * BN;
+                if (ml < mvalid && nl < nvalid) wsb[(long long)(m0 + ml) * p.n_out + n0 + nl] = Cs[ml * CLD + nl];
+            }
+            return;
+        }
+        // In-launch combine (cdna_hip_programming.md section 5, "in-launch split-K reduction", write-through form): the
+        // slab goes out with 16-byte sc1 (write-through) stores, which need no release fence -- a per-block
+        // `buffer_wbl2` made this 2.6x slower than the two-kernel path -- then every wave drains its stores and ONE
+        // relaxed agent-scope ticket is drawn.  The block that draws the last ticket of its tile acquires once and
+        // sums all slabs IN SLICE ORDER (its own included, from memory): the result does not depend on who is last.
+        {
+            const svcmi_rsrc sr = svcmi_make_rsrc(wsb, (unsigned)p.t_out * (unsigned)p.n_out * 4u);   // n_out % 4 == 0 here
+            for (int e = tid; e < BM * BN / 4; e += 256) {
+                const int ml = e / (BN / 4), nl = (e - ml * (BN / 4)) * 4;
+                if (ml < mvalid && nl < nvalid)
+                    svcmi_store16_sc1(*reinterpret_cast<const svcmi_f32x4*>(Cs + ml * CLD + nl), sr,
+                                      (unsigned)((m0 + ml) * p.n_out + n0 + nl) * 4u);
+            }
+        }
+        svcmi_dma_wait();                                   // every wave: its slab stores have left
+        __syncthreads();
+        int* const flag = reinterpret_cast<int*>(smem + BM * CLD);      // spare word behind the C tile (one LDS object only)
+        const int tile_id = (b * p.nt + by) * p.mt + bx;
+        if (tid == 0) *flag = svcmi_ticket(p.cnt + tile_id);
+        __syncthreads();
+        if (*flag != p.split - 1) return;
+        if (tid == 0) {
+            SVCMI_ACQUIRE_AGENT();
+            p.cnt[tile_id] = 0;                             // leave the counter ready for the next launch
+        }
+        __syncthreads();
+        float* yb2 = p.y + (long long)b * p.y_bs;
+        const float* rb2 = p.res ? p.res + (long long)b * p.r_bs : nullptr;
+        const float* ws0 = p.ws + (long long)b * p.split * p.t_out * p.n_out;
+        const long long sstride = (long long)p.t_out * p.n_out;
         for (int e = tid; e < BM * BN; e += 256) {
             const int ml = e / BN, nl = e - ml * BN;
-            if (ml < mvalid && nl < nvalid) wsb[(long long)(m0 + ml) * p.n_out + n0 + nl] = Cs[ml * CLD + nl];
+            if (ml >= mvalid || nl >= nvalid) continue;
+            const int t = m0 + ml, n = n0 + nl;
+            const float* src = ws0 + (long long)t * p.n_out + n;
+            float v = 0.f;
+            for (int sl = 0; sl < p.split; ++sl) v += src[sl * sstride];
+            float* dst = yb2 + (long long)t * p.ldy + n;
+            *dst = epilogue(p, v, p.bias ? p.bias[n] : 0.f, rb2 ? rb2 + (long long)t * p.ldr : nullptr, dst, n,
+                            (p.flags & SVCMI_CONV_MASK_OUT) && t >= len);
         }
         return;
     }
@@ -389,7 +434,7 @@ int launch(const ConvArgs& a_in, int batch, int mode, void* stream) {
     else if (mode == MODE_VEC) SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_VEC>), grid, dim3(256), 0, stream, a);
     else SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_SCALAR>), grid, dim3(256), 0, stream, a);
     int rc = SVCMI_LAST_ERROR();
-    if (rc == 0 && a.split > 1) {
+    if (rc == 0 && a.split > 1 && !a.cnt) {
         const long long total = (long long)batch * a.t_out * a.n_out;
         long long nb = (total + 255) / 256;
         if (nb > 2048) nb = 2048;
@@ -420,6 +465,7 @@ extern "C" int svcmi_conv_gemm_f32(const svcmi_conv_desc* d, void* stream) {
     ConvArgs a;
     a.x = d->x; a.w = d->w; a.bias = d->bias; a.res = d->res; a.y = d->y; a.lengths = d->lengths;
     a.ws = d->workspace;
+    a.cnt = nullptr;
     a.x_bs = d->x_bstride; a.y_bs = d->y_bstride; a.r_bs = d->res_bstride;
     a.t_in = d->t_in; a.t_out = d->t_out; a.c_in = d->c_in; a.ldx = d->ldx; a.n_out = d->n_out;
     a.ldw = d->ldw; a.ldy = d->ldy; a.ldr = d->ldr;
@@ -458,6 +504,12 @@ extern "C" int svcmi_conv_gemm_f32(const svcmi_conv_desc* d, void* stream) {
         if (s > 1) a.split = s;
     }
 
+    if (a.split > 1 && d->counters) {       // in-launch combine needs one zeroed counter per output tile
+        const int bm = tile == SVCMI_CONV_TILE_64x64 ? 64 : 128, bn = tile == SVCMI_CONV_TILE_128x128 ? 128 : 64;
+        const long long tiles = (long long)d->batch * ((d->t_out + bm - 1) / bm) * ((d->n_out + bn - 1) / bn);
+        if (tiles <= d->counters_len && d->n_out % 4 == 0 && (((uintptr_t)d->workspace & 15) == 0) &&
+            (long long)d->t_out * d->n_out < (1LL << 29)) a.cnt = d->counters;      // 16-byte write-through slab stores
+    }
     switch (tile) {
         case SVCMI_CONV_TILE_128x128: return launch<2, 2>(a, d->batch, mode, stream);
         case SVCMI_CONV_TILE_128x64: return launch<2, 1>(a, d->batch, mode, stream);

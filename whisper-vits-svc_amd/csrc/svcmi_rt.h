@@ -90,6 +90,20 @@ __device__ __forceinline__ void svcmi_lds_arrive(svcmi_f32x4& d) { asm volatile(
 // Order fence for a register-only value: nothing that produces `v` is scheduled below, nothing that consumes it above.
 __device__ __forceinline__ void svcmi_pin(svcmi_f32x16& v) { asm volatile("" : "+a"(v)); }   // "a": stays in the accumulator file
 
+// Cross-workgroup hand-off inside one launch (cdna_hip_programming.md Guideline 16): agent-scope release by the
+// producer, a relaxed agent-scope ticket, agent-scope acquire by the consumer.  Workgroup scope is NOT enough.
+#define SVCMI_RELEASE_AGENT() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
+#define SVCMI_ACQUIRE_AGENT() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+__device__ __forceinline__ int svcmi_ticket(int* counter) {
+    return __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// 16-byte write-through (sc1) store through a buffer descriptor: the data is visible to other XCDs once the issuing
+// wave's vmcnt drains -- no release fence (L2 write-back) needed for a hand-off (Guideline 16, R1).
+__device__ __forceinline__ void svcmi_store16_sc1(svcmi_f32x4 v, svcmi_rsrc r, unsigned byte_off) {
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen sc1\n\ts_nop 1" ::"v"(v), "v"(byte_off), "s"(r) : "memory");
+}
+
 // Scheduling hint: the next `n` instructions of class `mask` (0x008 MFMA, 0x100 DS read, 0x020 VMEM read, 0x002 VALU)
 // form a group, groups are emitted in source order (cdna_hip_programming.md T19).
 #define SVCMI_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)

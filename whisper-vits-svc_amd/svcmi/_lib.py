@@ -8,7 +8,7 @@ DEFAULT_LIB = os.path.join(HERE, "libsvcmi.so")
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_MISH, ACT_TANH = 0, 1, 2, 3, 4
 CONV_ACCUMULATE, CONV_MASK_IN, CONV_MASK_OUT = 1, 2, 4
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class ConvDesc(Structure):
@@ -20,6 +20,7 @@ class ConvDesc(Structure):
         ("ksize", c_int32), ("stride", c_int32), ("dilation", c_int32), ("pad", c_int32), ("x_row_shift", c_int32),
         ("act", c_int32), ("flags", c_int32), ("alpha", c_float), ("split_k", c_int32),
         ("workspace", c_void_p), ("workspace_floats", c_int64),
+        ("counters", c_void_p), ("counters_len", c_int64),
     ]
 
 

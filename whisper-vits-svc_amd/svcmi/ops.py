@@ -31,6 +31,10 @@ class Ops:
         self.launches = 0
         self.workspaces = {}     # split-K scratch, one per (device, stream): launches on parallel streams must not share it
         self.workspace_floats = 16 * 1024 * 1024
+        # split-K slices combined inside the GEMM launch by the last-arriving block of each tile.  Correct (bit-identical to
+        # the two-kernel reduction, tests/test_gpu_kernels.py) but SLOWER on MI355X at these slab sizes (64-128 KB per tile):
+        # 10 s step 15.8 ms (write-through slabs) / 16.1 ms (release fence per block) vs 12.6 ms -> off by default.
+        self.inlaunch_reduce = False
         self.timeline = None     # set to a list to record (kernel, work, start_event, end_event) per launch
 
     # ------------------------------------------------------------------ plumbing
@@ -96,9 +100,12 @@ class Ops:
         if split_k != 1:
             key = (x.device, self._stream())
             ws = self.workspaces.get(key)
-            if ws is None:
-                ws = self.workspaces[key] = torch.empty(self.workspace_floats, dtype=torch.float32, device=x.device)
-            d.split_k, d.workspace, d.workspace_floats = split_k, ws.data_ptr(), ws.numel()
+            if ws is None:     # slabs + zeroed per-tile arrival counters (the library keeps them zero)
+                ws = self.workspaces[key] = (torch.empty(self.workspace_floats, dtype=torch.float32, device=x.device),
+                                             torch.zeros(65536, dtype=torch.int32, device=x.device))
+            d.split_k, d.workspace, d.workspace_floats = split_k, ws[0].data_ptr(), ws[0].numel()
+            if self.inlaunch_reduce:
+                d.counters, d.counters_len = ws[1].data_ptr(), ws[1].numel()
         else:
             d.split_k, d.workspace, d.workspace_floats = 1, 0, 0
         self._call("svcmi_conv_gemm_f32", ctypes.byref(d), self._stream(),
