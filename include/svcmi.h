@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SVCMI_ABI_VERSION 5
+#define SVCMI_ABI_VERSION 6
 
 enum svcmi_status { SVCMI_OK = 0, SVCMI_EINVAL = -1, SVCMI_EUNSUPPORTED = -2, SVCMI_EALIGN = -3 };
 
@@ -36,6 +36,8 @@ enum svcmi_conv_flags {
     SVCMI_CONV_ACCUMULATE = 1, /* y += result instead of y = result                          */
     SVCMI_CONV_MASK_IN = 2,    /* input rows >= lengths[b] read as zero   (conv(x * x_mask))  */
     SVCMI_CONV_MASK_OUT = 4,   /* output rows >= lengths[b] written as zero  (... * x_mask)   */
+    SVCMI_CONV_PARTIALS = 8,   /* write exactly split_k raw partial slabs [batch][split_k][t_out][n_out] to `workspace` and stop:   */
+                               /* no reduction, no epilogue, y untouched (consumer: svcmi_splitk_layernorm_f32)                     */
     /* tuning knob (bits 8-9): force the block tile (time x channels); 0 = library heuristic        */
     SVCMI_CONV_TILE_64x64 = 0x100,
     SVCMI_CONV_TILE_128x64 = 0x200,
@@ -107,6 +109,15 @@ int svcmi_conv_gemm_f32(const svcmi_conv_desc* d, void* stream);
 int svcmi_layernorm_f32(const float* x, const float* res, const float* gamma, const float* beta, float* y,
                         int32_t batch, int32_t rows_per_batch, int32_t c, int32_t ldx, int32_t ldr, int32_t ldy,
                         int32_t gb_bstride, float eps, void* stream);
+
+/* Split-K tail fused with the residual update and the LayerNorm that follows it (whisper/model.py:118-129:
+ * `x = x + attn(...)` / `x = x + mlp(...)` then the next `ln(x)`):
+ *   x[r,:] += bias + sum_{s<split} partials[b, s, t, :]   (slice order fixed);   y[r,:] = LayerNorm(x[r,:]) * gamma + beta
+ * partials: the slabs a SVCMI_CONV_PARTIALS launch of svcmi_conv_gemm_f32 left in its workspace ([batch][split][t][c]).
+ * rows r = b*rows_per_batch + t.  c % 4 == 0, c <= 2048. */
+int svcmi_splitk_layernorm_f32(const float* partials, int32_t split, const float* bias, float* x, const float* gamma,
+                               const float* beta, float* y, int32_t batch, int32_t rows_per_batch, int32_t c,
+                               int32_t ldx, int32_t ldy, float eps, void* stream);
 
 /* Multi-head self-attention with exact (fp32, online) softmax.
  *   S[i,j] = scale * ( q_i . k_j  +  (|j-i| <= window ? q_i . rel_k[j-i+window] : 0) )

@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
     __syncthreads();
     const int nvalid = (p.n_out - n0) < BN ? (p.n_out - n0) : BN;
     const int mvalid = (p.t_out - m0) < BM ? (p.t_out - m0) : BM;
-    if (p.split > 1) {   // raw partial tile into this slice's slab
+    if (p.split > 1 || (p.flags & SVCMI_CONV_PARTIALS)) {   // raw partial tile into this slice's slab
         float* wsb = p.ws + ((long long)b * p.split + slice) * p.t_out * p.n_out;
         if (!p.cnt) {        // no ticket counters: splitk_reduce_kernel sums the slabs in a second launch
             for (int e = tid; e < BM * BN; e += 256) {
@@ -434,7 +434,7 @@ int launch(const ConvArgs& a_in, int batch, int mode, void* stream) {
     else if (mode == MODE_VEC) SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_VEC>), grid, dim3(256), 0, stream, a);
     else SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_SCALAR>), grid, dim3(256), 0, stream, a);
     int rc = SVCMI_LAST_ERROR();
-    if (rc == 0 && a.split > 1 && !a.cnt) {
+    if (rc == 0 && a.split > 1 && !a.cnt && !(a.flags & SVCMI_CONV_PARTIALS)) {
         const long long total = (long long)batch * a.t_out * a.n_out;
         long long nb = (total + 255) / 256;
         if (nb > 2048) nb = 2048;
@@ -489,7 +489,11 @@ extern "C" int svcmi_conv_gemm_f32(const svcmi_conv_desc* d, void* stream) {
     // Split-K: only for 64x64 tiles that leave CUs idle; slices keep >= 4 K-steps each.
     a.split = 1;
     const int nk = (a.ktot + BK - 1) / BK;
-    if (tile == SVCMI_CONV_TILE_64x64 && d->workspace && d->split_k != 1) {
+    if (d->flags & SVCMI_CONV_PARTIALS) {       // caller consumes the slabs itself: exactly split_k of them, no epilogue
+        if (!d->workspace || d->split_k < 1 || d->split_k > nk) return SVCMI_EINVAL;
+        if ((long long)d->batch * d->split_k * d->t_out * d->n_out > d->workspace_floats) return SVCMI_EINVAL;
+        a.split = d->split_k;
+    } else if (tile == SVCMI_CONV_TILE_64x64 && d->workspace && d->split_k != 1) {
         int s = d->split_k;
         if (s == 0) {   // heuristic fitted to sweeps on MI355X (scripts/microbench.py gemm / small): aim at ~5 blocks per CU, keep
                         // >= 10 K-steps per slice (shorter slices are all prologue), and leave grids of >= 1.5 blocks per CU alone --
@@ -504,7 +508,7 @@ extern "C" int svcmi_conv_gemm_f32(const svcmi_conv_desc* d, void* stream) {
         if (s > 1) a.split = s;
     }
 
-    if (a.split > 1 && d->counters) {       // in-launch combine needs one zeroed counter per output tile
+    if (a.split > 1 && d->counters && !(d->flags & SVCMI_CONV_PARTIALS)) {       // in-launch combine needs one zeroed counter per output tile
         const int bm = tile == SVCMI_CONV_TILE_64x64 ? 64 : 128, bn = tile == SVCMI_CONV_TILE_128x128 ? 128 : 64;
         const long long tiles = (long long)d->batch * ((d->t_out + bm - 1) / bm) * ((d->n_out + bn - 1) / bn);
         if (tiles <= d->counters_len && d->n_out % 4 == 0 && (((uintptr_t)d->workspace & 15) == 0) &&

@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_GELU, ACT_MISH, ACT_NONE, ACT_RELU, ACT_TANH, CONV_ACCUMULATE, CONV_MASK_IN,  # noqa: F401
-                   CONV_MASK_OUT, ConvDesc, SvcmiError)
+                   CONV_MASK_OUT, CONV_PARTIALS, ConvDesc, SvcmiError)
 
 
 def _ptr(t):
@@ -68,7 +68,7 @@ class Ops:
     # ------------------------------------------------------------------ conv / linear
     def conv(self, x, w, bias=None, *, ksize=1, stride=1, dilation=1, pad=0, t_out=None, act=ACT_NONE,
              res=None, alpha=1.0, accumulate=False, lengths=None, mask_in=False, mask_out=False, out=None,
-             x_row_shift=0, c_in=None, ldx=None, t_in=None, n_out=None, x_bstride=None, tile=0, split_k=0):
+             x_row_shift=0, c_in=None, ldx=None, t_in=None, n_out=None, x_bstride=None, tile=0, split_k=0, partials=False):
         """y[b,t,n] = epilogue(sum_k sum_ci x[b, t*stride + k*dilation - pad, ci] * w[n, k*c_in + ci]).
         ``x`` is [B, T, C]; ``w`` is [N, ldw] packed (weights.pack_conv)."""
         self._chk(x, w, bias, res, out, lengths)
@@ -84,32 +84,35 @@ class Ops:
         N = w.shape[0] if n_out is None else n_out
         if t_out is None:
             t_out = (t_in + 2 * pad - dilation * (ksize - 1) - 1) // stride + 1
-        if out is None:
+        if out is None and not partials:
             out = torch.empty(B, t_out, N, dtype=torch.float32, device=x.device)
         d = ConvDesc()
-        d.x, d.w, d.bias, d.res, d.y, d.lengths = _ptr(x), _ptr(w), _ptr(bias), _ptr(res), _ptr(out), _ptr(lengths)
-        d.x_bstride, d.y_bstride = x_bstride, out.stride(0)
+        d.x, d.w, d.bias, d.res, d.y, d.lengths = _ptr(x), _ptr(w), _ptr(bias), _ptr(res), _ptr(out if out is not None else x), _ptr(lengths)
+        d.x_bstride, d.y_bstride = x_bstride, (out.stride(0) if out is not None else 0)
         d.res_bstride = res.stride(0) if (res is not None and res.dim() == 3) else 0   # 2-D res is shared by the batch
         d.batch, d.t_in, d.t_out, d.c_in, d.ldx = B, t_in, t_out, c_in, ldx
-        d.n_out, d.ldw, d.ldy = N, w.shape[1], out.stride(1)
+        d.n_out, d.ldw, d.ldy = N, w.shape[1], (out.stride(1) if out is not None else N)
         d.ldr = res.stride(-2) if res is not None else 0
         d.ksize, d.stride, d.dilation, d.pad, d.x_row_shift = ksize, stride, dilation, pad, x_row_shift
         d.act = act
-        d.flags = (CONV_ACCUMULATE if accumulate else 0) | (CONV_MASK_IN if mask_in else 0) | (CONV_MASK_OUT if mask_out else 0) | (tile << 8)
+        d.flags = (CONV_ACCUMULATE if accumulate else 0) | (CONV_MASK_IN if mask_in else 0) | (CONV_MASK_OUT if mask_out else 0) | \
+                  (CONV_PARTIALS if partials else 0) | (tile << 8)
         d.alpha = alpha
-        if split_k != 1:
+        if split_k != 1 or partials:
             key = (x.device, self._stream())
             ws = self.workspaces.get(key)
             if ws is None:     # slabs + zeroed per-tile arrival counters (the library keeps them zero)
                 ws = self.workspaces[key] = (torch.empty(self.workspace_floats, dtype=torch.float32, device=x.device),
                                              torch.zeros(65536, dtype=torch.int32, device=x.device))
             d.split_k, d.workspace, d.workspace_floats = split_k, ws[0].data_ptr(), ws[0].numel()
-            if self.inlaunch_reduce:
+            if self.inlaunch_reduce and not partials:
                 d.counters, d.counters_len = ws[1].data_ptr(), ws[1].numel()
         else:
             d.split_k, d.workspace, d.workspace_floats = 1, 0, 0
         self._call("svcmi_conv_gemm_f32", ctypes.byref(d), self._stream(),
                    work={"flops": 2.0 * B * t_out * N * ksize * c_in})
+        if partials:      # [B, split, t_out, N] view of this stream's workspace; valid until the next split-K launch on it
+            return ws[0][:B * split_k * t_out * N].view(B, split_k, t_out, N)
         return out
 
     # ------------------------------------------------------------------ norm / attention
@@ -121,6 +124,16 @@ class Ops:
         self._call("svcmi_layernorm_f32", _ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(out), B, T, Cc,
                    x.stride(1), res.stride(1) if res is not None else 0, out.stride(1),
                    (gamma.stride(0) if gamma is not None else beta.stride(0)) if per_batch_affine else 0, eps, self._stream())
+        return out
+
+    def splitk_layernorm(self, partials, bias, x, gamma, beta, *, eps=1e-5, out=None):
+        """x += bias + sum_s partials[:, s]  (in place);  returns LayerNorm(x) * gamma + beta.  partials: [B, S, T, C]."""
+        self._chk(partials, bias, x, gamma, beta, out)
+        B, S, T, Cc = partials.shape
+        if out is None:
+            out = torch.empty_like(x)
+        self._call("svcmi_splitk_layernorm_f32", _ptr(partials), S, _ptr(bias), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(out),
+                   B, T, Cc, x.stride(1), out.stride(1), eps, self._stream())
         return out
 
     def attention(self, qkv, heads, scale, *, rel_k=None, rel_v=None, window=0, lengths=None, out=None):

@@ -19,6 +19,7 @@ class AudioEncoder:
 
     def __init__(self, w, ops):
         self.w, self.ops = w, ops
+        self.split_o, self.split_mlp = 4, 8      # K slices of the two N = state projections (scripts/microbench.py gemm)
 
     @torch.no_grad()
     def __call__(self, mel, noise=None, noise_scale=0.1):
@@ -35,15 +36,21 @@ class AudioEncoder:
             raise AssertionError("incorrect audio shape")                                   # model.py:156
         x = ops.conv(x, w.conv2_w, w.conv2_b, ksize=3, stride=2, pad=1, act=ACT_GELU, res=w.pos[:tw])  # :151-158
         scale = float(w.S // w.heads) ** -0.5          # (d^-0.25 on q) * (d^-0.25 on k), model.py:90-92
-        for blk in w.blocks:                            # model.py:118-129
-            h = ops.layernorm(x, blk["ln1_g"], blk["ln1_b"])
+        # model.py:118-129.  The two residual projections (attention out, MLP down: N = 1280 leaves most CUs idle) run
+        # split-K; their slabs are summed by the kernel that also applies the residual add and the NEXT LayerNorm
+        # (attn_ln -> mlp_ln -> next block's attn_ln -> ... -> ln_post), so a block is 6 launches.
+        nb = len(w.blocks)
+        h = ops.layernorm(x, w.blocks[0]["ln1_g"], w.blocks[0]["ln1_b"]) if nb else None
+        for i, blk in enumerate(w.blocks):
             qkv = ops.conv(h, blk["qkv_w"], blk["qkv_b"])
             a = ops.attention(qkv, w.heads, scale)
-            ops.conv(a, blk["o_w"], blk["o_b"], res=x, out=x)
-            h = ops.layernorm(x, blk["ln2_g"], blk["ln2_b"], out=h)
+            p = ops.conv(a, blk["o_w"], None, partials=True, split_k=max(1, min(self.split_o, blk["o_w"].shape[1] // 128)))
+            h = ops.splitk_layernorm(p, blk["o_b"], x, blk["ln2_g"], blk["ln2_b"], out=h)
             m = ops.conv(h, blk["m1_w"], blk["m1_b"], act=ACT_GELU)
-            ops.conv(m, blk["m2_w"], blk["m2_b"], res=x, out=x)
-        return ops.layernorm(x, w.lnp_g, w.lnp_b)
+            p = ops.conv(m, blk["m2_w"], None, partials=True, split_k=max(1, min(self.split_mlp, blk["m2_w"].shape[1] // 128)))
+            g, b = (w.blocks[i + 1]["ln1_g"], w.blocks[i + 1]["ln1_b"]) if i + 1 < nb else (w.lnp_g, w.lnp_b)
+            h = ops.splitk_layernorm(p, blk["m2_b"], x, g, b, out=h)
+        return h if nb else ops.layernorm(x, w.lnp_g, w.lnp_b)
 
 
 class WhisperEncoderModel:
