@@ -112,6 +112,25 @@ def check_layernorm(ops, c, device):
     _close(ops.layernorm(x.to(device), gb.to(device), bb.to(device), per_batch_affine=True), want, 2e-5, "ln per-batch")
 
 
+def check_splitk_layernorm(ops, device, B=2, S=3, T=7, c=1280):
+    """conv(partials=True) slabs -> fused reduce + bias + residual + LayerNorm, vs the unsplit conv + torch layer_norm."""
+    g = _g(100 + c + S)
+    cin = 64 * S
+    a = torch.randn(B, T, cin, generator=g)
+    w = torch.randn(c, cin, 1, generator=g) / math.sqrt(cin)
+    bias, x = torch.randn(c, generator=g), torch.randn(B, T, c, generator=g)
+    gamma, beta = torch.randn(c, generator=g), torch.randn(c, generator=g)
+    x_ref = x + F.conv1d(a.transpose(1, 2), w, bias).transpose(1, 2)
+    y_ref = F.layer_norm(x_ref, (c,), gamma, beta, 1e-5)
+    dev = lambda t: t.to(device)
+    xd = dev(x.clone())
+    part = ops.conv(dev(a), PW.pack_conv(w).to(device), None, partials=True, split_k=S)
+    assert tuple(part.shape) == (B, S, T, c)
+    y = ops.splitk_layernorm(part, dev(bias), xd, dev(gamma), dev(beta))
+    _close(xd, x_ref, 2e-5, "splitk_ln residual stream")
+    _close(y, y_ref, 5e-5, "splitk_ln output")
+
+
 ATTN_CASES_SMALL = [
     dict(id="d16_rel_w4_ragged", B=2, T=45, H=2, D=16, rel=True, W=4, lengths=[45, 31]),
     dict(id="d32_plain", B=1, T=70, H=3, D=32),

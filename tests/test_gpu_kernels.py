@@ -48,6 +48,11 @@ def test_snake_conv_fused(ops, case):
     K.check_snake_conv(ops, case, device="cuda")
 
 
+@pytest.mark.parametrize("S,c", [(1, 128), (3, 1280), (8, 2048)])
+def test_splitk_layernorm(ops, S, c):
+    K.check_splitk_layernorm(ops, "cuda", S=S, c=c)
+
+
 def test_flow_glue(ops):
     K.check_flow_glue(ops, device="cuda")
 

@@ -73,23 +73,36 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
 
 // Split-K tail fused with the residual update and the LayerNorm that follows it (Whisper: x += W_o a + b_o; h = LN(x)):
 //   x[r,:] += bias + sum_{s < split} partials[b, s, t, :]   (fixed slice order: deterministic);   y[r,:] = LN(x[r,:])
-// One wave per row like layernorm_kernel; replaces the split-K reduce launch and the LayerNorm launch.
+// One 256-thread block per row (a 500-row Whisper window would otherwise occupy only 500 waves, each waiting on
+// `split` dependent-latency slab reads): a thread owns <= 2 float4 columns, statistics go wave shuffle -> LDS.
+// Replaces the split-K reduce launch and the LayerNorm launch.
+constexpr int SKV = 2;      // float4 columns per thread: c <= 256 * 4 * SKV = 2048
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();                 // red[] may still be read from the previous reduction
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 __global__ __launch_bounds__(256) void splitk_layernorm_kernel(const float* part, int split, const float* bias, float* x,
-                                                               const float* gamma, const float* beta, float* y, int rows,
+                                                               const float* gamma, const float* beta, float* y,
                                                                int rows_per_batch, int c, int ldx, int ldy, float eps) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    __shared__ float red[4];
+    const int row = blockIdx.x;
     const int nv = c >> 2;
     const int b = row / rows_per_batch, t = row - b * rows_per_batch;
     float* xr = x + (long long)row * ldx;
     const float* pr = part + ((long long)b * split * rows_per_batch + t) * c;
     const long long sstride = (long long)rows_per_batch * c;
-    float4 v[LN_MAXV];
+    float4 v[SKV];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int q = lane + 64 * i;
+    for (int i = 0; i < SKV; ++i) {
+        const int q = threadIdx.x + 256 * i;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (q < nv) {
             float4 acc = *reinterpret_cast<const float4*>(pr + 4 * q);
             for (int sl = 1; sl < split; ++sl) {
@@ -105,25 +118,22 @@ __global__ __launch_bounds__(256) void splitk_layernorm_kernel(const float* part
             *reinterpret_cast<float4*>(xr + 4 * q) = acc;
             v[i] = acc;
             s += (acc.x + acc.y) + (acc.z + acc.w);
-        } else {
-            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    const float mean = wave_sum(s) / (float)c;
+    const float mean = block_sum_256(s, red) / (float)c;
     float ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int q = lane + 64 * i;
-        if (q < nv) {
+    for (int i = 0; i < SKV; ++i) {
+        if (threadIdx.x + 256 * i < nv) {
             const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
             ss += (dx * dx + dy * dy) + (dz * dz + dw * dw);
         }
     }
-    const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)c + eps);
+    const float rstd = 1.0f / sqrtf(block_sum_256(ss, red) / (float)c + eps);
     float* yr = y + (long long)row * ldy;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int q = lane + 64 * i;
+    for (int i = 0; i < SKV; ++i) {
+        const int q = threadIdx.x + 256 * i;
         if (q < nv) {
             const float4 g = gamma ? *reinterpret_cast<const float4*>(gamma + 4 * q) : make_float4(1.f, 1.f, 1.f, 1.f);
             const float4 bb = beta ? *reinterpret_cast<const float4*>(beta + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -445,14 +455,14 @@ extern "C" int svcmi_splitk_layernorm_f32(const float* partials, int32_t split, 
                                           const float* beta, float* y, int32_t batch, int32_t rows_per_batch, int32_t c,
                                           int32_t ldx, int32_t ldy, float eps, void* stream) {
     if (!partials || !x || !y || split < 1 || batch <= 0 || rows_per_batch <= 0 || c <= 0) return SVCMI_EINVAL;
-    if (c % 4 != 0 || c > 64 * 4 * LN_MAXV) return SVCMI_EUNSUPPORTED;
+    if (c % 4 != 0 || c > 256 * 4 * SKV) return SVCMI_EUNSUPPORTED;
     if (ldx % 4 || ldy % 4) return SVCMI_EALIGN;
     if (((uintptr_t)partials & 15) || ((uintptr_t)x & 15) || ((uintptr_t)y & 15) || ((uintptr_t)bias & 15) ||
         ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15)) return SVCMI_EALIGN;
     const long long rows = (long long)batch * rows_per_batch;
     if (rows > 0x7fffffffLL) return SVCMI_EUNSUPPORTED;
-    SVCMI_LAUNCH(splitk_layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, partials, split, bias, x, gamma,
-                 beta, y, (int)rows, rows_per_batch, c, ldx, ldy, eps);
+    SVCMI_LAUNCH(splitk_layernorm_kernel, dim3((unsigned)rows), dim3(256), 0, stream, partials, split, bias, x, gamma,
+                 beta, y, rows_per_batch, c, ldx, ldy, eps);
     return SVCMI_LAST_ERROR();
 }
 
