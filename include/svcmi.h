@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SVCMI_ABI_VERSION 6
+#define SVCMI_ABI_VERSION 7
 
 enum svcmi_status { SVCMI_OK = 0, SVCMI_EINVAL = -1, SVCMI_EUNSUPPORTED = -2, SVCMI_EALIGN = -3 };
 
@@ -158,6 +158,20 @@ int svcmi_snake_conv_f32(const float* x, const float* w, const float* bias, cons
                          const float* alpha_log, const float* beta_log, const float* filt,
                          int32_t batch, int32_t len, int32_t c, int32_t ld, int32_t ldw, int32_t ksize,
                          int32_t dilation, float alpha, int32_t accumulate, void* stream);
+
+/* Stage entry of the narrow generator stages in one launch (vits_decoder/generator.py:183-186):
+ *   y[b, u*q + r, co] = b_up[r*cp+co] + sum_{k<taps} sum_{ci<c_in} x[b, q + k - pad, ci] * w_up[r*cp+co, k*c_in + ci]      (ups[i], polyphase)
+ *                     + b_nz[co] + sum_{k<nz_k} src[b, (u*q+r)*nz_stride - nz_pad + k] * w_nz[co, k]                       (noise_convs[i])
+ * x: [batch][t_in][c_in]; w_up / b_up: the polyphase operands svcmi_conv_gemm_f32 would take ([u*cp][ldw_up], rows outside
+ * the tensor read as zero); src: [batch][src_len]; y: [batch][t_in*u][cp].  x == NULL selects the noise-only mode: y already
+ * holds ups[i](x) and only the second line is added (20-channel stage: its transposed convolution is faster on the
+ * matrix cores).  Supported: u == 2, cp in {12, 20}, c_in % 4 == 0
+ * (svcmi_upsample_noise_supported); other shapes use two svcmi_conv_gemm_f32 launches. */
+int svcmi_upsample_noise_supported(int32_t u, int32_t cp, int32_t c_in);
+int svcmi_upsample_noise_f32(const float* x, const float* w_up, const float* b_up, const float* src, const float* w_nz,
+                             const float* b_nz, float* y, int32_t batch, int32_t t_in, int32_t c_in, int32_t ldw_up,
+                             int32_t taps, int32_t pad, int32_t u, int32_t cp, int64_t src_len, int32_t nz_k,
+                             int32_t nz_stride, int32_t nz_pad, int32_t ldw_nz, void* stream);
 
 /* Development knob for the tuning scripts: "amp_tt" in {0 (default), 1, 2, 4} = time steps per thread of
  * svcmi_snake_conv_f32.  Results never depend on it.  Returns 0, or SVCMI_EINVAL for an unknown name/value. */

@@ -202,6 +202,42 @@ def check_snake(ops, n, c, device):
     _close(got, want, 1e-5, f"snake n={n} c={c}")
 
 
+UPNOISE_CASES = [
+    dict(id="stage4_20to10", cin=20, cout=10, k=4, u=2, p=1, nz_k=1, nz_s=1, nz_p=0, T=37, B=2),
+    dict(id="stage3_40to20", cin=40, cout=20, k=4, u=2, p=1, nz_k=4, nz_s=2, nz_p=1, T=50, B=1),
+]
+
+
+def check_upsample_noise(ops, c_, device):
+    """ups[i] (ConvTranspose1d) + noise_convs[i] (strided Conv1d on the source) in one launch vs torch."""
+    g = _g(hash(c_["id"]) % 10000)
+    cin, cout, k, u, pp, T, B = c_["cin"], c_["cout"], c_["k"], c_["u"], c_["p"], c_["T"], c_["B"]
+    cp = (cout + 3) // 4 * 4
+    x = torch.randn(B, T, cin, generator=g)
+    w = torch.randn(cin, cout, k, generator=g) / math.sqrt(cin * k / u)
+    bias = torch.randn(cout, generator=g)
+    L = T * u * c_["nz_s"]
+    src = torch.randn(B, L, generator=g)
+    nw = torch.randn(cout, 1, c_["nz_k"], generator=g)
+    nb = torch.randn(cout, generator=g)
+    ref = F.conv_transpose1d(x.transpose(1, 2), w, bias, stride=u, padding=pp)
+    ref = ref + F.conv1d(src[:, None, :], nw, nb, stride=c_["nz_s"], padding=c_["nz_p"])
+    up_w, up_b, taps, upad = PW.pack_conv_transpose(w, bias, u, pp, cin, cp)
+    assert ops.upsample_noise_supported(u, cp, cin)
+    dev = lambda t: t.to(device)
+    y = ops.upsample_noise(dev(x), dev(up_w), dev(up_b), taps, upad, u, cp, dev(src), dev(PW.pack_conv(nw, n_pad=cp)),
+                           dev(PW.pad_vec(nb, cp)), c_["nz_k"], c_["nz_s"], c_["nz_p"])
+    assert tuple(y.shape) == (B, T * u, cp)
+    _close(y[..., :cout], ref.transpose(1, 2), 2e-5, c_["id"])
+    if cp > cout:
+        assert float(y[..., cout:].abs().max()) == 0.0
+    # noise-only mode on top of a GEMM-computed ups[i](x)
+    y0 = ops.conv(dev(x), dev(up_w), dev(up_b), ksize=taps, pad=upad, t_out=T).view(B, T * u, cp)
+    y2 = ops.upsample_noise(None, None, None, taps, upad, u, cp, dev(src), dev(PW.pack_conv(nw, n_pad=cp)),
+                            dev(PW.pad_vec(nb, cp)), c_["nz_k"], c_["nz_s"], c_["nz_p"], y=y0)
+    _close(y2[..., :cout], ref.transpose(1, 2), 2e-5, c_["id"] + " noise-only")
+
+
 SNAKE_CONV_CASES = [
     dict(id="c10_k3_d1_short", B=2, n=37, c=10, ld=12, k=3, d=1),
     dict(id="c10_k11_d5_res_acc", B=1, n=1100, c=10, ld=12, k=11, d=5, res=True, alpha=1.0 / 3.0, accumulate=True),

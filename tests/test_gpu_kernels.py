@@ -53,6 +53,11 @@ def test_splitk_layernorm(ops, S, c):
     K.check_splitk_layernorm(ops, "cuda", S=S, c=c)
 
 
+@pytest.mark.parametrize("case", K.UPNOISE_CASES, ids=lambda c: c["id"])
+def test_upsample_noise_fused(ops, case):
+    K.check_upsample_noise(ops, case, device="cuda")
+
+
 def test_flow_glue(ops):
     K.check_flow_glue(ops, device="cuda")
 

@@ -206,6 +206,71 @@ __global__ __launch_bounds__(TPB) void snake_conv_kernel(AmpArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Stage entry of the two narrowest generator stages in one launch: polyphase transposed convolution of x plus the strided
+// "noise" convolution of the harmonic source (vits_decoder/generator.py:183-186: `x = ups[i](x); x = x + noise_convs[i](src)`).
+// As two padded implicit-GEMM launches these cost 84 + 105 us (10 channels) and 41 + 63 us (20 channels) for < 0.2 GFLOP:
+// the work is a 28 MB stream.  Here a thread owns one input frame q and produces its u output rows (N = u*cp contiguous
+// floats) with weights as SGPR operands.
+struct UpArgs {
+    const float* x; const float* wu; const float* bu; const float* src; const float* wn; const float* bn; float* y;
+    int t_in, cin, ldwu, taps, pad, u, cp, nz_k, nz_stride, nz_pad, ldwn;
+    long long src_len;
+};
+
+template <int N>
+__global__ __launch_bounds__(TPB) void upsample_noise_kernel(UpArgs p) {
+    const int b = blockIdx.y;
+    const int q = blockIdx.x * TPB + threadIdx.x;
+    if (q >= p.t_in) return;
+    const float* xb = p.x + (long long)b * p.t_in * p.cin;
+    float acc[N];
+    float* yr = p.y + ((long long)b * p.t_in + q) * N;      // rows 2q, 2q+1 of [t_in*2][cp] are contiguous
+    if (!p.x) {             // noise-only mode: y already holds ups[i](x) (wider inputs go through the MFMA GEMM)
+#pragma unroll
+        for (int n = 0; n < N; n += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(yr + n);
+            acc[n] = v.x; acc[n + 1] = v.y; acc[n + 2] = v.z; acc[n + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int n = 0; n < N; ++n) acc[n] = p.bu[n];
+    }
+    for (int k = 0; p.x && k < p.taps; ++k) {
+        const int row = q + k - p.pad;
+        if (row < 0 || row >= p.t_in) continue;
+        const float* xr = xb + (long long)row * p.cin;
+        const float* wk = p.wu + k * p.cin;
+        for (int c4 = 0; c4 < p.cin; c4 += 4) {
+            const float4 xv = *reinterpret_cast<const float4*>(xr + c4);
+#pragma unroll
+            for (int n = 0; n < N; ++n) {
+                const float4 wv = *reinterpret_cast<const float4*>(wk + (long long)n * p.ldwu + c4);   // uniform: scalar load
+                acc[n] = fmaf(wv.x, xv.x, acc[n]);
+                acc[n] = fmaf(wv.y, xv.y, acc[n]);
+                acc[n] = fmaf(wv.z, xv.z, acc[n]);
+                acc[n] = fmaf(wv.w, xv.w, acc[n]);
+            }
+        }
+    }
+    const float* sb = p.src + (long long)b * p.src_len;
+    const int cp = N / 2;                                   // u == 2 in both instantiations
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const long long t = 2LL * q + r;
+        for (int k = 0; k < p.nz_k; ++k) {
+            const long long si = t * p.nz_stride - p.nz_pad + k;
+            const float sv = (si >= 0 && si < p.src_len) ? sb[si] : 0.f;
+#pragma unroll
+            for (int co = 0; co < cp; ++co) acc[r * cp + co] = fmaf(p.wn[co * p.ldwn + k], sv, acc[r * cp + co]);
+        }
+#pragma unroll
+        for (int co = 0; co < cp; ++co) acc[r * cp + co] += p.bn[co];
+    }
+#pragma unroll
+    for (int n = 0; n < N; n += 4) *reinterpret_cast<float4*>(yr + n) = make_float4(acc[n], acc[n + 1], acc[n + 2], acc[n + 3]);
+}
+
 template <int CP, int CR, int G, int TT>
 int launch_amp(const AmpArgs& a, int batch, int ksize, void* stream) {
     constexpr int TB = (4 / G) * 64 * TT;
@@ -251,6 +316,30 @@ extern "C" int svcmi_snake_conv_f32(const float* x, const float* w, const float*
     if (c == 10) return tt == 1 ? launch_amp<12, 10, 1, 1>(a, batch, ksize, stream) : tt == 2 ? launch_amp<12, 10, 1, 2>(a, batch, ksize, stream) : launch_amp<12, 10, 1, 4>(a, batch, ksize, stream);
     if (c == 20) return tt == 1 ? launch_amp<20, 20, 2, 1>(a, batch, ksize, stream) : tt == 2 ? launch_amp<20, 20, 2, 2>(a, batch, ksize, stream) : launch_amp<20, 20, 2, 4>(a, batch, ksize, stream);
     return tt == 1 ? launch_amp<40, 40, 4, 1>(a, batch, ksize, stream) : tt == 2 ? launch_amp<40, 40, 4, 2>(a, batch, ksize, stream) : launch_amp<40, 40, 4, 4>(a, batch, ksize, stream);
+}
+
+extern "C" int svcmi_upsample_noise_supported(int32_t u, int32_t cp, int32_t cin) {
+    return u == 2 && (cp == 12 || cp == 20) && cin % 4 == 0 && cin > 0;
+}
+
+extern "C" int svcmi_upsample_noise_f32(const float* x, const float* w_up, const float* b_up, const float* src, const float* w_nz,
+                                        const float* b_nz, float* y, int32_t batch, int32_t t_in, int32_t c_in, int32_t ldw_up,
+                                        int32_t taps, int32_t pad, int32_t u, int32_t cp, int64_t src_len, int32_t nz_k,
+                                        int32_t nz_stride, int32_t nz_pad, int32_t ldw_nz, void* stream) {
+    if (!src || !w_nz || !b_nz || !y || batch <= 0 || t_in <= 0 || nz_k <= 0) return SVCMI_EINVAL;
+    if (x && (!w_up || !b_up || taps <= 0)) return SVCMI_EINVAL;
+    if (!svcmi_upsample_noise_supported(u, cp, c_in)) return SVCMI_EUNSUPPORTED;
+    if ((x && (ldw_up < taps * c_in || ldw_up % 4)) || ldw_nz < nz_k) return SVCMI_EINVAL;
+    if (((uintptr_t)x & 15) || ((uintptr_t)w_up & 15) || ((uintptr_t)y & 15)) return SVCMI_EALIGN;
+    if (batch > 65535) return SVCMI_EUNSUPPORTED;
+    UpArgs a;
+    a.x = x; a.wu = w_up; a.bu = b_up; a.src = src; a.wn = w_nz; a.bn = b_nz; a.y = y;
+    a.t_in = t_in; a.cin = c_in; a.ldwu = ldw_up; a.taps = taps; a.pad = pad; a.u = u; a.cp = cp;
+    a.nz_k = nz_k; a.nz_stride = nz_stride; a.nz_pad = nz_pad; a.ldwn = ldw_nz; a.src_len = src_len;
+    dim3 grid((unsigned)((t_in + TPB - 1) / TPB), (unsigned)batch);
+    if (cp == 12) SVCMI_LAUNCH((upsample_noise_kernel<24>), grid, dim3(TPB), 0, stream, a);
+    else SVCMI_LAUNCH((upsample_noise_kernel<40>), grid, dim3(TPB), 0, stream, a);
+    return SVCMI_LAST_ERROR();
 }
 
 // Development knob (scripts/microbench.py): returns 0 if the name is known.

@@ -8,7 +8,7 @@ DEFAULT_LIB = os.path.join(HERE, "libsvcmi.so")
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_MISH, ACT_TANH = 0, 1, 2, 3, 4
 CONV_ACCUMULATE, CONV_MASK_IN, CONV_MASK_OUT, CONV_PARTIALS = 1, 2, 4, 8
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class ConvDesc(Structure):
@@ -36,6 +36,8 @@ SIGNATURES = {
     "svcmi_snake_conv_supported": (c_int, [_I, _I, _I, _I]),
     "svcmi_snake_conv_preferred": (c_int, [_I, _I, _I, _I]),
     "svcmi_snake_conv_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
+    "svcmi_upsample_noise_supported": (c_int, [_I, _I, _I]),
+    "svcmi_upsample_noise_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _L, _I, _I, _I, _I, _P]),
     "svcmi_tune_set": (c_int, [c_char_p, _I]),
     "svcmi_wn_gate_f32": (c_int, [_P, _P, _L, _I, _I, _I, _P]),
     "svcmi_wn_update_f32": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

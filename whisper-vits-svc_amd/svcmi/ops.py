@@ -160,6 +160,24 @@ class Ops:
                    B, L, Cc, x.stride(1), self._stream(), work={"bytes": 8.0 * B * L * Cc})
         return out
 
+    def upsample_noise_supported(self, u, cp, cin):
+        return bool(self.lib.svcmi_upsample_noise_supported(u, cp, cin))
+
+    def upsample_noise(self, x, up_w, up_b, taps, pad, u, cp, src, nz_w, nz_b, nz_k, nz_stride, nz_pad, y=None):
+        """ups[i](x) + noise_convs[i](src) for the narrow stages: x [B, t_in, cin], src [B, L] -> [B, t_in*u, cp].
+        With ``y`` given (= ups[i](x) already computed, [B, t_in*u, cp]) only the noise convolution is added."""
+        self._chk(x, up_w, up_b, src, nz_w, nz_b, y)
+        noise_only = y is not None
+        if noise_only:
+            B, t_in, cin = y.shape[0], y.shape[1] // u, 4
+        else:
+            B, t_in, cin = x.shape
+            y = torch.empty(B, t_in * u, cp, dtype=torch.float32, device=x.device)
+        self._call("svcmi_upsample_noise_f32", 0 if noise_only else _ptr(x), _ptr(up_w), _ptr(up_b), _ptr(src), _ptr(nz_w),
+                   _ptr(nz_b), _ptr(y), B, t_in, cin, up_w.shape[1] if up_w is not None else 0, taps, pad, u, cp, src.shape[1],
+                   nz_k, nz_stride, nz_pad, nz_w.shape[1], self._stream(), work={"bytes": 4.0 * B * t_in * (cin + u * cp)})
+        return y
+
     def snake_conv_supported(self, c, ld, ksize, dilation):
         return bool(self.lib.svcmi_snake_conv_supported(c, ld, ksize, dilation))
 
