@@ -38,11 +38,17 @@ enum svcmi_conv_flags {
     SVCMI_CONV_MASK_OUT = 4,   /* output rows >= lengths[b] written as zero  (... * x_mask)   */
     SVCMI_CONV_PARTIALS = 8,   /* write exactly split_k raw partial slabs [batch][split_k][t_out][n_out] to `workspace` and stop:   */
                                /* no reduction, no epilogue, y untouched (consumer: svcmi_splitk_layernorm_f32)                     */
-    /* tuning knob (bits 8-9): force the block tile (time x channels); 0 = library heuristic        */
+    /* tuning knob (bits 8-11): force the block tile (time x channels); 0 = library heuristic       */
     SVCMI_CONV_TILE_64x64 = 0x100,
     SVCMI_CONV_TILE_128x64 = 0x200,
     SVCMI_CONV_TILE_128x128 = 0x300,
-    SVCMI_CONV_TILE_MASK = 0x300
+    /* 16x16x4-MFMA tiles whose N spans the whole (narrow) output: n_out <= 48 / 80 / 160, c_in % 4 == 0 */
+    SVCMI_CONV_TILE_P16_64x48 = 0x400,
+    SVCMI_CONV_TILE_P16_128x48 = 0x500,
+    SVCMI_CONV_TILE_P16_64x80 = 0x600,
+    SVCMI_CONV_TILE_P16_128x80 = 0x700,
+    SVCMI_CONV_TILE_P16_64x160 = 0x800,
+    SVCMI_CONV_TILE_MASK = 0xF00
 };
 
 int svcmi_abi_version(void);

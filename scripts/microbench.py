@@ -75,6 +75,10 @@ def main():
         gemm(ops, "encp_pre", 1000, 1280, 192, k=5, tiles=(0,), splits=(1, 0, 4, 8))
         gemm(ops, "dec_pre", 1000, 192, 320, k=7, tiles=(0,), splits=sp)
         gemm(ops, "up0", 1000, 320, 800, k=3, tiles=(0,), splits=sp)
+    if "p16" in what:         # 64-multiple tiles vs right-sized 16x16x4 tiles for the generator's mid stages
+        for (C, n, tl) in ((160, 5000, (0, 1, 8)), (80, 20000, (1, 6, 7)), (40, 80000, (1, 4, 5))):
+            for k, d in ((3, 1), (7, 3), (11, 5), (11, 1)):
+                gemm(ops, f"amp_C{C}", n, C, C, k=k, dil=d, res=True, tiles=tl, splits=(0,))
     if "dec" in what:
         for (C, n) in ((160, 5000), (80, 20000), (40, 80000), (20, 160000), (10, 320000)):
             for k, d in ((3, 1), (7, 3), (11, 5), (11, 1)):

@@ -141,6 +141,7 @@ static inline int svcmi_ticket(int* counter) { return (*counter)++; }   // block
 static inline void svcmi_lds_read16(svcmi_f32x4& dst, const float* p, svcmi_f32x4&) { memcpy(&dst, p, 16); }
 static inline void svcmi_lds_arrive(svcmi_f32x4&) {}
 static inline void svcmi_pin(svcmi_f32x16&) {}
+static inline void svcmi_pin(svcmi_f32x4&) {}
 // LDS-DMA emulation (buffer form): lane l copies its 16 (4) bytes from rsrc.base + voff to lds_wave_base + 16*l
 // (4*l); an out-of-range lane writes zeros, like the hardware.  Synchronous here.  `lds_wave_base` is the LDS
 // "address" svcmi_lds_addr() returned -- in the emulator simply the pointer.

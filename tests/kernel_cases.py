@@ -46,6 +46,12 @@ CONV_CASES_SMALL = [
     dict(id="vec_cin20_k11_d5", B=1, T=90, cin=20, n=20, k=11, dil=5, pad=25, res=True),
     dict(id="tile_128x64", B=1, T=150, cin=16, n=70, k=3, pad=1, tile=2),
     dict(id="tile_128x128", B=1, T=150, cin=16, n=140, k=1, tile=3),
+    # 16x16x4 policy (tiles 4..8; auto-selected for 65 <= n_out <= 80 and t_out >= 1024)
+    dict(id="p16_n40_vec_k11_d5_res", B=1, T=300, cin=40, n=40, k=11, dil=5, pad=25, res=True, tile=5),
+    dict(id="p16_n80_vec_k3_acc_auto", B=2, T=1030, cin=80, n=80, k=3, pad=1, res=True, alpha=1.0 / 3.0, accumulate=True),
+    dict(id="p16_n160_chunk_k7_d3_splitk", B=1, T=200, cin=160, n=160, k=7, dil=3, pad=9, res=True, split_k=2, tile=8),
+    dict(id="p16_n38_ragged_masks", B=2, T=150, cin=16, n=38, k=5, pad=2, lengths=[150, 111], mask_in=True, mask_out=True, tile=4),
+    dict(id="p16_n70_128x80", B=1, T=200, cin=32, n=70, k=3, pad=1, act=ACT_GELU, tile=7),
 ]
 CONV_CASES_LARGE = [
     dict(id="whisper_qkv", B=1, T=500, cin=1280, n=3840, k=1),

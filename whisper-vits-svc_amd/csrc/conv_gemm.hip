@@ -93,23 +93,29 @@ __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 
 constexpr unsigned OOB = 0x40000000u;   // added to an offset that must read as zero; buffers are < 2^29 bytes
 
-template <int WM, int WN, int MODE>
+// Two micro-kernel policies share everything but the fragment / MFMA / accumulator code:
+//   P16 = false: waves 2 x 2, wave tile (32*WM) x (32*WN), v_mfma_f32_32x32x2_f32   -> block (64*WM) x (64*WN);
+//   P16 = true : waves 4 x 1, wave tile (16*WM) x (16*WN), v_mfma_f32_16x16x4_f32   -> block (64*WM) x (16*WN):
+//                right-sized N for the 40 / 80 / 160-channel generator stages (a 64-multiple pads them by 60 / 60 / 20 %),
+//                and since fp32 MFMA time is proportional to the padded tile, that padding is pure loss.
+template <int WM, int WN, int MODE, bool P16>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
-    constexpr int BM = 64 * WM, BN = 64 * WN;
-    constexpr int A_PER = BM / 32, B_PER = BN / 32;   // 1-KiB LDS-DMA pieces (8 rows x 32 k) per wave per K-step
+    constexpr int BM = 64 * WM, BN = P16 ? 16 * WN : 64 * WN;
+    constexpr int BNL = (BN + 31) / 32 * 32;          // B rows held in LDS (whole 8-row x 4-wave DMA rounds)
+    constexpr int A_PER = BM / 32, B_PER = BNL / 32;  // 1-KiB LDS-DMA pieces (8 rows x 32 k) per wave per K-step
     constexpr int CLD = BN;                           // epilogue staging tile [BM][BN] reuses the operand buffers
     // LDS ring of NST operand tiles (48 / 72 / 64 KiB per block): tile it+NST-1 is in flight while tile
     // `it` is consumed, so a K-step never waits a full HBM/L2 round trip -- what short K ranges (split-K slices,
     // the k=1 projections of the prior encoder / flow, k=3 convolutions) would otherwise pay on every step.
-    constexpr int NST = (WM * WN == 1) ? 3 : (WM * WN == 2 ? 3 : 2);
-    static_assert(BM * CLD <= NST * (BM + BN) * BK, "C tile must fit in the operand buffers");
-    __shared__ __attribute__((aligned(16))) float smem[NST * (BM + BN) * BK + 4];   // + the split-K ticket word
+    constexpr int NST = P16 ? ((BM + BNL) > 192 ? 2 : 3) : ((WM * WN == 1) ? 3 : (WM * WN == 2 ? 3 : 2));
+    static_assert(BM * CLD <= NST * (BM + BNL) * BK, "C tile must fit in the operand buffers");
+    __shared__ __attribute__((aligned(16))) float smem[NST * (BM + BNL) * BK + 4];   // + the split-K ticket word
     float* const As0 = smem;                          // As[slot] = As0 + slot*BM*BK, rows of 32 floats, chunk-swizzled
     float* const Bs0 = smem + NST * BM * BK;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = SVCMI_UNIFORM((int)(tid >> 6));
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = P16 ? wave : (wave >> 1), wn = P16 ? 0 : (wave & 1);
     // XCD-aware bijective enumeration: XCD g owns a contiguous range of the (z, n-tile, m-tile) order, m fastest
     int bx, by, bz;
     {
@@ -164,14 +170,17 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
     }
     const svcmi_ldsaddr lds_a = svcmi_lds_advance(svcmi_lds_addr(As0), wave * 8 * BK);
     const svcmi_ldsaddr lds_b = svcmi_lds_advance(svcmi_lds_addr(Bs0), wave * 8 * BK);
+    static_assert(!P16 || (MODE == MODE_CHUNK || MODE == MODE_VEC), "16x16x4 policy: vector gathers only");
 
-    svcmi_f32x16 acc[WM][WN];
+    using acc_t = typename std::conditional<P16, svcmi_f32x4, svcmi_f32x16>::type;
+    constexpr int ACC_N = P16 ? 4 : 16;
+    acc_t acc[WM][WN];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int j = 0; j < WN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < ACC_N; ++r) acc[i][j][r] = 0.f;
 
     // Per-K-step source offsets of tile `it`, then the DMA pieces (none lands in registers, none is waited for here).
     unsigned a_koff = 0, b_koff = 0;     // K part of this lane's byte offset (or OOB), valid between prep and issue
@@ -213,19 +222,26 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
         }
     };
     auto stage_b = [&](int buf, int i) {
-        svcmi_bdma16(b_row[i] + b_koff, svcmi_lds_advance(lds_b, buf * BN * BK + 4 * i * 8 * BK), wr);
+        svcmi_bdma16(b_row[i] + b_koff, svcmi_lds_advance(lds_b, buf * BNL * BK + 4 * i * 8 * BK), wr);
     };
 
-    // fragment addresses: row (lane&31) of the wave tile, logical chunk 2s + (lane>>5) -> position ^ (row&7)
-    const int frow = lane & 31, fhi = lane >> 5;
-    const int a_off = (wm * 32 * WM + frow) * BK, b_off = (wn * 32 * WN + frow) * BK;
+    // fragment addresses.  32x32x2: row (lane&31) of the wave tile, logical chunk 2s + (lane>>5), 4 sub-steps of 8 k;
+    // 16x16x4: row (lane&15), chunk 4s + (lane>>4), 2 sub-steps of 16 k (MFMA #c contracts k = 16s + c + {0,4,8,12}).
+    // Either way the chunk sits at position chunk ^ swz(row), and both access patterns are bank-conflict free.
+    constexpr int FR = P16 ? 16 : 32;                  // rows per MFMA tile
+    const int frow = lane & (FR - 1), fhi = P16 ? (lane >> 4) : (lane >> 5);
+    const int a_off = (wm * FR * WM + frow) * BK, b_off = (wn * FR * WN + frow) * BK;
     // Fragment reads of sub-step s into (a4, b4).  `tie` is a register the MFMAs issued next consume.
     auto load_frags = [&](const float* Ab, const float* Bb, int s, svcmi_f32x4 (&a4)[WM], svcmi_f32x4 (&b4)[WN], svcmi_f32x4& tie) {
-        const int pos = (((2 * s + fhi) ^ swz(frow)) << 2);
+        const int pos = ((((P16 ? 4 : 2) * s + fhi) ^ swz(frow)) << 2);
 #pragma unroll
-        for (int i = 0; i < WM; ++i) svcmi_lds_read16(a4[i], Ab + i * 32 * BK + pos, tie);
+        for (int i = 0; i < WM; ++i) svcmi_lds_read16(a4[i], Ab + i * FR * BK + pos, tie);
 #pragma unroll
-        for (int j = 0; j < WN; ++j) svcmi_lds_read16(b4[j], Bb + j * 32 * BK + pos, tie);
+        for (int j = 0; j < WN; ++j) svcmi_lds_read16(b4[j], Bb + j * FR * BK + pos, tie);
+    };
+    auto mma = [&](acc_t& c, float a, float b) {
+        if constexpr (P16) c = svcmi_mfma_16x16x4(a, b, c);
+        else c = svcmi_mfma_32x32x2(a, b, c);
     };
     auto frags_arrive = [&](svcmi_f32x4 (&a4)[WM], svcmi_f32x4 (&b4)[WN]) {
 #pragma unroll
@@ -234,7 +250,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
         for (int j = 0; j < WN; ++j) svcmi_lds_arrive(b4[j]);
     };
 
-    constexpr int NSUB = BK / 8;                          // 4 sub-steps of 8 k per tile
+    constexpr int NSUB = P16 ? BK / 16 : BK / 8;          // sub-steps per tile: 4 x 8 k (32x32x2) or 2 x 16 k (16x16x4)
     constexpr int PIECES = A_PER + B_PER;                 // pieces per tile per wave ...
     constexpr int DMAS = (MODE == MODE_SCALAR ? 4 * A_PER : A_PER) + B_PER;   // ... and the DMA instructions they take
     // prologue: tiles it_beg .. it_beg+NST-2 into slots 0 .. NST-2
@@ -262,7 +278,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
         if (nslot >= NST) nslot -= NST;
         if (ISSUE) stage_prep(it + NST - 1);
         const float* Ab = As0 + slot * BM * BK + a_off;
-        const float* Bb = Bs0 + slot * BN * BK + b_off;
+        const float* Bb = Bs0 + slot * BNL * BK + b_off;
         svcmi_f32x4 a4[2][WM], b4[2][WN];
         svcmi_f32x4 tie0 = {0.f, 0.f, 0.f, 0.f};
         load_frags(Ab, Bb, 0, a4[0], b4[0], tie0);
@@ -283,19 +299,19 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int j = 0; j < WN; ++j) acc[i][j] = svcmi_mfma_32x32x2(af[i][0], bf[j][0], acc[i][j]);
+                for (int j = 0; j < WN; ++j) mma(acc[i][j], af[i][0], bf[j][0]);
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int j = 0; j < WN; ++j) acc[i][j] = svcmi_mfma_32x32x2(af[i][1], bf[j][1], acc[i][j]);
+                for (int j = 0; j < WN; ++j) mma(acc[i][j], af[i][1], bf[j][1]);
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int j = 0; j < WN; ++j) acc[i][j] = svcmi_mfma_32x32x2(af[i][2], bf[j][2], acc[i][j]);
+                for (int j = 0; j < WN; ++j) mma(acc[i][j], af[i][2], bf[j][2]);
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int j = 0; j < WN; ++j) acc[i][j] = svcmi_mfma_32x32x2(af[i][3], bf[j][3], acc[i][j]);
+                for (int j = 0; j < WN; ++j) mma(acc[i][j], af[i][3], bf[j][3]);
             // ... and waited for after them (the pins keep this sub-step's MFMAs above the wait)
             if (s + 1 < NSUB) {
 #pragma unroll
@@ -330,9 +346,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
 #pragma unroll
         for (int j = 0; j < WN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ml = wm * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int nl = wn * 32 * WN + j * 32 + (lane & 31);
+            for (int r = 0; r < ACC_N; ++r) {
+                // D layouts: 32x32 -> col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5);  16x16 -> col = lane&15, row = 4*(lane>>4) + r
+                const int ml = P16 ? (wm * 16 * WM + i * 16 + 4 * (lane >> 4) + r)
+                                   : (wm * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
+                const int nl = P16 ? (j * 16 + (lane & 15)) : (wn * 32 * WN + j * 32 + (lane & 31));
                 Cs[ml * CLD + nl] = acc[i][j][r];
             }
     __syncthreads();
@@ -420,19 +438,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs p, int batc
     }
 }
 
-template <int WM, int WN>
+template <int WM, int WN, bool P16>
 int launch(const ConvArgs& a_in, int batch, int mode, void* stream) {
-    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int BM = 64 * WM, BN = P16 ? 16 * WN : 64 * WN;
     ConvArgs a = a_in;
     a.mt = (a.t_out + BM - 1) / BM;
     a.nt = (a.n_out + BN - 1) / BN;
     const long long blocks = (long long)a.mt * a.nt * batch * a.split;
     if (blocks > 0x7fffffffLL) return SVCMI_EUNSUPPORTED;
     dim3 grid((unsigned)blocks);
-    if (mode == MODE_CHUNK) SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_CHUNK>), grid, dim3(256), 0, stream, a);
-    else if (mode == MODE_CHUNK_RS) SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_CHUNK_RS>), grid, dim3(256), 0, stream, a);
-    else if (mode == MODE_VEC) SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_VEC>), grid, dim3(256), 0, stream, a);
-    else SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_SCALAR>), grid, dim3(256), 0, stream, a);
+    if (mode == MODE_CHUNK) SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_CHUNK, P16>), grid, dim3(256), 0, stream, a);
+    else if (mode == MODE_VEC) SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_VEC, P16>), grid, dim3(256), 0, stream, a);
+    else if constexpr (!P16) {
+        if (mode == MODE_CHUNK_RS) SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_CHUNK_RS, false>), grid, dim3(256), 0, stream, a);
+        else SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_SCALAR, false>), grid, dim3(256), 0, stream, a);
+    } else {
+        return SVCMI_EUNSUPPORTED;
+    }
     int rc = SVCMI_LAST_ERROR();
     if (rc == 0 && a.split > 1 && !a.cnt && !(a.flags & SVCMI_CONV_PARTIALS)) {
         const long long total = (long long)batch * a.t_out * a.n_out;
@@ -479,8 +501,26 @@ extern "C" int svcmi_conv_gemm_f32(const svcmi_conv_desc* d, void* stream) {
 
     // Tile: fill the 256 CUs first, then grow the tile for operand reuse (or honour the override).
     const long long mt64 = (d->t_out + 63) / 64, nt64 = (d->n_out + 63) / 64;
-    const long long blocks64 = mt64 * nt64 * d->batch;
+    long long blocks64 = mt64 * nt64 * d->batch;
     int tile = (d->flags & SVCMI_CONV_TILE_MASK);
+    // narrow outputs (the 40 / 80 / 160-channel generator stages): the 16x16x4 policy with N right-sized to 48 / 80 / 160
+    int p16_nt = 0, p16_wm = 1;
+    const int n16 = (d->n_out + 15) / 16;
+    const bool p16_ok = mode == MODE_CHUNK || mode == MODE_VEC;
+    if (tile >= SVCMI_CONV_TILE_P16_64x48) {                       // explicit override (tuning / tests)
+        if (!p16_ok) return SVCMI_EUNSUPPORTED;
+        p16_nt = tile == SVCMI_CONV_TILE_P16_64x160 ? 10 : (tile >= SVCMI_CONV_TILE_P16_64x80 ? 5 : 3);
+        p16_wm = (tile == SVCMI_CONV_TILE_P16_128x48 || tile == SVCMI_CONV_TILE_P16_128x80) ? 2 : 1;
+        if (n16 > p16_nt) return SVCMI_EUNSUPPORTED;               // these tiles span the whole N
+    } else if (!tile && p16_ok && (n16 == 3 || n16 == 5) && d->t_out >= 1024) {
+        // measured on MI355X (scripts/microbench.py p16): 64x80 beats 2 x (64x64) by 18 % at 80 channels, 64x48 beats 64x64
+        // by 13 % at 40; the 128-row variants lose (half the blocks), and at 160 channels / 5000 rows 64x160 only ties
+        p16_nt = n16;
+    }
+    if (p16_nt) {
+        blocks64 = (long long)((d->t_out + 64 * p16_wm - 1) / (64 * p16_wm)) * d->batch;
+        tile = SVCMI_CONV_TILE_64x64;       // (only steers the split-K branch below)
+    }
     if (!tile) {
         if (d->n_out > 64 && blocks64 >= 4 * 1024 && d->t_out >= 128) tile = SVCMI_CONV_TILE_128x128;
         else if (blocks64 >= 2 * 1024 && d->t_out >= 128) tile = SVCMI_CONV_TILE_128x64;
@@ -509,14 +549,18 @@ extern "C" int svcmi_conv_gemm_f32(const svcmi_conv_desc* d, void* stream) {
     }
 
     if (a.split > 1 && d->counters && !(d->flags & SVCMI_CONV_PARTIALS)) {       // in-launch combine needs one zeroed counter per output tile
-        const int bm = tile == SVCMI_CONV_TILE_64x64 ? 64 : 128, bn = tile == SVCMI_CONV_TILE_128x128 ? 128 : 64;
+        const int bm = p16_nt ? 64 * p16_wm : (tile == SVCMI_CONV_TILE_64x64 ? 64 : 128);
+        const int bn = p16_nt ? 16 * p16_nt : (tile == SVCMI_CONV_TILE_128x128 ? 128 : 64);
         const long long tiles = (long long)d->batch * ((d->t_out + bm - 1) / bm) * ((d->n_out + bn - 1) / bn);
         if (tiles <= d->counters_len && d->n_out % 4 == 0 && (((uintptr_t)d->workspace & 15) == 0) &&
             (long long)d->t_out * d->n_out < (1LL << 29)) a.cnt = d->counters;      // 16-byte write-through slab stores
     }
+    if (p16_nt == 3) return p16_wm == 2 ? launch<2, 3, true>(a, d->batch, mode, stream) : launch<1, 3, true>(a, d->batch, mode, stream);
+    if (p16_nt == 5) return p16_wm == 2 ? launch<2, 5, true>(a, d->batch, mode, stream) : launch<1, 5, true>(a, d->batch, mode, stream);
+    if (p16_nt == 10) return launch<1, 10, true>(a, d->batch, mode, stream);
     switch (tile) {
-        case SVCMI_CONV_TILE_128x128: return launch<2, 2>(a, d->batch, mode, stream);
-        case SVCMI_CONV_TILE_128x64: return launch<2, 1>(a, d->batch, mode, stream);
-        default: return launch<1, 1>(a, d->batch, mode, stream);
+        case SVCMI_CONV_TILE_128x128: return launch<2, 2, false>(a, d->batch, mode, stream);
+        case SVCMI_CONV_TILE_128x64: return launch<2, 1, false>(a, d->batch, mode, stream);
+        default: return launch<1, 1, false>(a, d->batch, mode, stream);
     }
 }

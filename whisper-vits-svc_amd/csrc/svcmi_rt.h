@@ -89,6 +89,7 @@ __device__ __forceinline__ void svcmi_lds_arrive(svcmi_f32x4& d) { asm volatile(
 
 // Order fence for a register-only value: nothing that produces `v` is scheduled below, nothing that consumes it above.
 __device__ __forceinline__ void svcmi_pin(svcmi_f32x16& v) { asm volatile("" : "+a"(v)); }   // "a": stays in the accumulator file
+__device__ __forceinline__ void svcmi_pin(svcmi_f32x4& v) { asm volatile("" : "+a"(v)); }
 
 // Cross-workgroup hand-off inside one launch (cdna_hip_programming.md Guideline 16): agent-scope release by the
 // producer, a relaxed agent-scope ticket, agent-scope acquire by the consumer.  Workgroup scope is NOT enough.
