@@ -75,6 +75,11 @@ def main():
         gemm(ops, "encp_pre", 1000, 1280, 192, k=5, tiles=(0,), splits=(1, 0, 4, 8))
         gemm(ops, "dec_pre", 1000, 192, 320, k=7, tiles=(0,), splits=sp)
         gemm(ops, "up0", 1000, 320, 800, k=3, tiles=(0,), splits=sp)
+    if "wp16" in what:        # Whisper shapes on the 16x16x4 tiles (128x80 gives exactly 256 blocks for N = 5120)
+        gemm(ops, "whisper_qkv", 500, 1280, 3840, tiles=(1, 6, 7), splits=(1,))
+        gemm(ops, "whisper_o", 500, 1280, 1280, res=True, tiles=(1, 6, 7), splits=(4, 2, 3))
+        gemm(ops, "whisper_mlp1", 500, 1280, 5120, tiles=(1, 6, 7), splits=(1,))
+        gemm(ops, "whisper_mlp2", 500, 5120, 1280, res=True, tiles=(1, 6, 7), splits=(8, 4))
     if "p16" in what:         # 64-multiple tiles vs right-sized 16x16x4 tiles for the generator's mid stages
         for (C, n, tl) in ((160, 5000, (0, 1, 8)), (80, 20000, (1, 6, 7)), (40, 80000, (1, 4, 5))):
             for k, d in ((3, 1), (7, 3), (11, 5), (11, 1)):

@@ -511,7 +511,6 @@ extern "C" int svcmi_conv_gemm_f32(const svcmi_conv_desc* d, void* stream) {
         if (!p16_ok) return SVCMI_EUNSUPPORTED;
         p16_nt = tile == SVCMI_CONV_TILE_P16_64x160 ? 10 : (tile >= SVCMI_CONV_TILE_P16_64x80 ? 5 : 3);
         p16_wm = (tile == SVCMI_CONV_TILE_P16_128x48 || tile == SVCMI_CONV_TILE_P16_128x80) ? 2 : 1;
-        if (n16 > p16_nt) return SVCMI_EUNSUPPORTED;               // these tiles span the whole N
     } else if (!tile && p16_ok && (n16 == 3 || n16 == 5) && d->t_out >= 1024) {
         // measured on MI355X (scripts/microbench.py p16): 64x80 beats 2 x (64x64) by 18 % at 80 channels, 64x48 beats 64x64
         // by 13 % at 40; the 128-row variants lose (half the blocks), and at 160 channels / 5000 rows 64x160 only ties

@@ -19,7 +19,11 @@ class AudioEncoder:
 
     def __init__(self, w, ops):
         self.w, self.ops = w, ops
-        self.split_o, self.split_mlp = 4, 8      # K slices of the two N = state projections (scripts/microbench.py gemm)
+        # Tuning table for the M = 500-row window GEMMs (scripts/microbench.py gemm / wp16, MI355X): K slices of the two
+        # N = n_state projections, and the 64x80 tile of the 16x16x4 policy where it balances the 256 CUs better than
+        # 64x64 (N = 5120 -> 8 x 64 = 512 blocks; N = 1280 with 2-4 K slices); the QKV projection stays on 64x64.
+        self.split_o, self.split_mlp = 2, 4
+        self.tile_o = self.tile_mlp = 6          # SVCMI_CONV_TILE_P16_64x80 >> 8
 
     @torch.no_grad()
     def __call__(self, mel, noise=None, noise_scale=0.1):
@@ -44,10 +48,10 @@ class AudioEncoder:
         for i, blk in enumerate(w.blocks):
             qkv = ops.conv(h, blk["qkv_w"], blk["qkv_b"])
             a = ops.attention(qkv, w.heads, scale)
-            p = ops.conv(a, blk["o_w"], None, partials=True, split_k=max(1, min(self.split_o, blk["o_w"].shape[1] // 128)))
+            p = ops.conv(a, blk["o_w"], None, partials=True, split_k=max(1, min(self.split_o, blk["o_w"].shape[1] // 128)), tile=self.tile_o)
             h = ops.splitk_layernorm(p, blk["o_b"], x, blk["ln2_g"], blk["ln2_b"], out=h)
-            m = ops.conv(h, blk["m1_w"], blk["m1_b"], act=ACT_GELU)
-            p = ops.conv(m, blk["m2_w"], None, partials=True, split_k=max(1, min(self.split_mlp, blk["m2_w"].shape[1] // 128)))
+            m = ops.conv(h, blk["m1_w"], blk["m1_b"], act=ACT_GELU, tile=self.tile_mlp, split_k=1)
+            p = ops.conv(m, blk["m2_w"], None, partials=True, split_k=max(1, min(self.split_mlp, blk["m2_w"].shape[1] // 128)), tile=self.tile_mlp)
             g, b = (w.blocks[i + 1]["ln1_g"], w.blocks[i + 1]["ln1_b"]) if i + 1 < nb else (w.lnp_g, w.lnp_b)
             h = ops.splitk_layernorm(p, blk["m2_b"], x, g, b, out=h)
         return h if nb else ops.layernorm(x, w.lnp_g, w.lnp_b)
