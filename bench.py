@@ -42,7 +42,7 @@ class Workload:
     """Device-resident synthetic inputs + the engine objects for one rank."""
 
     def __init__(self, ops, device, batch, seconds, wsd, vsd, hp, seed):
-        from oracle import inputs as I        # synthetic input recipe only (SURVEY.md 8d config 2)
+        from workload import inputs as I      # synthetic input recipe (SURVEY.md 8d config 2)
         from svcmi import SynthesizerInfer
         from svcmi.whisper.inference import load_model
         self.ops, self.device, self.hp = ops, device, hp
@@ -177,7 +177,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
-    from oracle import config as C, weights as W        # synthetic checkpoint factory + base.yaml values
+    from workload import config as C, weights as W      # synthetic checkpoint factory + base.yaml values
     from svcmi import Ops, dist as D
     import torch.distributed as dist
 

@@ -17,11 +17,11 @@ import types
 import numpy as np
 import torch
 
-from . import config as C
-from . import inputs as I
+from workload import config as C
+from workload import inputs as I
 from . import ref_import as R
 from . import svc_oracle as O
-from . import weights as W
+from workload import weights as W
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 TOL = 5e-5

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from . import config as C
+from workload import config as C
 
 
 # ----------------------------------------------------------------------------- helpers

@@ -5,10 +5,10 @@ import os
 import numpy as np
 import torch
 
-from oracle import config as C
-from oracle import inputs as I
+from workload import config as C
+from workload import inputs as I
 from oracle import svc_oracle as O
-from oracle import weights as W
+from workload import weights as W
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 WAVE_TOL = 1e-3     # north_star: max-abs on the waveform vs the reference CPU path

@@ -10,7 +10,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import svc_oracle as O
-from oracle import weights as W
+from workload import weights as W
 from svcmi import weights as PW
 from svcmi.ops import ACT_GELU, ACT_MISH, ACT_NONE, ACT_RELU, ACT_TANH
 
@@ -357,8 +357,8 @@ def check_bridges(ops, device):
 
 
 def check_pitch2source(ops, T, B, device, hop=320):
-    from oracle import config as C
-    from oracle import inputs as I
+    from workload import config as C
+    from workload import inputs as I
     hp = C.base_hp()
     if hop != 320:
         hp = C.AttrDict({**C.BASE, "gen": {**C.BASE["gen"], "upsample_rates": [hop], "upsample_kernel_sizes": [2 * hop]}})

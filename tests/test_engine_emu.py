@@ -3,7 +3,7 @@ executed on the CPU SIMT emulator at the tiny configuration and compared with th
 the real reference.  Slow-ish (fibers), sized to stay within the CPU test budget."""
 import pytest
 
-from oracle import config as C
+from workload import config as C
 from tests import engine_cases as E
 from tests.emu import emu_ops
 

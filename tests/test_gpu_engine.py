@@ -6,10 +6,10 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import config as C
-from oracle import inputs as I
+from workload import config as C
+from workload import inputs as I
 from oracle import svc_oracle as O
-from oracle import weights as W
+from workload import weights as W
 from tests import engine_cases as E
 
 pytestmark = pytest.mark.gpu

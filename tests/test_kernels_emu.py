@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import svc_oracle as O
-from oracle import weights as W
+from workload import weights as W
 from tests import kernel_cases as K
 from tests.emu import emu_ops
 

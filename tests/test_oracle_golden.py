@@ -6,10 +6,10 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import config as C
-from oracle import inputs as I
+from workload import config as C
+from workload import inputs as I
 from oracle import svc_oracle as O
-from oracle import weights as W
+from workload import weights as W
 from oracle.make_golden import checksum
 
 TOL = 5e-5   # fp32 CPU vs fp32 CPU (different BLAS blocking across hosts); waveform in [-1,1]

@@ -1,4 +1,4 @@
-"""Hyper-parameters of the hot path (test infrastructure, see oracle/__init__.py).
+"""Hyper-parameters of the hot path (workload definition shared by bench, tests and oracle).
 
 The values restate /root/reference/configs/base.yaml:16-47 (data/vits/gen groups) and the
 constants the reference hard-codes in Python instead of YAML ("Config"):

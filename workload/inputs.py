@@ -1,4 +1,4 @@
-"""Seeded synthetic inputs for the benchmark configurations (test infrastructure).
+"""Seeded synthetic inputs for the benchmark configurations (workload definition; no model arithmetic).
 
 SURVEY.md section 8d, config 2: mel ~ clamp-normalised log-mel range, vec ~ N(0,1), integer-Hz F0 with
 ~20 % unvoiced runs, the three stochastic draws of the path supplied explicitly.
@@ -35,7 +35,7 @@ def synth_spk(dim=256, seed=7):
 
 def synth_clip(T=1000, hp=None, seed=0, B=1, ppg=True):
     """All inputs + noise draws for ``B`` clips of ``T`` frames (10 ms each)."""
-    from . import config as C
+    from workload import config as C
     hp = hp or C.base_hp()
     g = torch.Generator().manual_seed(1000 + seed)
     hop = int(np.prod(list(hp.gen.upsample_rates)))

@@ -1,4 +1,4 @@
-"""Seeded synthetic checkpoints with the reference's key names (test infrastructure).
+"""Seeded synthetic checkpoints with the reference's key names (workload definition; no model arithmetic).
 
 No pretrained weights ship with the reference, so parity runs on
 random-but-seeded tensors.  Key names and shapes follow ``SynthesizerInfer.state_dict()``
@@ -15,7 +15,7 @@ import math
 
 import torch
 
-from . import config as C
+from workload import config as C
 
 
 def kaiser_sinc_filter(cutoff=0.25, half_width=0.3, taps=12):
