@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SVCMI_ABI_VERSION 7
+#define SVCMI_ABI_VERSION 8
 
 enum svcmi_status { SVCMI_OK = 0, SVCMI_EINVAL = -1, SVCMI_EUNSUPPORTED = -2, SVCMI_EALIGN = -3 };
 
@@ -115,6 +115,13 @@ int svcmi_conv_gemm_f32(const svcmi_conv_desc* d, void* stream);
 int svcmi_layernorm_f32(const float* x, const float* res, const float* gamma, const float* beta, float* y,
                         int32_t batch, int32_t rows_per_batch, int32_t c, int32_t ldx, int32_t ldr, int32_t ldy,
                         int32_t gb_bstride, float eps, void* stream);
+
+/* Per-channel normalisation over time + GELU: GroupNorm(num_groups = c, c) followed by exact-erf GELU, the first layer of
+ * HuBERT's feature extractor (hubert/hubert_model.py:78,88): y[b,t,ch] = gelu((x[b,t,ch] - mean_t) / sqrt(var_t + eps) *
+ * gamma[ch] + beta[ch]) with mean / biased variance over the t axis of batch item b.  x, y: [batch][t][ld] time-major
+ * (y may alias x); scratch: >= batch * 129 * c doubles.  c % 4 == 0. */
+int svcmi_channel_norm_gelu_f32(const float* x, const float* gamma, const float* beta, float* y, double* scratch,
+                                int32_t batch, int32_t t, int32_t c, int32_t ldx, int32_t ldy, float eps, void* stream);
 
 /* Split-K tail fused with the residual update and the LayerNorm that follows it (whisper/model.py:118-129:
  * `x = x + attn(...)` / `x = x + mlp(...)` then the next `ln(x)`):

@@ -162,6 +162,25 @@ def logmel_fixture(tag, n, seed):
                         filterbank_checksum=checksum([torch.from_numpy(fb)]), audio_checksum=checksum([x]))
 
 
+def hubert_fixture(tag, n, seed):
+    """The reference HubertSoft.units (hubert/hubert_model.py:64-72) at its own dimensions on a seeded waveform."""
+    print(f"[{tag}] n={n}")
+    from . import hubert_oracle as H
+    R._prepare()
+    from hubert.hubert_model import HubertSoft
+    sd = W.make_hubert_state()
+    ref = HubertSoft()
+    ref.load_state_dict(sd, strict=True)
+    ref.eval()
+    g = torch.Generator().manual_seed(seed)
+    wav = torch.randn(1, 1, n, generator=g) * 0.3
+    with torch.no_grad():
+        u = ref.units(wav)
+        o = H.units(sd, wav, 12)
+    _agree("hubert units", o, u)
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), n=n, seed=seed, units=u.numpy(), weights_checksum=checksum(sd))
+
+
 def main():
     assert R.available(), "needs /root/reference"
     os.makedirs(OUT, exist_ok=True)
@@ -172,6 +191,7 @@ def main():
     whisper_fixture("whisper_large_v2_n200", C.WHISPER_LARGE_V2, n=200)
     svc_infer_fixture("svc_infer_tiny_2chunks", C.tiny_hp(), T=2600)
     logmel_fixture("logmel_2p5s", n=40000, seed=21)
+    hubert_fixture("hubert_soft_1s", n=16000, seed=3)
     print("golden fixtures written to", OUT)
 
 

@@ -100,3 +100,33 @@ def check_logmel_golden(ops, device, tol=2e-4):
     # fp32 FFT has the same noise there, so the tolerance is on the log-mel value, not on the power
     assert err <= tol, err
     return err
+
+
+def check_hubert_against_oracle(ops, device, dims, n, heads, tol=TIGHT):
+    """HuBERT-Soft units (svcmi.hubert) vs the oracle on seeded weights of ``dims`` and a seeded waveform."""
+    from oracle import hubert_oracle as H
+    from svcmi.hubert import load_model
+    sd = W.make_hubert_state(dims)
+    m = load_model(sd, device, ops=ops)
+    g = torch.Generator().manual_seed(3)
+    wav = torch.randn(2, 1, n, generator=g) * 0.3
+    got = m.units(wav)
+    with torch.no_grad():
+        want = H.units(sd, wav, heads)
+    assert tuple(got.shape) == tuple(want.shape) == (2, (n + 80 - 400) // 320 + 1, dims["proj"])
+    err = maxerr(got, want)
+    assert err <= tol * max(1.0, float(want.abs().max())), err
+    return err
+
+
+def check_hubert_golden(ops, device, tol=TIGHT):
+    """svcmi.hubert at the reference dimensions vs the reference HubertSoft.units itself (golden fixture)."""
+    from svcmi.hubert import load_model
+    g = golden("hubert_soft_1s")
+    sd = W.make_hubert_state()
+    m = load_model(sd, device, ops=ops)
+    gen = torch.Generator().manual_seed(int(g["seed"]))
+    wav = torch.randn(1, 1, int(g["n"]), generator=gen) * 0.3
+    err = maxerr(m.units(wav), _t(g["units"]))
+    assert err <= tol * max(1.0, float(np.abs(g["units"]).max())), err
+    return err

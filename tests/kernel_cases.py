@@ -118,6 +118,15 @@ def check_layernorm(ops, c, device):
     _close(ops.layernorm(x.to(device), gb.to(device), bb.to(device), per_batch_affine=True), want, 2e-5, "ln per-batch")
 
 
+def check_channel_norm_gelu(ops, device, B=2, T=700, c=32):
+    g = _g(5 + c)
+    x = torch.randn(B, T, c, generator=g) * 2.0 + 0.7
+    gamma, beta = torch.randn(c, generator=g), torch.randn(c, generator=g)
+    want = F.gelu(F.group_norm(x.transpose(1, 2), c, gamma, beta, 1e-5)).transpose(1, 2)
+    got = ops.channel_norm_gelu(x.to(device), gamma.to(device), beta.to(device))
+    _close(got, want, 2e-5, "channel_norm_gelu")
+
+
 def check_splitk_layernorm(ops, device, B=2, S=3, T=7, c=1280):
     """conv(partials=True) slabs -> fused reduce + bias + residual + LayerNorm, vs the unsplit conv + torch layer_norm."""
     g = _g(100 + c + S)

@@ -24,3 +24,7 @@ def test_whisper_tiny_matches_reference_golden(ops):
 
 def test_logmel_frontend_matches_reference_golden(ops):
     print(E.check_logmel_golden(ops, "cpu"))
+
+
+def test_hubert_tiny_matches_oracle(ops):
+    print(E.check_hubert_against_oracle(ops, "cpu", C.HUBERT_TINY_TEST, n=4000, heads=4))

@@ -54,6 +54,19 @@ def test_logmel_15s_window_against_oracle(ops):
     assert E.maxerr(got, ref) <= 2e-4
 
 
+def test_hubert_soft_golden(ops):
+    print(E.check_hubert_golden(ops, "cuda"))
+
+
+def test_hubert_soft_10s_against_oracle(ops):
+    """HuBERT-Soft at the reference dimensions on a 10 s window (T = 500 frames) vs the CPU oracle."""
+    print(E.check_hubert_against_oracle(ops, "cuda", C.HUBERT_SOFT, n=160000, heads=12))
+
+
+def test_hubert_tiny_against_oracle(ops):
+    print(E.check_hubert_against_oracle(ops, "cuda", C.HUBERT_TINY_TEST, n=4000, heads=4))
+
+
 def test_svc_infer_two_chunks_golden(ops):
     print(E.check_svc_infer_golden(ops, "cuda"))
 

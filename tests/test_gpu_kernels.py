@@ -58,6 +58,11 @@ def test_upsample_noise_fused(ops, case):
     K.check_upsample_noise(ops, case, device="cuda")
 
 
+@pytest.mark.parametrize("T,c", [(5, 8), (700, 32)] + ([(64000, 512)] if "cuda" == "cuda" else []))
+def test_channel_norm_gelu(ops, T, c):
+    K.check_channel_norm_gelu(ops, "cuda", T=T, c=c)
+
+
 def test_flow_glue(ops):
     K.check_flow_glue(ops, device="cuda")
 

@@ -136,3 +136,15 @@ def test_slaney_filterbank_properties():
     assert abs(centres[0] - 200.0 / 3.0) < 30.0                                    # first centre = 1 mel step = 66.7 Hz
     # Slaney normalisation: each triangle has unit area in Hz
     assert np.allclose(fb.sum(1) * 40.0, 1.0, atol=0.08)
+
+
+def test_hubert_oracle_matches_reference_golden(golden_dir):
+    from oracle import hubert_oracle as H
+    g = _load(golden_dir, "hubert_soft_1s")
+    sd = W.make_hubert_state()
+    assert abs(checksum(sd) - float(g["weights_checksum"])) <= 1e-6 * abs(float(g["weights_checksum"]))
+    gen = torch.Generator().manual_seed(int(g["seed"]))
+    wav = torch.randn(1, 1, int(g["n"]), generator=gen) * 0.3
+    with torch.no_grad():
+        got = H.units(sd, wav, 12)
+    assert float((got - _t(g["units"])).abs().max()) <= TOL

@@ -71,6 +71,77 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
     }
 }
 
+// ------------------------------------------------------------------------------------ per-channel norm over time
+// GroupNorm(C, C) + GELU of HuBERT's first feature-extractor layer (hubert/hubert_model.py:78,88): every channel is
+// normalised over the whole time axis of its batch item.  On time-major rows that is a column reduction: (1) fp64
+// partial sums per (batch item, time chunk, channel), lanes walking channels so loads stay coalesced; (2) a tiny
+// finalise to mean / rstd; (3) one elementwise pass.  Fixed chunking and summation order: deterministic.
+constexpr int CN_CHUNKS_MAX = 64;
+
+__global__ __launch_bounds__(256) void colstats_kernel(const float* x, double* part, int t, int c, int ldx, int nch) {
+    __shared__ double red[2][4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int ch = blockIdx.x * 64 + cl, chunk = blockIdx.y, b = blockIdx.z;
+    const int per = (t + nch - 1) / nch;
+    const int r0 = chunk * per, r1 = (r0 + per) < t ? (r0 + per) : t;
+    double s = 0.0, ss = 0.0;
+    if (ch < c) {
+        const float* xb = x + (long long)b * t * ldx + ch;
+        for (int r = r0 + rl; r < r1; r += 4) {
+            const double v = (double)xb[(long long)r * ldx];
+            s += v;
+            ss += v * v;
+        }
+    }
+    red[0][rl][cl] = s;
+    red[1][rl][cl] = ss;
+    __syncthreads();
+    if (rl == 0 && ch < c) {
+        double* o = part + (((long long)b * nch + chunk) * c + ch) * 2;
+        o[0] = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+        o[1] = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+    }
+}
+
+__global__ __launch_bounds__(256) void colstats_final_kernel(const double* part, float* stats, int t, int c, int nch, float eps) {
+    const int ch = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (ch >= c) return;
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < nch; ++k) {
+        const double* o = part + (((long long)b * nch + k) * c + ch) * 2;
+        s += o[0];
+        ss += o[1];
+    }
+    const double mean = s / t;
+    double var = ss / t - mean * mean;         // biased, like torch group_norm
+    if (var < 0.0) var = 0.0;
+    stats[((long long)b * c + ch) * 2] = (float)mean;
+    stats[((long long)b * c + ch) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+__global__ __launch_bounds__(256) void channel_norm_gelu_kernel(const float* x, const float* stats, const float* gamma,
+                                                                const float* beta, float* y, int t, int c, int ldx, int ldy) {
+    const int c4 = c >> 2;
+    const long long total = (long long)t * c4;
+    const int b = blockIdx.y;
+    const float* xb = x + (long long)b * t * ldx;
+    float* yb = y + (long long)b * t * ldy;
+    const float* st = stats + (long long)b * c * 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / c4;
+        const int cc = (int)(i - r * c4) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(xb + r * ldx + cc);
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float n = (vv[j] - st[2 * (cc + j)]) * st[2 * (cc + j) + 1] * (gamma ? gamma[cc + j] : 1.f) + (beta ? beta[cc + j] : 0.f);
+            o[j] = 0.5f * n * (1.f + erff(n * 0.70710678118654752440f));
+        }
+        *reinterpret_cast<float4*>(yb + r * ldy + cc) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 // Split-K tail fused with the residual update and the LayerNorm that follows it (Whisper: x += W_o a + b_o; h = LN(x)):
 //   x[r,:] += bias + sum_{s < split} partials[b, s, t, :]   (fixed slice order: deterministic);   y[r,:] = LN(x[r,:])
 // One 256-thread block per row (a 500-row Whisper window would otherwise occupy only 500 waves, each waiting on
@@ -448,6 +519,27 @@ extern "C" int svcmi_layernorm_f32(const float* x, const float* res, const float
     if (rows > 0x7fffffffLL) return SVCMI_EUNSUPPORTED;
     SVCMI_LAUNCH(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, res, gamma, beta, y,
                  (int)rows, rows_per_batch, c, ldx, ldr, ldy, gb_bstride, eps);
+    return SVCMI_LAST_ERROR();
+}
+
+extern "C" int svcmi_channel_norm_gelu_f32(const float* x, const float* gamma, const float* beta, float* y, double* scratch,
+                                           int32_t batch, int32_t t, int32_t c, int32_t ldx, int32_t ldy, float eps, void* stream) {
+    // scratch: >= batch * (2*64 + 1) * c doubles (chunk partials, then mean/rstd as floats behind them)
+    if (!x || !y || !scratch || batch <= 0 || t <= 0 || c <= 0) return SVCMI_EINVAL;
+    if (c % 4 || ldx % 4 || ldy % 4 || ((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return SVCMI_EALIGN;
+    if (batch > 65535) return SVCMI_EUNSUPPORTED;
+    int nch = (t + 255) / 256;
+    if (nch > CN_CHUNKS_MAX) nch = CN_CHUNKS_MAX;
+    float* stats = reinterpret_cast<float*>(scratch + (long long)batch * CN_CHUNKS_MAX * c * 2);
+    SVCMI_LAUNCH(colstats_kernel, dim3((c + 63) / 64, nch, batch), dim3(256), 0, stream, x, scratch, t, c, ldx, nch);
+    int rc = SVCMI_LAST_ERROR();
+    if (rc) return rc;
+    SVCMI_LAUNCH(colstats_final_kernel, dim3((c + 255) / 256, batch), dim3(256), 0, stream, (const double*)scratch, stats, t, c, nch, eps);
+    rc = SVCMI_LAST_ERROR();
+    if (rc) return rc;
+    long long nb = ((long long)t * (c / 4) + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    SVCMI_LAUNCH(channel_norm_gelu_kernel, dim3((unsigned)nb, batch), dim3(256), 0, stream, x, (const float*)stats, gamma, beta, y, t, c, ldx, ldy);
     return SVCMI_LAST_ERROR();
 }
 

@@ -8,7 +8,7 @@ DEFAULT_LIB = os.path.join(HERE, "libsvcmi.so")
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_MISH, ACT_TANH = 0, 1, 2, 3, 4
 CONV_ACCUMULATE, CONV_MASK_IN, CONV_MASK_OUT, CONV_PARTIALS = 1, 2, 4, 8
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class ConvDesc(Structure):
@@ -30,6 +30,7 @@ SIGNATURES = {
     "svcmi_build_info": (c_char_p, []),
     "svcmi_conv_gemm_f32": (c_int, [POINTER(ConvDesc), _P]),
     "svcmi_layernorm_f32": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "svcmi_channel_norm_gelu_f32": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "svcmi_splitk_layernorm_f32": (c_int, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "svcmi_attention_f32": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _I, _I, _I, _I, _F, _P, _P, _I, _P, _P]),
     "svcmi_snake_alias_f32": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -126,6 +126,17 @@ class Ops:
                    (gamma.stride(0) if gamma is not None else beta.stride(0)) if per_batch_affine else 0, eps, self._stream())
         return out
 
+    def channel_norm_gelu(self, x, gamma, beta, eps=1e-5, out=None):
+        """GroupNorm(C, C) over time + GELU on time-major x [B, T, C] (hubert/hubert_model.py:78,88)."""
+        self._chk(x, gamma, beta, out)
+        B, T, Cc = x.shape
+        if out is None:
+            out = torch.empty_like(x)
+        scratch = torch.empty(B * 129 * Cc, dtype=torch.float64, device=x.device)
+        self._call("svcmi_channel_norm_gelu_f32", _ptr(x), _ptr(gamma), _ptr(beta), _ptr(out), _ptr(scratch), B, T, Cc,
+                   x.stride(1), out.stride(1), eps, self._stream())
+        return out
+
     def splitk_layernorm(self, partials, bias, x, gamma, beta, *, eps=1e-5, out=None):
         """x += bias + sum_s partials[:, s]  (in place);  returns LayerNorm(x) * gamma + beta.  partials: [B, S, T, C]."""
         self._chk(partials, bias, x, gamma, beta, out)

@@ -192,3 +192,47 @@ class WhisperWeights:
                 m1_w=f(sd[b + ".mlp.0.weight"]), m1_b=f(sd[b + ".mlp.0.bias"]),
                 m2_w=f(sd[b + ".mlp.2.weight"]), m2_b=f(sd[b + ".mlp.2.bias"])))
         self.lnp_g, self.lnp_b = f(sd["encoder.ln_post.weight"]), f(sd["encoder.ln_post.bias"])
+
+
+class HubertWeights:
+    """Packed ``HubertSoft`` parameters (hubert/hubert_model.py state-dict keys) on one device; dimensions are read
+    from the tensor shapes."""
+
+    def __init__(self, sd, device):
+        f = lambda t: t.float().to(device).contiguous()
+        self.conv0_w = f(pack_conv(sd["feature_extractor.conv0.weight"]))
+        self.norm0_g, self.norm0_b = f(sd["feature_extractor.norm0.weight"]), f(sd["feature_extractor.norm0.bias"])
+        self.convs = []
+        i = 1
+        while f"feature_extractor.conv{i}.weight" in sd:
+            w = sd[f"feature_extractor.conv{i}.weight"]
+            self.convs.append((f(pack_conv(w)), int(w.shape[2])))
+            i += 1
+        self.fp_g, self.fp_b = f(sd["feature_projection.norm.weight"]), f(sd["feature_projection.norm.bias"])
+        self.fp_w = f(pack_conv(sd["feature_projection.projection.weight"].unsqueeze(-1)))
+        self.fp_b2 = f(sd["feature_projection.projection.bias"])
+        # positional conv: weight_norm(dim=2) -> one norm per kernel tap over (out, in) (hubert_model.py:123-124)
+        v, g = sd["positional_embedding.conv.weight_v"].float(), sd["positional_embedding.conv.weight_g"].float()
+        w = g * v / v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()
+        self.E, self.pos_k = int(v.shape[0]), int(v.shape[2])
+        self.G = self.E // int(v.shape[1])
+        cg = self.E // self.G
+        pb = sd["positional_embedding.conv.bias"].float()
+        self.pos_w = [f(pack_conv(w[gi * cg:(gi + 1) * cg])) for gi in range(self.G)]
+        self.pos_b = [f(pb[gi * cg:(gi + 1) * cg]) for gi in range(self.G)]
+        self.norm_g, self.norm_b = f(sd["norm.weight"]), f(sd["norm.bias"])
+        self.layers = []
+        i = 0
+        while f"encoder.layers.{i}.norm1.weight" in sd:
+            p = f"encoder.layers.{i}."
+            self.layers.append(dict(
+                in_w=f(pack_conv(sd[p + "self_attn.in_proj_weight"].unsqueeze(-1))), in_b=f(sd[p + "self_attn.in_proj_bias"]),
+                out_w=f(pack_conv(sd[p + "self_attn.out_proj.weight"].unsqueeze(-1))), out_b=f(sd[p + "self_attn.out_proj.bias"]),
+                l1_w=f(pack_conv(sd[p + "linear1.weight"].unsqueeze(-1))), l1_b=f(sd[p + "linear1.bias"]),
+                l2_w=f(pack_conv(sd[p + "linear2.weight"].unsqueeze(-1))), l2_b=f(sd[p + "linear2.bias"]),
+                n1_g=f(sd[p + "norm1.weight"]), n1_b=f(sd[p + "norm1.bias"]),
+                n2_g=f(sd[p + "norm2.weight"]), n2_b=f(sd[p + "norm2.bias"])))
+            i += 1
+        # heads: the reference fixes 12 x 64 (hubert_model.py:21); smaller test models keep head_dim 16
+        self.heads = 12 if self.E == 768 else self.E // 16
+        self.proj_w, self.proj_b = f(pack_conv(sd["proj.weight"].unsqueeze(-1))), f(sd["proj.bias"])

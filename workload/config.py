@@ -78,3 +78,10 @@ WHISPER_TINY_TEST = {"n_mels": 80, "n_audio_ctx": 1500, "n_audio_state": 128,
                      "n_audio_head": 4, "n_audio_layer": 4,
                      "n_vocab": 64, "n_text_ctx": 8, "n_text_state": 128,
                      "n_text_head": 4, "n_text_layer": 1}
+
+
+# HuBERT-Soft dimensions hard-coded in the reference (hubert/hubert_model.py:11-28,70-121) and a small set for the
+# CPU-emulator tests (same structure, so every code path is exercised).
+HUBERT_SOFT = {"conv_dim": 512, "embed": 768, "heads": 12, "ffn": 3072, "layers": 12, "pos_kernel": 128, "pos_groups": 16, "proj": 256}
+HUBERT_TINY_TEST = {"conv_dim": 32, "embed": 64, "heads": 4, "ffn": 128, "layers": 2, "pos_kernel": 16, "pos_groups": 4, "proj": 16}
+HUBERT_WINDOW_S = 20          # hubert/inference.py:30: 20 s windows

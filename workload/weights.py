@@ -187,3 +187,45 @@ def make_whisper_state(dims=None, seed=4321, n_layers_present=None):
     sd["encoder.ln_post.weight"] = r.normal(S, std=0.1, mean=1.0)
     sd["encoder.ln_post.bias"] = r.normal(S, std=0.1)
     return {"dims": dims, "model_state_dict": {k: v.float().contiguous() for k, v in sd.items()}}
+
+
+def make_hubert_state(dims=None, seed=2468):
+    """``HubertSoft().state_dict()`` key layout (hubert/hubert_model.py; 166 tensors at the reference dims), seeded.
+    ``masked_spec_embed`` / ``label_embedding`` are training-only and included so a strict load succeeds."""
+    d = dict(C.HUBERT_SOFT if dims is None else dims)
+    r = _Rng(seed)
+    sd = {}
+    Cc, E, Fd = d["conv_dim"], d["embed"], d["ffn"]
+    sd["masked_spec_embed"] = r.uniform(E)
+    sd["feature_extractor.conv0.weight"] = r.normal(Cc, 1, 10, std=1.0 / math.sqrt(10))
+    sd["feature_extractor.norm0.weight"] = r.normal(Cc, std=0.2, mean=1.0)
+    sd["feature_extractor.norm0.bias"] = r.normal(Cc, std=0.1)
+    for i, k in zip(range(1, 7), (3, 3, 3, 3, 2, 2)):
+        sd[f"feature_extractor.conv{i}.weight"] = r.normal(Cc, Cc, k, std=1.4 / math.sqrt(Cc * k))
+    sd["feature_projection.norm.weight"] = r.normal(Cc, std=0.2, mean=1.0)
+    sd["feature_projection.norm.bias"] = r.normal(Cc, std=0.1)
+    sd["feature_projection.projection.weight"] = r.normal(E, Cc, std=1.0 / math.sqrt(Cc))
+    sd["feature_projection.projection.bias"] = r.normal(E, std=0.05)
+    G, Kp = d["pos_groups"], d["pos_kernel"]
+    sd["positional_embedding.conv.bias"] = r.normal(E, std=0.05)
+    sd["positional_embedding.conv.weight_g"] = r.uniform(1, 1, Kp, lo=0.5, hi=1.5)
+    sd["positional_embedding.conv.weight_v"] = r.normal(E, E // G, Kp, std=1.0)
+    sd["norm.weight"] = r.normal(E, std=0.2, mean=1.0)
+    sd["norm.bias"] = r.normal(E, std=0.1)
+    for i in range(d["layers"]):
+        p = f"encoder.layers.{i}."
+        sd[p + "self_attn.in_proj_weight"] = r.normal(3 * E, E, std=1.0 / math.sqrt(E))
+        sd[p + "self_attn.in_proj_bias"] = r.normal(3 * E, std=0.05)
+        sd[p + "self_attn.out_proj.weight"] = r.normal(E, E, std=1.0 / math.sqrt(E))
+        sd[p + "self_attn.out_proj.bias"] = r.normal(E, std=0.05)
+        sd[p + "linear1.weight"] = r.normal(Fd, E, std=1.0 / math.sqrt(E))
+        sd[p + "linear1.bias"] = r.normal(Fd, std=0.05)
+        sd[p + "linear2.weight"] = r.normal(E, Fd, std=1.0 / math.sqrt(Fd))
+        sd[p + "linear2.bias"] = r.normal(E, std=0.05)
+        for n in ("norm1", "norm2"):
+            sd[p + n + ".weight"] = r.normal(E, std=0.2, mean=1.0)
+            sd[p + n + ".bias"] = r.normal(E, std=0.1)
+    sd["proj.weight"] = r.normal(d["proj"], E, std=1.0 / math.sqrt(E))
+    sd["proj.bias"] = r.normal(d["proj"], std=0.05)
+    sd["label_embedding.weight"] = r.normal(100, d["proj"])
+    return sd
