@@ -101,8 +101,9 @@ class Ops:
         if split_k != 1 or partials:
             key = (x.device, self._stream())
             ws = self.workspaces.get(key)
-            if ws is None:     # slabs + zeroed per-tile arrival counters (the library keeps them zero)
-                ws = self.workspaces[key] = (torch.empty(self.workspace_floats, dtype=torch.float32, device=x.device),
+            need = max(self.workspace_floats, B * max(split_k, 1) * t_out * N if partials else 0)
+            if ws is None or ws[0].numel() < need:     # slabs + zeroed per-tile arrival counters (the library keeps them zero)
+                ws = self.workspaces[key] = (torch.empty(need, dtype=torch.float32, device=x.device),
                                              torch.zeros(65536, dtype=torch.int32, device=x.device))
             d.split_k, d.workspace, d.workspace_floats = split_k, ws[0].data_ptr(), ws[0].numel()
             if self.inlaunch_reduce and not partials:
