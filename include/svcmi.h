@@ -26,11 +26,11 @@
 extern "C" {
 #endif
 
-#define SVCMI_ABI_VERSION 8
+#define SVCMI_ABI_VERSION 10
 
 enum svcmi_status { SVCMI_OK = 0, SVCMI_EINVAL = -1, SVCMI_EUNSUPPORTED = -2, SVCMI_EALIGN = -3 };
 
-enum svcmi_act { SVCMI_ACT_NONE = 0, SVCMI_ACT_RELU = 1, SVCMI_ACT_GELU = 2, SVCMI_ACT_MISH = 3, SVCMI_ACT_TANH = 4 };
+enum svcmi_act { SVCMI_ACT_NONE = 0, SVCMI_ACT_RELU = 1, SVCMI_ACT_GELU = 2, SVCMI_ACT_MISH = 3, SVCMI_ACT_TANH = 4, SVCMI_ACT_SIGMOID = 5 };
 
 enum svcmi_conv_flags {
     SVCMI_CONV_ACCUMULATE = 1, /* y += result instead of y = result                          */
@@ -248,6 +248,26 @@ int svcmi_pitch_source_f32(const float* f0, const double* prefix, const float* n
 int svcmi_reflect_pad_f32(const float* x, float* y, int32_t batch, int64_t n, int32_t pad, void* stream);
 int svcmi_power_spectrum_f32(const float* ri, float* p, int64_t rows, int32_t nbins, int32_t half, int32_t ldri, int32_t ldp, void* stream);
 int svcmi_logmel_finish_f32(float* mel_power, float* scratch, float* out, int32_t batch, int32_t t, int32_t c, void* stream);
+
+/* CREPE F0 extractor glue (row N3; the six convolutions and the classifier are svcmi_conv_gemm_f32 launches):
+ *   crepe_frames: crepe/core.py:664-703 -- frame f = samples [f*hop - 512, f*hop + 512) of the waveform (zeros outside
+ *                 [0, n)), minus its mean, divided by max(1e-10, unbiased std).  Written as rows of `ld` (>= 1532, % 4 == 0)
+ *                 floats: 254 zeros, the 1024 samples, zeros -- the zero padding of the first convolution (model.py:119),
+ *                 placed so that its stride-4 / 512-tap window reads 16-byte aligned groups of 4 samples, i.e. the first
+ *                 layer is a stride-1, 128-tap convolution over rows of 4 "channels".
+ *   bn_maxpool2:  y[r, c] = max(x[2r, c], x[2r+1, c] as a' = a*scale[c] + shift[c]) -- eval-mode BatchNorm2d applied after
+ *                 the ReLU, then max_pool2d((2,1)) (model.py:128-134); rows_out = rows_in / 2, rows never straddle frames
+ *                 because every per-frame length is even. */
+int svcmi_crepe_frames_f32(const float* audio, int64_t n, int32_t hop, int32_t frame0, int32_t frames, float* out, int32_t ld, void* stream);
+int svcmi_bn_maxpool2_f32(const float* x, const float* scale, const float* shift, float* y, int64_t rows_out, int32_t c,
+                          int32_t ldx, int32_t ldy, void* stream);
+/* Viterbi decoding of the 360-bin pitch posteriorgram (crepe/decode.py:53-80; librosa.sequence.viterbi semantics: uniform
+ * prior, log domain): prob [frames][360] = the network's sigmoid outputs; bins outside [minidx, maxidx) are excluded
+ * (crepe/core.py:597-598); softmax over the rest in fp32, DP in fp64, independently per batch of `batch_frames` frames
+ * (crepe/core.py:683-686).  log_trans: [360][360] doubles = log(transition + tiny).  lp_scratch: frames*360 floats,
+ * ptr_scratch: frames*360 int16.  path: [frames] decoded bins. */
+int svcmi_viterbi_decode(const float* prob, const double* log_trans, float* lp_scratch, int16_t* ptr_scratch, int32_t* path,
+                         int32_t frames, int32_t batch_frames, int32_t minidx, int32_t maxidx, void* stream);
 
 /* int16 side output, vits_decoder/generator.py:167-173: clamp(32768*x, -32768, 32767) truncated to short. */
 int svcmi_source2wav_i16(const float* x, int16_t* y, int64_t n, void* stream);

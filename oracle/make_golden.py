@@ -181,6 +181,56 @@ def hubert_fixture(tag, n, seed):
     np.savez_compressed(os.path.join(OUT, tag + ".npz"), n=n, seed=seed, units=u.numpy(), weights_checksum=checksum(sd))
 
 
+def crepe_fixture(tag, capacity, n, seed):
+    """The reference's vendored crepe package (crepe/core.py preprocess + infer + postprocess) on seeded weights.
+    resampy is stubbed (16 kHz input needs no resampling); librosa.sequence.viterbi -- absent -- is replaced by the
+    oracle's restatement, so the Viterbi routine itself is the one unpinned piece."""
+    print(f"[{tag}] n={n}")
+    import importlib.machinery
+    from . import crepe_oracle as CO
+    R._prepare()
+    for name in ("resampy", "tqdm"):
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                m = types.ModuleType(name)
+                m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+                sys.modules[name] = m
+    import librosa
+    seq = types.ModuleType("librosa.sequence")
+    seq.viterbi = lambda p, t: CO.viterbi_path(p, t)
+    librosa.sequence = seq
+    sys.modules["librosa.sequence"] = seq
+    import crepe
+    import scipy.stats
+    sd = W.make_crepe_state(capacity)
+    model = crepe.Crepe(capacity)
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    crepe.infer.model, crepe.infer.capacity = model, capacity
+    gen = torch.Generator().manual_seed(seed)
+    t = torch.arange(n) / 16000.0
+    audio = (0.4 * torch.sin(2 * np.pi * (180 + 60 * torch.sin(2 * np.pi * 1.5 * t)) * t) + 0.02 * torch.randn(n, generator=gen)).float()
+    with torch.no_grad():
+        frames = next(crepe.preprocess(audio[None].clone(), 16000, 320, None, "cpu", True))
+        prob = crepe.infer(frames, capacity)
+        o_prob = CO.network(sd, CO.preprocess(audio[None], 320))
+    _agree("crepe posteriors", o_prob, prob, 1e-6)
+    orig = scipy.stats.triang.rvs
+    scipy.stats.triang.rvs = lambda c, loc, scale, size: np.zeros(tuple(size))       # dither off for the fixture
+    try:
+        f0a = crepe.postprocess(prob.reshape(1, -1, 360).transpose(1, 2).clone(), 50., 1000., crepe.decode.argmax)[0]
+        f0v = crepe.postprocess(prob.reshape(1, -1, 360).transpose(1, 2).clone(), 50., 1000., crepe.decode.viterbi)[0]
+    finally:
+        scipy.stats.triang.rvs = orig
+    z = np.zeros(prob.shape[0])
+    _agree("argmax f0", CO.decode(o_prob, 50., 1000., "argmax", z), f0a, 1e-3)
+    _agree("viterbi f0", CO.decode(o_prob, 50., 1000., "viterbi", z), f0v, 1e-3)
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), n=n, seed=seed, prob=prob.numpy(), f0_argmax=f0a.numpy(),
+                        f0_viterbi=f0v.numpy(), weights_checksum=checksum({k: v.float() for k, v in sd.items()}))
+
+
 def main():
     assert R.available(), "needs /root/reference"
     os.makedirs(OUT, exist_ok=True)
@@ -192,6 +242,7 @@ def main():
     svc_infer_fixture("svc_infer_tiny_2chunks", C.tiny_hp(), T=2600)
     logmel_fixture("logmel_2p5s", n=40000, seed=21)
     hubert_fixture("hubert_soft_1s", n=16000, seed=3)
+    crepe_fixture("crepe_full_1s", "full", n=16000, seed=5)
     print("golden fixtures written to", OUT)
 
 

@@ -130,3 +130,49 @@ def check_hubert_golden(ops, device, tol=TIGHT):
     err = maxerr(m.units(wav), _t(g["units"]))
     assert err <= tol * max(1.0, float(np.abs(g["units"]).max())), err
     return err
+
+
+def crepe_test_audio(n, seed):
+    g = torch.Generator().manual_seed(seed)
+    t = torch.arange(n) / 16000.0
+    return (0.4 * torch.sin(2 * np.pi * (180 + 60 * torch.sin(2 * np.pi * 1.5 * t)) * t) + 0.02 * torch.randn(n, generator=g)).float()
+
+
+def check_crepe_against_oracle(ops, device, capacity, n, tol=2e-5):
+    """CREPE posteriors on the GPU kernels vs the oracle, then compute_f0_sing (Viterbi, injected noise/dither) end to end."""
+    from oracle import crepe_oracle as CO
+    from svcmi.pitch import compute_f0_sing, load_crepe
+    sd = W.make_crepe_state(capacity)
+    m = load_crepe(sd, device, ops=ops)
+    audio = crepe_test_audio(n, 5)
+    got = m.probabilities(audio, hop=320)
+    with torch.no_grad():
+        want = CO.network(sd, CO.preprocess(audio[None], 320))
+    assert tuple(got.shape) == tuple(want.shape) == (1 + n // 320, 360)
+    err = maxerr(got, want)
+    assert err <= tol, err
+    g = torch.Generator().manual_seed(9)
+    noise = torch.randn(n, generator=g)
+    dither = (torch.rand(1 + n // 320, generator=g) * 2 - 1).numpy() * 20.0
+    f0 = compute_f0_sing(audio, device, model=m, noise=noise, dither=dither)
+    with torch.no_grad():
+        f0_ref = CO.compute_f0_sing(sd, audio, noise, dither).numpy()
+    assert f0.shape == f0_ref.shape == (2 * (1 + n // 320),)
+    # the decoded path is discrete: posteriors that agree to 1e-5 give the same bins except at exact ties
+    same = np.isclose(f0, f0_ref, rtol=1e-5, atol=1e-3, equal_nan=True)
+    assert same.mean() >= 0.98, float(same.mean())
+    return err, float(same.mean())
+
+
+def check_crepe_golden(ops, device, tol=2e-5):
+    """svcmi.pitch.Crepe at the reference's `full` capacity vs the reference crepe package itself (golden fixture)."""
+    from svcmi.pitch import decode, load_crepe
+    g = golden("crepe_full_1s")
+    m = load_crepe(W.make_crepe_state("full"), device, ops=ops)
+    audio = crepe_test_audio(int(g["n"]), int(g["seed"]))
+    prob = m.probabilities(audio, hop=320).cpu()
+    err = maxerr(prob, _t(g["prob"]))
+    assert err <= tol, err
+    f0 = decode(prob, 50.0, 1000.0, "argmax", np.zeros(prob.shape[0])).numpy()
+    assert np.isclose(f0, g["f0_argmax"], rtol=1e-5).mean() >= 0.98
+    return err

@@ -6,6 +6,7 @@ class (different summation orders), stated per check.
 """
 import math
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -116,6 +117,25 @@ def check_layernorm(ops, c, device):
     gb, bb = torch.randn(B, c, generator=g), torch.randn(B, c, generator=g)
     want = F.layer_norm(x, (c,), None, None, 1e-5) * gb[:, None] + bb[:, None]
     _close(ops.layernorm(x.to(device), gb.to(device), bb.to(device), per_batch_affine=True), want, 2e-5, "ln per-batch")
+
+
+def check_viterbi(ops, device, frames=70, batch_frames=32):
+    """Device Viterbi (fp32 softmax, fp64 DP, per decoding batch) vs the host restatement of librosa.sequence.viterbi."""
+    from svcmi.pitch import inference as PI
+    g = _g(31 + frames)
+    centre = 120 + 40 * torch.sin(torch.arange(frames) / 7.0)
+    prob = torch.sigmoid(-((torch.arange(360)[None, :] - centre[:, None]) / 6.0) ** 2 + 0.8 * torch.randn(frames, 360, generator=g))
+    lo, hi = PI._frequency_to_bins(50.0), PI._frequency_to_bins(1000.0, ceil=True)
+    lt = torch.from_numpy(np.log(PI._transition() + np.finfo(np.float32).tiny))
+    got = ops.viterbi_decode(prob.to(device), lt.to(device), batch_frames, lo, hi).cpu().numpy()
+    want = []
+    for i in range(0, frames, batch_frames):
+        p = prob[i:i + batch_frames].t().clone()
+        p[:lo] = -float("inf")
+        p[hi:] = -float("inf")
+        want.append(PI.viterbi_path(torch.softmax(p, dim=0).numpy(), PI._transition()))
+    want = np.concatenate(want)
+    assert got.shape == want.shape and (got == want).mean() >= 0.99, float((got == want).mean())
 
 
 def check_channel_norm_gelu(ops, device, B=2, T=700, c=32):

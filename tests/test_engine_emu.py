@@ -28,3 +28,7 @@ def test_logmel_frontend_matches_reference_golden(ops):
 
 def test_hubert_tiny_matches_oracle(ops):
     print(E.check_hubert_against_oracle(ops, "cpu", C.HUBERT_TINY_TEST, n=4000, heads=4))
+
+
+def test_crepe_tiny_matches_oracle(ops):
+    print(E.check_crepe_against_oracle(ops, "cpu", "tiny", n=1600))

@@ -67,6 +67,19 @@ def test_hubert_tiny_against_oracle(ops):
     print(E.check_hubert_against_oracle(ops, "cuda", C.HUBERT_TINY_TEST, n=4000, heads=4))
 
 
+def test_crepe_full_golden(ops):
+    print(E.check_crepe_golden(ops, "cuda"))
+
+
+def test_crepe_full_10s_against_oracle(ops):
+    """compute_f0_sing at the reference's `full` capacity on 3 s (151 frames; the CPU oracle needs ~1.4 GMAC per frame)."""
+    print(E.check_crepe_against_oracle(ops, "cuda", "full", n=48000))
+
+
+def test_crepe_tiny_against_oracle(ops):
+    print(E.check_crepe_against_oracle(ops, "cuda", "tiny", n=16000 * 12))     # 601 frames: two decoding batches
+
+
 def test_svc_infer_two_chunks_golden(ops):
     print(E.check_svc_infer_golden(ops, "cuda"))
 

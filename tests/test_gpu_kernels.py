@@ -63,6 +63,10 @@ def test_channel_norm_gelu(ops, T, c):
     K.check_channel_norm_gelu(ops, "cuda", T=T, c=c)
 
 
+def test_viterbi_decode(ops):
+    K.check_viterbi(ops, "cuda", frames=1100, batch_frames=512)
+
+
 def test_flow_glue(ops):
     K.check_flow_glue(ops, device="cuda")
 

@@ -59,6 +59,10 @@ def test_channel_norm_gelu(ops, T, c):
     K.check_channel_norm_gelu(ops, "cpu", T=T, c=c)
 
 
+def test_viterbi_decode(ops):
+    K.check_viterbi(ops, "cpu", frames=40, batch_frames=16)
+
+
 def test_flow_glue(ops):
     K.check_flow_glue(ops, device="cpu")
 

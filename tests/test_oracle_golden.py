@@ -148,3 +148,26 @@ def test_hubert_oracle_matches_reference_golden(golden_dir):
     with torch.no_grad():
         got = H.units(sd, wav, 12)
     assert float((got - _t(g["units"])).abs().max()) <= TOL
+
+
+def test_crepe_oracle_matches_reference_golden(golden_dir):
+    from oracle import crepe_oracle as CO
+    from tests.engine_cases import crepe_test_audio
+    g = _load(golden_dir, "crepe_full_1s")
+    sd = W.make_crepe_state("full")
+    audio = crepe_test_audio(int(g["n"]), int(g["seed"]))
+    with torch.no_grad():
+        prob = CO.network(sd, CO.preprocess(audio[None], 320))
+    assert float((prob - _t(g["prob"])).abs().max()) <= 1e-5
+    z = np.zeros(prob.shape[0])
+    assert np.allclose(CO.decode(prob, 50., 1000., "argmax", z).numpy(), g["f0_argmax"], rtol=1e-5)
+    assert np.allclose(CO.decode(prob, 50., 1000., "viterbi", z).numpy(), g["f0_viterbi"], rtol=1e-5)
+
+
+def test_viterbi_restatement_on_a_known_case():
+    """Hand-checkable 3-state case: sticky transitions keep the path on state 0 through one ambiguous frame."""
+    from oracle import crepe_oracle as CO
+    prob = np.array([[0.8, 0.45, 0.8], [0.1, 0.5, 0.1], [0.1, 0.05, 0.1]])
+    tr = np.array([[0.9, 0.05, 0.05], [0.05, 0.9, 0.05], [0.05, 0.05, 0.9]])
+    assert CO.viterbi_path(prob, tr).tolist() == [0, 0, 0]
+    assert CO.viterbi_path(prob, np.full((3, 3), 1 / 3)).tolist() == [0, 1, 0]

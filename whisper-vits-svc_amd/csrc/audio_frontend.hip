@@ -85,7 +85,158 @@ __global__ __launch_bounds__(TPB) void logmel_finish_kernel(const float* x, cons
     }
 }
 
+// ------------------------------------------------------------------------------------ CREPE glue
+constexpr int CREPE_WIN = 1024, CREPE_LEAD = 254;
+
+// one block per frame: 256 threads x 4 samples; mean and unbiased std by wave shuffles + LDS
+__global__ __launch_bounds__(TPB) void crepe_frames_kernel(const float* audio, long long n, int hop, int frame0, float* out, int ld) {
+    __shared__ float red[TPB / 64];
+    const int f = blockIdx.x;
+    const long long s0 = (long long)(frame0 + f) * hop - CREPE_WIN / 2;
+    float v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long long i = s0 + threadIdx.x * 4 + j;
+        v[j] = (i >= 0 && i < n) ? audio[i] : 0.f;
+        s += v[j];
+    }
+    auto block_sum = [&](float x) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
+        __syncthreads();
+        return (red[0] + red[1]) + (red[2] + red[3]);
+    };
+    const float mean = block_sum(s) / (float)CREPE_WIN;
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] -= mean; ss += v[j] * v[j]; }
+    const float sd = sqrtf(block_sum(ss) / (float)(CREPE_WIN - 1));      // torch.std: unbiased
+    const float inv = 1.0f / fmaxf(1e-10f, sd);
+    float* o = out + (long long)f * ld;
+    for (int i = threadIdx.x; i < ld; i += TPB)
+        if (i < CREPE_LEAD || i >= CREPE_LEAD + CREPE_WIN) o[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[CREPE_LEAD + threadIdx.x * 4 + j] = v[j] * inv;
+}
+
+__global__ __launch_bounds__(TPB) void bn_maxpool2_kernel(const float* x, const float* scale, const float* shift, float* y,
+                                                          long long rows_out, int c, int ldx, int ldy) {
+    const int c4 = c >> 2;
+    const long long total = rows_out * c4;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+        const long long r = i / c4;
+        const int cc = (int)(i - r * c4) * 4;
+        const float4 a = *reinterpret_cast<const float4*>(x + (2 * r) * ldx + cc);
+        const float4 b = *reinterpret_cast<const float4*>(x + (2 * r + 1) * ldx + cc);
+        const float4 sc = *reinterpret_cast<const float4*>(scale + cc);
+        const float4 sh = *reinterpret_cast<const float4*>(shift + cc);
+        float4 o;
+        o.x = fmaxf(fmaf(a.x, sc.x, sh.x), fmaf(b.x, sc.x, sh.x));
+        o.y = fmaxf(fmaf(a.y, sc.y, sh.y), fmaf(b.y, sc.y, sh.y));
+        o.z = fmaxf(fmaf(a.z, sc.z, sh.z), fmaf(b.z, sc.z, sh.z));
+        o.w = fmaxf(fmaf(a.w, sc.w, sh.w), fmaf(b.w, sc.w, sh.w));
+        *reinterpret_cast<float4*>(y + r * ldy + cc) = o;
+    }
+}
+
+// Viterbi decoding of a pitch posteriorgram (crepe/decode.py:53-80 -> librosa.sequence.viterbi): per frame, softmax over
+// the allowed bins of the network's (sigmoid) outputs as torch does it in fp32, log-likelihood log(p + tiny); then the
+// dynamic programme over S = 360 states in fp64 -- one 384-thread block per decoding batch, thread k owns state k,
+// the running values live in LDS, back-pointers in global memory, thread 0 walks them back.  Ties resolve to the lowest
+// state index like numpy's argmax.
+constexpr int VS = 360;
+
+__global__ __launch_bounds__(64) void viterbi_loglik_kernel(const float* prob, float* lp, int minidx, int maxidx) {
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const float* pr = prob + (long long)t * VS;
+    float m = -3.0e38f;
+    for (int s = minidx + lane; s < maxidx; s += 64) m = fmaxf(m, pr[s]);
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, __shfl_xor(m, k));
+    float sum = 0.f;
+    for (int s = minidx + lane; s < maxidx; s += 64) sum += expf(pr[s] - m);
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) sum += __shfl_xor(sum, k);
+    for (int s = lane; s < VS; s += 64) {
+        const float p = (s >= minidx && s < maxidx) ? expf(pr[s] - m) / sum : 0.f;
+        lp[(long long)t * VS + s] = logf(p + 1.17549435e-38f);
+    }
+}
+
+__global__ __launch_bounds__(384) void viterbi_dp_kernel(const float* lp, const double* log_trans, short* ptr, int* path, int t_total,
+                                                         int batch_frames) {
+    __shared__ double val[2][VS];
+    __shared__ int best;
+    const int k = threadIdx.x;
+    const int f0 = blockIdx.x * batch_frames;
+    const int T = (t_total - f0) < batch_frames ? (t_total - f0) : batch_frames;
+    const float* lpb = lp + (long long)f0 * VS;
+    short* pb = ptr + (long long)f0 * VS;
+    if (k < VS) val[0][k] = (double)lpb[k] + log(1.0 / VS + 2.2250738585072014e-308);
+    __syncthreads();
+    for (int t = 1; t < T; ++t) {
+        const double* prev = val[(t - 1) & 1];
+        if (k < VS) {
+            double bv = prev[0] + log_trans[k];
+            int bj = 0;
+            for (int j = 1; j < VS; ++j) {
+                const double c = prev[j] + log_trans[(long long)j * VS + k];
+                if (c > bv) { bv = c; bj = j; }
+            }
+            val[t & 1][k] = (double)lpb[(long long)t * VS + k] + bv;
+            pb[(long long)t * VS + k] = (short)bj;
+        }
+        __syncthreads();
+    }
+    if (k == 0) {
+        const double* last = val[(T - 1) & 1];
+        int bj = 0;
+        for (int j = 1; j < VS; ++j)
+            if (last[j] > last[bj]) bj = j;
+        best = bj;
+        int cur = bj;
+        path[f0 + T - 1] = cur;
+        for (int t = T - 2; t >= 0; --t) {
+            cur = pb[(long long)(t + 1) * VS + cur];
+            path[f0 + t] = cur;
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int svcmi_viterbi_decode(const float* prob, const double* log_trans, float* lp_scratch, int16_t* ptr_scratch, int32_t* path,
+                                    int32_t frames, int32_t batch_frames, int32_t minidx, int32_t maxidx, void* stream) {
+    if (!prob || !log_trans || !lp_scratch || !ptr_scratch || !path || frames <= 0 || batch_frames <= 0) return SVCMI_EINVAL;
+    if (minidx < 0 || maxidx > VS || minidx >= maxidx) return SVCMI_EINVAL;
+    SVCMI_LAUNCH(viterbi_loglik_kernel, dim3((unsigned)frames), dim3(64), 0, stream, prob, lp_scratch, minidx, maxidx);
+    int rc = SVCMI_LAST_ERROR();
+    if (rc) return rc;
+    SVCMI_LAUNCH(viterbi_dp_kernel, dim3((unsigned)((frames + batch_frames - 1) / batch_frames)), dim3(384), 0, stream,
+                 (const float*)lp_scratch, log_trans, (short*)ptr_scratch, path, frames, batch_frames);
+    return SVCMI_LAST_ERROR();
+}
+
+extern "C" int svcmi_crepe_frames_f32(const float* audio, int64_t n, int32_t hop, int32_t frame0, int32_t frames, float* out, int32_t ld, void* stream) {
+    if (!audio || !out || n <= 0 || hop <= 0 || frame0 < 0 || frames <= 0) return SVCMI_EINVAL;
+    if (ld < CREPE_LEAD + CREPE_WIN + CREPE_LEAD || ld % 4) return SVCMI_EINVAL;
+    SVCMI_LAUNCH(crepe_frames_kernel, dim3((unsigned)frames), dim3(TPB), 0, stream, audio, (long long)n, hop, frame0, out, ld);
+    return SVCMI_LAST_ERROR();
+}
+
+extern "C" int svcmi_bn_maxpool2_f32(const float* x, const float* scale, const float* shift, float* y, int64_t rows_out, int32_t c,
+                                     int32_t ldx, int32_t ldy, void* stream) {
+    if (!x || !scale || !shift || !y || rows_out <= 0 || c <= 0) return SVCMI_EINVAL;
+    if (c % 4 || ldx % 4 || ldy % 4 || ((uintptr_t)x & 15) || ((uintptr_t)y & 15) || ((uintptr_t)scale & 15) || ((uintptr_t)shift & 15))
+        return SVCMI_EALIGN;
+    long long nb = (rows_out * (c / 4) + TPB - 1) / TPB;
+    if (nb > 8192) nb = 8192;
+    SVCMI_LAUNCH(bn_maxpool2_kernel, dim3((unsigned)nb), dim3(TPB), 0, stream, x, scale, shift, y, (long long)rows_out, c, ldx, ldy);
+    return SVCMI_LAST_ERROR();
+}
 
 extern "C" int svcmi_reflect_pad_f32(const float* x, float* y, int32_t batch, int64_t n, int32_t pad, void* stream) {
     if (!x || !y || batch <= 0 || n <= 0 || pad < 0 || pad >= n) return SVCMI_EINVAL;

@@ -68,6 +68,7 @@ __device__ __forceinline__ float act_apply(float v, int act) {
             return v * tanhf(sp);
         }
         case SVCMI_ACT_TANH: return tanhf(v);
+        case SVCMI_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
         default: return v;
     }
 }
@@ -478,7 +479,7 @@ extern "C" int svcmi_conv_gemm_f32(const svcmi_conv_desc* d, void* stream) {
     if (d->ldw % 4 != 0 || d->ldw < d->ksize * d->c_in) return SVCMI_EINVAL;
     if (d->ldy < d->n_out || (d->res && d->ldr < d->n_out) || d->ldx < d->c_in) return SVCMI_EINVAL;
     if ((d->flags & (SVCMI_CONV_MASK_IN | SVCMI_CONV_MASK_OUT)) && !d->lengths) return SVCMI_EINVAL;
-    if (d->act < SVCMI_ACT_NONE || d->act > SVCMI_ACT_TANH) return SVCMI_EINVAL;
+    if (d->act < SVCMI_ACT_NONE || d->act > SVCMI_ACT_SIGMOID) return SVCMI_EINVAL;
     if (d->split_k < 0 || (d->split_k > 1 && !d->workspace)) return SVCMI_EINVAL;
     if (((uintptr_t)d->w & 15) != 0) return SVCMI_EALIGN;
     // magic-number division q / c_in is exact while q * c_in < 2^32 (q < ksize*c_in)

@@ -6,9 +6,9 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(HERE, "libsvcmi.so")
 
-ACT_NONE, ACT_RELU, ACT_GELU, ACT_MISH, ACT_TANH = 0, 1, 2, 3, 4
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_MISH, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4, 5
 CONV_ACCUMULATE, CONV_MASK_IN, CONV_MASK_OUT, CONV_PARTIALS = 1, 2, 4, 8
-ABI_VERSION = 8
+ABI_VERSION = 10
 
 
 class ConvDesc(Structure):
@@ -53,6 +53,9 @@ SIGNATURES = {
     "svcmi_reflect_pad_f32": (c_int, [_P, _P, _I, _L, _I, _P]),
     "svcmi_power_spectrum_f32": (c_int, [_P, _P, _L, _I, _I, _I, _I, _P]),
     "svcmi_logmel_finish_f32": (c_int, [_P, _P, _P, _I, _I, _I, _P]),
+    "svcmi_crepe_frames_f32": (c_int, [_P, _L, _I, _I, _I, _P, _I, _P]),
+    "svcmi_bn_maxpool2_f32": (c_int, [_P, _P, _P, _P, _L, _I, _I, _I, _P]),
+    "svcmi_viterbi_decode": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "svcmi_source2wav_i16": (c_int, [_P, _P, _L, _P]),
 }
 

@@ -9,7 +9,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import (ACT_GELU, ACT_MISH, ACT_NONE, ACT_RELU, ACT_TANH, CONV_ACCUMULATE, CONV_MASK_IN,  # noqa: F401
+from ._lib import (ACT_GELU, ACT_MISH, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, CONV_ACCUMULATE, CONV_MASK_IN,  # noqa: F401
                    CONV_MASK_OUT, CONV_PARTIALS, ConvDesc, SvcmiError)
 
 
@@ -241,6 +241,34 @@ class Ops:
         out = torch.empty(B, Cc, T, dtype=torch.float32, device=mel_power.device)
         self._call("svcmi_logmel_finish_f32", _ptr(mel_power), _ptr(scratch), _ptr(out), B, T, Cc, self._stream())
         return out
+
+    # ------------------------------------------------------------------ CREPE glue
+    def crepe_frames(self, audio, hop, frame0, frames, ld=1536):
+        """audio [n] -> normalised, first-layer-padded frames [frames, ld] (crepe/core.py:664-703)."""
+        self._chk(audio)
+        out = torch.empty(frames, ld, dtype=torch.float32, device=audio.device)
+        self._call("svcmi_crepe_frames_f32", _ptr(audio), audio.numel(), hop, frame0, frames, _ptr(out), ld, self._stream())
+        return out
+
+    def bn_maxpool2(self, x, scale, shift):
+        """x [B, T, C] (T even) -> max over row pairs of x*scale + shift: [B, T/2, C] (crepe/model.py:128-134)."""
+        self._chk(x, scale, shift)
+        B, T, Cc = x.shape
+        y = torch.empty(B, T // 2, Cc, dtype=torch.float32, device=x.device)
+        self._call("svcmi_bn_maxpool2_f32", _ptr(x), _ptr(scale), _ptr(shift), _ptr(y), B * (T // 2), Cc, x.stride(1), y.stride(1),
+                   self._stream(), work={"bytes": 6.0 * B * T * Cc})
+        return y
+
+    def viterbi_decode(self, prob, log_trans, batch_frames, minidx, maxidx):
+        """prob [frames, 360] (sigmoid outputs), log_trans [360, 360] float64 -> decoded bins int32 [frames]."""
+        self._chk(prob, log_trans)
+        Fr = prob.shape[0]
+        lp = torch.empty(Fr * 360, dtype=torch.float32, device=prob.device)
+        ptr = torch.empty(Fr * 360, dtype=torch.int16, device=prob.device)
+        path = torch.empty(Fr, dtype=torch.int32, device=prob.device)
+        self._call("svcmi_viterbi_decode", _ptr(prob), _ptr(log_trans), _ptr(lp), _ptr(ptr), _ptr(path), Fr, batch_frames,
+                   minidx, maxidx, self._stream())
+        return path
 
     def source2wav(self, x):
         self._chk(x)

@@ -1,0 +1,188 @@
+"""Drop-in for the reference's pitch/inference.py (``compute_f0_sing``, the CSV pitch format) with the CREPE network on
+the svcmi kernels (row N3 of SURVEY.md 8f: the extractor that produces the ``pit`` input of the synthesiser; at 705 GMAC
+per 10 s it is the heaviest stage of the reference CLI).
+
+    crepe = load_crepe("crepe/assets/full.pth", "cuda")          # crepe/load.py:23-36 checkpoint (state dict)
+    f0 = compute_f0_sing("in.wav", "cuda", model=crepe)          # np.float32 [2 * (1 + n // 320)] Hz, NaN-free
+    save_csv_pitch(f0, "in.pit.csv"); load_csv_pitch("in.pit.csv")
+
+On the GPU: framing + per-frame normalisation, six [pad, conv, ReLU, BatchNorm, max-pool] layers (the convolutions are
+implicit GEMMs with the frames as the batch; the 512-tap stride-4 first layer runs as a 128-tap stride-1 convolution over
+rows of 4 samples), classifier + sigmoid.  On the host, as in the reference (numpy + librosa there): the Viterbi / argmax
+decoding of the 360-bin posteriorgram per batch of 512 frames, dithering, the x2 repeat and the mean filter.
+The Viterbi routine restates ``librosa.sequence.viterbi`` (not installed here; parity unpinned for that one function).
+"""
+import numpy as np
+import torch
+
+from .. import weights as PW
+from ..ops import ACT_RELU, ACT_SIGMOID, Ops
+
+CENTS_PER_BIN, PITCH_BINS, SAMPLE_RATE, WINDOW_SIZE = 20, 360, 16000, 1024
+FRAME_LD = 1536          # 254 + 1024 + 258 floats: 384 rows of 4 samples
+
+
+class Crepe:
+    """crepe.Crepe in eval mode (crepe/model.py:14-134): ``probabilities(audio) -> [frames, 360]``."""
+
+    def __init__(self, state_dict, device, ops=None):
+        self.ops = ops if ops is not None else Ops()
+        self.device = torch.device(device)
+        self.w = PW.CrepeWeights(state_dict, self.device)
+
+    @torch.no_grad()
+    def probabilities(self, audio, hop=320, batch_size=512):
+        """audio [n] float @16 kHz -> sigmoid outputs [1 + n // hop, 360] (device tensor), batches of ``batch_size`` frames."""
+        w, ops = self.w, self.ops
+        audio = audio.to(self.device, torch.float32).contiguous().view(-1)
+        total = 1 + audio.numel() // hop
+        out = torch.empty(total, PITCH_BINS, dtype=torch.float32, device=self.device)
+        for f0 in range(0, total, batch_size):
+            nf = min(batch_size, total - f0)
+            x = ops.crepe_frames(audio, hop, f0, nf, FRAME_LD).view(nf, FRAME_LD // 4, 4)
+            for i, L in enumerate(w.layers):
+                if i == 0:      # 512 taps, stride 4, pad 254/254 == 128 taps, stride 1 over rows of 4 samples
+                    x = ops.conv(x, L["w"], L["b"], ksize=128, pad=0, t_out=256, act=ACT_RELU)
+                else:           # 64 taps, pad 31/32 (the right pad is the kernel's out-of-range zero fill)
+                    x = ops.conv(x, L["w"], L["b"], ksize=64, pad=31, t_out=x.shape[1], act=ACT_RELU)
+                x = ops.bn_maxpool2(x, L["scale"], L["shift"])
+            feat = x.reshape(1, nf, -1)                     # [F, 4, 512] -> 2048 = h * 512 + c, model.py:112
+            ops.conv(feat, w.fc_w, w.fc_b, act=ACT_SIGMOID, out=out[f0:f0 + nf].view(1, nf, PITCH_BINS))
+        return out
+
+
+def load_crepe(path, device, ops=None):
+    sd = torch.load(path, map_location="cpu") if isinstance(path, str) else path
+    return Crepe(sd, device, ops=ops)
+
+
+# ------------------------------------------------------------------------------------------ host-side decoding
+def _frequency_to_bins(f, ceil=False):
+    b = (1200.0 * np.log2(np.float32(f) / np.float32(10.0)) - 1997.3794084376191) / CENTS_PER_BIN     # crepe/convert.py:29-50
+    return int(np.ceil(b)) if ceil else int(np.floor(b))
+
+
+def viterbi_path(prob, transition):
+    """Most likely state path, ``librosa.sequence.viterbi(prob, transition)`` semantics: prob [S, T] observation
+    likelihoods, row-stochastic transition [S, S], uniform initial distribution, log domain."""
+    S, T = prob.shape
+    tiny = np.finfo(prob.dtype).tiny
+    lp, lt = np.log(prob + tiny), np.log(transition + tiny)
+    val = lp[:, 0] + np.log(1.0 / S + tiny)
+    ptr = np.zeros((T, S), dtype=np.int64)
+    cols = np.arange(S)
+    for t in range(1, T):
+        tr = val[:, None] + lt
+        ptr[t] = np.argmax(tr, axis=0)
+        val = lp[:, t] + tr[ptr[t], cols]
+    path = np.zeros(T, dtype=np.int64)
+    path[-1] = int(np.argmax(val))
+    for t in range(T - 2, -1, -1):
+        path[t] = ptr[t + 1][path[t + 1]]
+    return path
+
+
+_TRANSITION = None
+
+
+def _transition():
+    global _TRANSITION
+    if _TRANSITION is None:             # crepe/decode.py:55-60
+        xx, yy = np.meshgrid(range(PITCH_BINS), range(PITCH_BINS))
+        tr = np.maximum(12 - abs(xx - yy), 0)
+        _TRANSITION = tr / tr.sum(axis=1, keepdims=True)
+    return _TRANSITION
+
+
+def bins_to_hz(bins, dither=None):
+    """crepe/convert.py:13-34,58-64: bins -> cents (+ triangular dither) -> Hz."""
+    bins = torch.as_tensor(bins).cpu().long()
+    if dither is None:
+        import scipy.stats
+        dither = scipy.stats.triang.rvs(c=0.5, loc=-CENTS_PER_BIN, scale=2 * CENTS_PER_BIN, size=tuple(bins.shape))
+    cents = CENTS_PER_BIN * bins + 1997.3794084376191
+    cents = cents + cents.new_tensor(np.asarray(dither))
+    return 10 * 2 ** (cents / 1200)
+
+
+def decode(prob, fmin=50.0, fmax=1000.0, decoder="viterbi", dither=None):
+    """One batch of posteriors [F, 360] (CPU) -> Hz [F]: crepe/core.py:592-603, decode.py, convert.py.
+    ``dither`` [F] cents; None draws the reference's triangular noise (scipy.stats.triang, convert.py:58-64)."""
+    p = prob.t().clone()
+    p[:_frequency_to_bins(fmin)] = -float("inf")
+    p[_frequency_to_bins(fmax, ceil=True):] = -float("inf")
+    if decoder == "argmax":
+        bins = p.argmax(dim=0).numpy()
+    elif decoder == "viterbi":
+        bins = viterbi_path(torch.softmax(p, dim=0).numpy(), _transition())
+    else:
+        raise ValueError(decoder)
+    if dither is None:
+        import scipy.stats
+        dither = scipy.stats.triang.rvs(c=0.5, loc=-CENTS_PER_BIN, scale=2 * CENTS_PER_BIN, size=bins.shape)
+    cents = CENTS_PER_BIN * torch.from_numpy(bins) + 1997.3794084376191
+    cents = cents + cents.new_tensor(np.asarray(dither))
+    return 10 * 2 ** (cents / 1200)
+
+
+def mean_filter(signals, win_length):
+    """crepe/filter.py:10-57: NaN-aware moving average over [1, T]; exact zeros become NaN."""
+    import torch.nn.functional as F
+    x = signals.unsqueeze(1)
+    mask = ~torch.isnan(x)
+    mx = torch.where(mask, x, torch.zeros_like(x))
+    ones = torch.ones(1, 1, win_length)
+    s = F.conv1d(mx, ones, padding=win_length // 2)
+    c = F.conv1d(mask.float(), ones, padding=win_length // 2).clamp(min=1)
+    out = s / c
+    out[out == 0] = float("nan")
+    return out.squeeze(1)
+
+
+@torch.no_grad()
+def compute_f0_sing(filename, device, model=None, noise=None, dither=None, decoder="viterbi"):
+    """pitch/inference.py:74-99.  ``filename``: wav path or a 16 kHz float waveform [n]; ``model``: a ``Crepe`` (the
+    reference loads crepe/assets/full.pth on first use).  ``noise`` [n] ~ N(0,1) pins the 1e-3 input noise (:77),
+    ``dither`` [frames] pins convert.py:58-64.  Returns np.float32 Hz [2 * (1 + n // 320)]."""
+    if model is None:
+        raise ValueError("pass model=load_crepe(<crepe full.pth>, device)")
+    if isinstance(filename, str):
+        from ..whisper.audio import load_audio
+        audio = torch.from_numpy(load_audio(filename))
+    else:
+        audio = torch.as_tensor(filename, dtype=torch.float32)
+    nz = torch.randn_like(audio) if noise is None else torch.as_tensor(noise, dtype=torch.float32)
+    audio = audio + nz * 0.001
+    prob = model.probabilities(audio, hop=320, batch_size=512)
+    if decoder == "viterbi" and model.ops.on_gpu:      # the DP on the device (one block per 512-frame decoding batch)
+        lt = torch.from_numpy(np.log(_transition() + np.finfo(np.float32).tiny)).to(prob.device)
+        bins = model.ops.viterbi_decode(prob, lt, 512, _frequency_to_bins(50.0), _frequency_to_bins(1000.0, ceil=True))
+        pitch = bins_to_hz(bins, dither)[None].float()
+    else:
+        prob, out = prob.cpu(), []
+        for i in range(0, prob.shape[0], 512):         # crepe/core.py:683-686: decoding restarts with every batch
+            d = None if dither is None else np.asarray(dither)[i:i + 512]
+            out.append(decode(prob[i:i + 512], 50.0, 1000.0, decoder, d))
+        pitch = torch.cat(out)[None].float()
+    pitch = torch.from_numpy(np.repeat(pitch.numpy(), 2, -1))        # 320 -> 160 * 2 (:95)
+    return mean_filter(pitch, 5).squeeze(0).numpy()
+
+
+def save_csv_pitch(pitch, path):
+    """pitch/inference.py:102-110: one line per 10 ms frame, ``<m>m <s>s <ms>,<int Hz>``."""
+    with open(path, "w", encoding="utf-8") as f:
+        for i in range(len(pitch)):
+            t = i * 10
+            minute = t // 60000
+            seconds = (t - minute * 60000) // 1000
+            millisecond = t % 1000
+            print(f"{minute}m {seconds}s {millisecond:3d},{int(pitch[i])}", file=f)
+
+
+def load_csv_pitch(path):
+    """pitch/inference.py:113-119."""
+    pitch = []
+    with open(path, "r", encoding="utf-8") as f:
+        for line in f.readlines():
+            pitch.append(int(line.strip().split(",")[-1]))
+    return pitch

@@ -236,3 +236,26 @@ class HubertWeights:
         # heads: the reference fixes 12 x 64 (hubert_model.py:21); smaller test models keep head_dim 16
         self.heads = 12 if self.E == 768 else self.E // 16
         self.proj_w, self.proj_b = f(pack_conv(sd["proj.weight"].unsqueeze(-1))), f(sd["proj.bias"])
+
+
+class CrepeWeights:
+    """Packed ``crepe.Crepe`` parameters (crepe/model.py state-dict keys): Conv2d [out, in, k, 1] -> implicit-GEMM
+    operand [out, k*in]; eval-mode BatchNorm2d (eps 0.0010000000474974513) -> per-channel scale / shift."""
+
+    def __init__(self, sd, device, eps=0.0010000000474974513):
+        f = lambda t: t.float().to(device).contiguous()
+        self.layers = []
+        i = 1
+        while f"conv{i}.weight" in sd:
+            w = sd[f"conv{i}.weight"].float()[:, :, :, 0]                       # [out, in, k]
+            if i == 1:      # in == 1: k = 512 taps read as 128 taps x 4 "channels"; the flat order is already tap-major
+                packed = w[:, 0, :].contiguous()
+            else:
+                packed = pack_conv(w)
+            g, b = sd[f"conv{i}_BN.weight"].float(), sd[f"conv{i}_BN.bias"].float()
+            mu, var = sd[f"conv{i}_BN.running_mean"].float(), sd[f"conv{i}_BN.running_var"].float()
+            scale = g / torch.sqrt(var + eps)
+            self.layers.append(dict(w=f(packed), b=f(sd[f"conv{i}.bias"]), scale=f(scale), shift=f(b - mu * scale)))
+            i += 1
+        self.fc_w = f(pack_conv(sd["classifier.weight"].float().unsqueeze(-1)))
+        self.fc_b = f(sd["classifier.bias"])

@@ -229,3 +229,27 @@ def make_hubert_state(dims=None, seed=2468):
     sd["proj.bias"] = r.normal(d["proj"], std=0.05)
     sd["label_embedding.weight"] = r.normal(100, d["proj"])
     return sd
+
+
+CREPE_CAPACITY = {"full": ([1, 1024, 128, 128, 128, 256], [1024, 128, 128, 128, 256, 512], 2048),
+                  "tiny": ([1, 128, 16, 16, 16, 32], [128, 16, 16, 16, 32, 64], 256)}
+
+
+def make_crepe_state(capacity="full", seed=1357):
+    """``crepe.Crepe(capacity).state_dict()`` key layout (crepe/model.py:14-101), seeded; BatchNorm running statistics are
+    drawn non-trivially (eval-mode BatchNorm is the affine map they define)."""
+    cin, cout, feat = CREPE_CAPACITY[capacity]
+    r = _Rng(seed)
+    sd = {}
+    for i, (a, b) in enumerate(zip(cin, cout), start=1):
+        k = 512 if i == 1 else 64
+        sd[f"conv{i}.weight"] = r.normal(b, a, k, 1, std=1.4 / math.sqrt(a * k))
+        sd[f"conv{i}.bias"] = r.normal(b, std=0.05)
+        sd[f"conv{i}_BN.weight"] = r.uniform(b, lo=0.6, hi=1.4)
+        sd[f"conv{i}_BN.bias"] = r.normal(b, std=0.1)
+        sd[f"conv{i}_BN.running_mean"] = r.normal(b, std=0.2, mean=0.3)
+        sd[f"conv{i}_BN.running_var"] = r.uniform(b, lo=0.5, hi=1.5)
+        sd[f"conv{i}_BN.num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
+    sd["classifier.weight"] = r.normal(360, feat, std=2.0 / math.sqrt(feat))
+    sd["classifier.bias"] = r.normal(360, std=0.1)
+    return sd
