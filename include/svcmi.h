@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SVCMI_ABI_VERSION 10
+#define SVCMI_ABI_VERSION 11
 
 enum svcmi_status { SVCMI_OK = 0, SVCMI_EINVAL = -1, SVCMI_EUNSUPPORTED = -2, SVCMI_EALIGN = -3 };
 
@@ -268,6 +268,18 @@ int svcmi_bn_maxpool2_f32(const float* x, const float* scale, const float* shift
  * ptr_scratch: frames*360 int16.  path: [frames] decoded bins. */
 int svcmi_viterbi_decode(const float* prob, const double* log_trans, float* lp_scratch, int16_t* ptr_scratch, int32_t* path,
                          int32_t frames, int32_t batch_frames, int32_t minidx, int32_t maxidx, void* stream);
+
+/* Feature retrieval (row N4; feature_retrieval/index.py:57-94 -- faiss search_and_reconstruct + the RVC weighting):
+ *   row_sqnorm: out[r] = sum_c x[r, c]^2 (the |b|^2 term of the bank, computed once per index).
+ *   knn_blend:  for every query row i < t: the k (<= 8) stored vectors with the smallest squared L2 distance, ranked by
+ *               |x|^2 + bank_sq[j] - 2*dots[i, j] with dots = X * Bank^T from svcmi_conv_gemm_f32 (ties -> smaller j);
+ *               their distances are re-measured as sum_c (x - b)^2, weight_q = (1/dist_q)^2 / sum_q' (1/dist_q')^2, and
+ *               out[i, :] = (1 - ratio) * x[i, :] + ratio * sum_q weight_q * bank[nn_q, :].
+ *               An exact search, i.e. faiss IVF-Flat with nprobe = nlist (the reference's nprobe = 1 is its approximation). */
+int svcmi_row_sqnorm_f32(const float* x, int32_t ldx, int64_t rows, int32_t d, float* out, void* stream);
+int svcmi_knn_blend_f32(const float* x, int32_t ldx, const float* bank, int32_t ldb, const float* dots, int64_t ldd,
+                        const float* bank_sq, float* out, int32_t ldo, int32_t t, int32_t n, int32_t d, int32_t k,
+                        float ratio, void* stream);
 
 /* int16 side output, vits_decoder/generator.py:167-173: clamp(32768*x, -32768, 32767) truncated to short. */
 int svcmi_source2wav_i16(const float* x, int16_t* y, int64_t n, void* stream);

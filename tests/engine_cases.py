@@ -87,6 +87,42 @@ def check_svc_infer_golden(ops, device, tol=TIGHT):
     return errs
 
 
+def check_svc_infer_retrieval(ops, device, T=90, tol=2e-4, check_changed=True):
+    """svc_infer with the on-device kNN blend (svcmi.feature_retrieval) vs the same engine fed through a CPU IRetrieval
+    hook that runs the retrieval oracle -- checks the wiring of row N4 into the chunk loop (features stay on the device,
+    same chunk slices), the blend itself being covered by kernel_cases.check_knn_blend."""
+    from oracle import retrieval_oracle as RO
+    from svcmi import IRetrieval, svc_infer
+    from svcmi.feature_retrieval import KnnFeatureIndex, KnnIndexRetrieval
+    hp = C.tiny_hp()
+    m, _ = make_model(hp, ops, device)
+    d = I.synth_clip(T=T, hp=hp, seed=5, B=1)
+    gen = torch.Generator().manual_seed(9)
+    banks = {"ppg": torch.randn(400, hp.vits.ppg_dim, generator=gen).numpy(), "vec": torch.randn(333, hp.vits.vec_dim, generator=gen).numpy()}
+    enc_noises = [torch.randn(1, hp.vits.inter_channels, ce - cs, generator=gen) for (cs, ce, _, _) in O.chunk_schedule(T, 320)]
+    noise = {"rand_ini": d["rand_ini"], "src_noise": d["src_noise"], "enc_noises": enc_noises}
+
+    class OracleHook(IRetrieval):
+        def retriv_whisper(self, vec):
+            assert vec.device.type == "cpu"
+            return torch.from_numpy(RO.retriv(vec.numpy(), banks["ppg"], 0.5, 3))
+
+        def retriv_hubert(self, vec):
+            return torch.from_numpy(RO.retriv(vec.numpy(), banks["vec"], 0.5, 3))
+
+    knn = KnnIndexRetrieval(hubert_index=KnnFeatureIndex(banks["vec"], 0.5, 3, device=device, ops=ops),
+                            whisper_index=KnnFeatureIndex(banks["ppg"], 0.5, 3, device=device, ops=ops))
+    args = (d["spk"][0], d["pit"][0], d["ppg"][0], d["vec"][0], hp, device)
+    got = svc_infer(m, knn, *args, noise=noise, write_pit_wav=False)
+    want = svc_infer(m, OracleHook(), *args, noise=noise, write_pit_wav=False)
+    err = float(np.abs(got - want).max())
+    assert err <= tol, err
+    if check_changed:      # the blend actually changed the features
+        plain = svc_infer(m, None, *args, noise=noise, write_pit_wav=False)
+        assert float(np.abs(got - plain).max()) > 100 * tol
+    return err
+
+
 def check_logmel_golden(ops, device, tol=2e-4):
     """GPU log-mel front-end (svcmi.whisper.audio) vs the reference's own log_mel_spectrogram (golden fixture)."""
     from oracle import audio_oracle as A

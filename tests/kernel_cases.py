@@ -138,6 +138,26 @@ def check_viterbi(ops, device, frames=70, batch_frames=32):
     assert got.shape == want.shape and (got == want).mean() >= 0.99, float((got == want).mean())
 
 
+def check_knn_blend(ops, device, t=37, n=301, d=64, k=3, ratio=0.5):
+    """GEMM scores + knn_blend through the host index class vs the exhaustive-search restatement of faiss + the RVC
+    weighting (oracle/retrieval_oracle.py).  fp32 round-off only: the winners' distances are re-measured exactly."""
+    from oracle import retrieval_oracle as RO
+    from svcmi.feature_retrieval import KnnFeatureIndex
+    g = _g(97 + t + n + k)
+    centres = torch.randn(8, d, generator=g) * 2.0
+    bank = (centres[torch.randint(0, 8, (n,), generator=g)] + torch.randn(n, d, generator=g)).numpy()
+    feats = (centres[torch.randint(0, 8, (t,), generator=g)] + torch.randn(t, d, generator=g)).numpy()
+    index = KnnFeatureIndex(bank, ratio, k, device=device, ops=ops)
+    _close(index.bank_sq, torch.from_numpy((bank.astype(np.float64) ** 2).sum(1)).float(), 2e-6, "row_sqnorm")
+    want = torch.from_numpy(RO.retriv(feats, bank, ratio, k))
+    got = index.retriv(feats)
+    assert isinstance(got, np.ndarray) and got.dtype == np.float32
+    _close(torch.from_numpy(got), want, 2e-5, f"knn_blend t={t} n={n} d={d} k={k}")
+    got_t = index.retriv(torch.from_numpy(feats).to(device))      # tensors stay on their device
+    assert got_t.device.type == torch.device(device).type
+    _close(got_t, want, 2e-5, "knn_blend tensor")
+
+
 def check_channel_norm_gelu(ops, device, B=2, T=700, c=32):
     g = _g(5 + c)
     x = torch.randn(B, T, c, generator=g) * 2.0 + 0.7

@@ -32,3 +32,7 @@ def test_hubert_tiny_matches_oracle(ops):
 
 def test_crepe_tiny_matches_oracle(ops):
     print(E.check_crepe_against_oracle(ops, "cpu", "tiny", n=1600))
+
+
+def test_svc_infer_with_knn_retrieval(ops):
+    print(E.check_svc_infer_retrieval(ops, "cpu", T=24, check_changed=False))

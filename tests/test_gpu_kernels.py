@@ -63,6 +63,12 @@ def test_channel_norm_gelu(ops, T, c):
     K.check_channel_norm_gelu(ops, "cuda", T=T, c=c)
 
 
+@pytest.mark.parametrize("t,n,d,k,ratio", [(2510, 50000, 1280, 3, 0.5), (2510, 50001, 256, 3, 0.5), (17, 9, 16, 8, 0.25),
+                                           (300, 4097, 256, 1, 1.0)])
+def test_knn_blend(ops, t, n, d, k, ratio):
+    K.check_knn_blend(ops, "cuda", t, n, d, k, ratio)
+
+
 def test_viterbi_decode(ops):
     K.check_viterbi(ops, "cuda", frames=1100, batch_frames=512)
 

@@ -59,6 +59,11 @@ def test_channel_norm_gelu(ops, T, c):
     K.check_channel_norm_gelu(ops, "cpu", T=T, c=c)
 
 
+@pytest.mark.parametrize("t,n,d,k,ratio", [(9, 70, 32, 3, 0.5), (5, 300, 256, 1, 1.0), (3, 9, 16, 8, 0.25)])
+def test_knn_blend(ops, t, n, d, k, ratio):
+    K.check_knn_blend(ops, "cpu", t, n, d, k, ratio)
+
+
 def test_viterbi_decode(ops):
     K.check_viterbi(ops, "cpu", frames=40, batch_frames=16)
 

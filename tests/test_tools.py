@@ -1,0 +1,138 @@
+"""Row N4 host tooling: checkpoint export / merge / speaker mix (formats the engine loads), the retrieval host logic,
+and -- in the build container -- the same functions of the reference run side by side."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from svcmi import SynthesizerInfer, load_svc_model, tools
+from workload import config as C
+from workload import weights as W
+
+
+def _train_ckpt(tmp_path, seed=0):
+    hp = C.tiny_hp()
+    sd = W.make_vits_state(hp, seed=seed)
+    full = dict(sd)
+    full["enc_q.pre.weight"] = torch.randn(4, 4, 1)             # posterior encoder: training only
+    dropped = next(k for k in sd if k.startswith("dec.") and k.endswith("bias"))
+    del full[dropped]                                            # a key the checkpoint lacks keeps its init value
+    path = tmp_path / f"train_{seed}.pt"
+    torch.save({"model_g": full, "model_d": {"d.weight": torch.ones(2)}, "optim_g": {}, "optim_d": {}, "step": 7, "epoch": 1,
+                "hp_str": "x"}, path)
+    return hp, sd, path, dropped
+
+
+def test_export_checkpoint_format(tmp_path):
+    hp, sd, path, dropped = _train_ckpt(tmp_path)
+    out = tmp_path / "sovits5.0.pth"
+    tools.export_checkpoint(hp, str(path), str(out))
+    saved = torch.load(out, map_location="cpu")
+    assert list(saved.keys()) == ["model_g"]
+    model = SynthesizerInfer(hp.data.filter_length // 2 + 1, hp.data.segment_size // hp.data.hop_length, hp)
+    assert list(saved["model_g"].keys()) == list(model.state_dict().keys())        # no enc_q, reference key order
+    for k, v in saved["model_g"].items():
+        if k != dropped:
+            assert torch.equal(v, sd[k]), k
+    assert torch.equal(saved["model_g"][dropped], model.state_dict()[dropped])
+    load_svc_model(str(out), model)                                                 # and the engine's loader takes it
+
+
+def test_save_pretrain(tmp_path):
+    _, _, path, _ = _train_ckpt(tmp_path)
+    out = tmp_path / "pre.pth"
+    tools.save_pretrain(str(path), str(out))
+    assert sorted(torch.load(out, map_location="cpu").keys()) == ["model_d", "model_g"]
+
+
+def test_merge_and_average(tmp_path):
+    hp = C.tiny_hp()
+    a, b = W.make_vits_state(hp, seed=1), W.make_vits_state(hp, seed=2)
+    m = tools.merge_model(a, b, 0.3)
+    k = "flow.flows.0.enc.in_layers.0.weight_v" if "flow.flows.0.enc.in_layers.0.weight_v" in a else next(iter(a))
+    assert torch.equal(m[k], 0.3 * a[k] + (1 - 0.3) * b[k])
+    avg = tools.average_model([a, b])
+    assert torch.allclose(avg[k], (a[k] + b[k]) / 2)
+    with pytest.raises(AssertionError):
+        tools.merge_model(a, b, 1.0)
+    tools.save_model_g(m, tmp_path / "m.pth")
+    assert torch.equal(tools.load_model_g(str(tmp_path / "m.pth"))[k], m[k])
+
+
+def test_mix_speakers(tmp_path):
+    rng = np.random.default_rng(0)
+    p = []
+    for i in range(3):
+        p.append(str(tmp_path / f"s{i}.npy"))
+        np.save(p[-1], rng.standard_normal(256).astype(np.float32))
+    conf = {p[0]: 0, p[1]: 0.5, p[2]: 0.5}
+    eva = tools.mix_speakers(conf, str(tmp_path / "eva.spk.npy"))
+    assert eva.dtype == np.float64 and eva.shape == (256,)
+    want = np.zeros(256)
+    for path, v in conf.items():      # svc_eva.py:15-19: float32 product, float64 running sum
+        want = want + np.load(path) * v
+    assert np.array_equal(np.load(tmp_path / "eva.spk.npy"), want)
+
+
+@pytest.mark.needs_reference
+def test_merge_matches_reference(tmp_path):
+    spec = importlib.util.spec_from_file_location("ref_svc_merge", "/root/reference/svc_merge.py")
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    hp = C.tiny_hp()
+    a, b = W.make_vits_state(hp, seed=3), W.make_vits_state(hp, seed=4)
+    want, got = ref.merge_model(a, b, 0.7), tools.merge_model(a, b, 0.7)
+    assert list(want.keys()) == list(got.keys()) and all(torch.equal(want[k], got[k]) for k in want)
+    want, got = ref.average_model([a, b, a]), tools.average_model([a, b, a])
+    assert all(torch.equal(want[k], got[k]) for k in want)
+
+
+@pytest.mark.needs_reference
+def test_export_matches_reference(tmp_path):
+    """The reference's svc_export.load_model / save_model on ITS SynthesizerInfer vs export_checkpoint."""
+    from oracle import ref_import as R
+    hp, sd, path, dropped = _train_ckpt(tmp_path, seed=5)
+    ref_model = R.ref_synthesizer(hp, sd)                       # reference nn.Module with the seeded weights
+    saved = torch.load(path, map_location="cpu")["model_g"]
+    want = {k: (saved[k] if k in saved else v) for k, v in ref_model.state_dict().items()}     # svc_export.py:18-23
+    got = tools.export_checkpoint(hp, str(path), str(tmp_path / "o.pth"))
+    assert list(got.keys()) == list(want.keys())
+    for k in want:
+        if k != dropped:
+            assert torch.equal(got[k], want[k]), k
+
+
+# ---------------------------------------------------------------------------------------------- retrieval host logic
+def test_retrieval_oracle_weighting():
+    """k = 1 returns the stored vector itself at ratio 1; a duplicated neighbour set gives equal weights."""
+    from oracle import retrieval_oracle as RO
+    rng = np.random.default_rng(1)
+    bank = rng.standard_normal((50, 8)).astype(np.float32)
+    x = rng.standard_normal((6, 8)).astype(np.float32)
+    out = RO.retriv(x, bank, 1.0, 1)
+    ids = np.argmin(((x[:, None] - bank[None]) ** 2).sum(-1), axis=1)
+    assert np.allclose(out, bank[ids], atol=1e-6)
+    assert np.allclose(RO.retriv(x, bank, 0.0, 3), x)
+    w = RO.weight_nearest_vectors(np.stack([bank[:2]] * 6), np.full((6, 2), 4.0, np.float32))
+    assert np.allclose(w, bank[:2].mean(0), atol=1e-6)
+
+
+def test_retrieval_cli_paths(tmp_path, monkeypatch):
+    from svcmi import feature_retrieval as FR
+    from svcmi.svc_inference import DummyRetrieval, build_parser
+    assert FR.get_speaker_name_from_path("configs/singers/singer0001.npy") == "singer0001"
+    args = build_parser().parse_args(["--config", "c", "--model", "m", "--wave", "w", "--spk", "s.spk.npy"])
+    assert isinstance(FR.create_retrival(args), DummyRetrieval)
+    assert args.retrieval_ratio == 0.5 and args.n_retrieval_vectors == 3 and args.retrieval_index_prefix == ""
+    with pytest.raises(ValueError):
+        FR.KnnFeatureIndex(np.zeros((4, 8), np.float32), 0.5, 0, ops=object())
+    with pytest.raises(ValueError):
+        FR.KnnFeatureIndex(np.zeros((4, 8), np.float32), 1.5, 1, ops=object())
+    d = tmp_path / "feat" / "spk"
+    os.makedirs(d)
+    np.save(d / "a.npy", np.ones((3, 8), np.float32))
+    np.save(d / "b.npy", np.zeros((2, 8), np.float32))
+    bank = FR.build_index_bank(tmp_path / "feat", tmp_path / "bank.npy")
+    assert bank.shape == (5, 8) and np.array_equal(np.load(tmp_path / "bank.npy"), bank)

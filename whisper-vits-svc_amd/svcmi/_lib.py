@@ -8,7 +8,7 @@ DEFAULT_LIB = os.path.join(HERE, "libsvcmi.so")
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_MISH, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4, 5
 CONV_ACCUMULATE, CONV_MASK_IN, CONV_MASK_OUT, CONV_PARTIALS = 1, 2, 4, 8
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class ConvDesc(Structure):
@@ -56,6 +56,8 @@ SIGNATURES = {
     "svcmi_crepe_frames_f32": (c_int, [_P, _L, _I, _I, _I, _P, _I, _P]),
     "svcmi_bn_maxpool2_f32": (c_int, [_P, _P, _P, _P, _L, _I, _I, _I, _P]),
     "svcmi_viterbi_decode": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "svcmi_row_sqnorm_f32": (c_int, [_P, _I, _L, _I, _P, _P]),
+    "svcmi_knn_blend_f32": (c_int, [_P, _I, _P, _I, _P, _L, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "svcmi_source2wav_i16": (c_int, [_P, _P, _L, _P]),
 }
 

@@ -270,6 +270,23 @@ class Ops:
                    minidx, maxidx, self._stream())
         return path
 
+    # ------------------------------------------------------------------ feature retrieval
+    def row_sqnorm(self, x):
+        """x [rows, d] -> [rows] squared L2 norms."""
+        self._chk(x)
+        out = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+        self._call("svcmi_row_sqnorm_f32", _ptr(x), x.stride(0), x.shape[0], x.shape[1], _ptr(out), self._stream())
+        return out
+
+    def knn_blend(self, x, bank, dots, bank_sq, k, ratio, out=None):
+        """x [t, d], bank [n, d], dots [t, >= n] = x @ bank.T -> (1 - ratio) * x + ratio * weighted k-NN mean."""
+        self._chk(x, bank, dots, bank_sq, out)
+        if out is None:
+            out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        self._call("svcmi_knn_blend_f32", _ptr(x), x.stride(0), _ptr(bank), bank.stride(0), _ptr(dots), dots.stride(0),
+                   _ptr(bank_sq), _ptr(out), out.stride(0), x.shape[0], bank.shape[0], x.shape[1], k, ratio, self._stream())
+        return out
+
     def source2wav(self, x):
         self._chk(x)
         x = x.contiguous()

@@ -97,7 +97,9 @@ def svc_infer(model, retrieval, spk, pit, ppg, vec, hp, device, noise=None, writ
     pieces = []
     for i, (cs, ce, cso, ceo) in enumerate(chunk_schedule(n, hop)):
         sub_ppg, sub_vec = ppg[cs:ce], vec[cs:ce]
-        if not passthrough:      # user hook works on CPU tensors (feature_retrieval/retrieval.py:11-28)
+        if getattr(retrieval, "on_device", False):      # svcmi.feature_retrieval.KnnIndexRetrieval: the GPU kNN blend
+            sub_ppg, sub_vec = retrieval.retriv_whisper(sub_ppg), retrieval.retriv_hubert(sub_vec)
+        elif not passthrough:      # user hook works on CPU tensors (feature_retrieval/retrieval.py:11-28)
             sub_ppg = retrieval.retriv_whisper(sub_ppg.cpu()).to(dev)
             sub_vec = retrieval.retriv_hubert(sub_vec.cpu()).to(dev)
         sub_len = torch.tensor([ce - cs], dtype=torch.int64)
@@ -163,8 +165,8 @@ def main(args):
     hp = load_config(args.config)
     model = SynthesizerInfer(hp.data.filter_length // 2 + 1, hp.data.segment_size // hp.data.hop_length, hp)
     load_svc_model(args.model, model)
-    if getattr(args, "enable_retrieval", False):
-        raise NotImplementedError("faiss feature retrieval (row N4) is not part of svcmi; pass an IRetrieval to svc_infer")
+    from .feature_retrieval import create_retrival
+    retrieval = create_retrival(args, device)      # DummyRetrieval unless --enable-retrieval (:25-58)
     model.eval()
     model.to(device)
     spk = torch.FloatTensor(np.load(args.spk))
@@ -172,7 +174,7 @@ def main(args):
     vec = torch.FloatTensor(np.repeat(np.load(args.vec), 2, 0))
     print("pitch shift: ", args.shift)
     pit = torch.FloatTensor(shift_pitch(pitch_inf.load_csv_pitch(args.pit), args.shift))
-    out_audio = svc_infer(model, DummyRetrieval(), spk, pit, ppg, vec, hp, device)
+    out_audio = svc_infer(model, retrieval, spk, pit, ppg, vec, hp, device)
     write("svc_out.wav", hp.data.sampling_rate, out_audio)
     return out_audio
 
@@ -188,7 +190,13 @@ def build_parser():
     p.add_argument("--vec", type=str, help="Path of hubert vector.")
     p.add_argument("--pit", type=str, help="Path of pitch csv file.")
     p.add_argument("--shift", type=int, default=0, help="Pitch shift key.")
-    p.add_argument("--enable-retrieval", action="store_true", help="(not supported: faiss retrieval is out of scope)")
+    p.add_argument("--enable-retrieval", action="store_true", help="Enable index feature retrieval")
+    p.add_argument("--retrieval-index-prefix", default="",
+                   help="retrieval index file prefix. Will load file %%prefix%%hubert.index.npy/%%prefix%%whisper.index.npy")
+    p.add_argument("--retrieval-ratio", type=float, default=.5, help="ratio of feature retrieval effect. Must be in range 0..1")
+    p.add_argument("--n-retrieval-vectors", type=int, default=3, help="get n nearest vectors from retrieval index (1..8)")
+    p.add_argument("--hubert-index-path", required=False, help="path to a hubert feature bank (.npy [n, 256])")
+    p.add_argument("--whisper-index-path", required=False, help="path to a whisper feature bank (.npy [n, 1280])")
     p.add_argument("--whisper", type=str, default=os.path.join("whisper_pretrain", "large-v2.pt"))
     p.add_argument("--hubert", type=str, default=os.path.join("hubert_pretrain", "hubert-soft-0d54a1f4.pt"))
     p.add_argument("--crepe", type=str, default=os.path.join("crepe", "assets", "full.pth"))
