@@ -273,7 +273,8 @@ int svcmi_viterbi_decode(const float* prob, const double* log_trans, float* lp_s
  *   row_sqnorm: out[r] = sum_c x[r, c]^2 (the |b|^2 term of the bank, computed once per index).
  *   knn_blend:  for every query row i < t: the k (<= 8) stored vectors with the smallest squared L2 distance, ranked by
  *               |x|^2 + bank_sq[j] - 2*dots[i, j] with dots = X * Bank^T from svcmi_conv_gemm_f32 (ties -> smaller j);
- *               their distances are re-measured as sum_c (x - b)^2, weight_q = (1/dist_q)^2 / sum_q' (1/dist_q')^2, and
+ *               the 8 best-ranked candidates are re-measured as sum_c (x - b)^2 and the k nearest of those kept (so fp32
+ *               cancellation in the ranking cannot swap near-equidistant neighbours), weight_q = (1/dist_q)^2 / sum_q' (1/dist_q')^2, and
  *               out[i, :] = (1 - ratio) * x[i, :] + ratio * sum_q weight_q * bank[nn_q, :].
  *               An exact search, i.e. faiss IVF-Flat with nprobe = nlist (the reference's nprobe = 1 is its approximation). */
 int svcmi_row_sqnorm_f32(const float* x, int32_t ldx, int64_t rows, int32_t d, float* out, void* stream);

@@ -148,6 +148,8 @@ def check_knn_blend(ops, device, t=37, n=301, d=64, k=3, ratio=0.5):
     bank = (centres[torch.randint(0, 8, (n,), generator=g)] + torch.randn(n, d, generator=g)).numpy()
     feats = (centres[torch.randint(0, 8, (t,), generator=g)] + torch.randn(t, d, generator=g)).numpy()
     index = KnnFeatureIndex(bank, ratio, k, device=device, ops=ops)
+    if 128 < n < 10000:
+        index._bank_block = 128          # exercise the multi-launch score GEMM over bank blocks
     _close(index.bank_sq, torch.from_numpy((bank.astype(np.float64) ** 2).sum(1)).float(), 2e-6, "row_sqnorm")
     want = torch.from_numpy(RO.retriv(feats, bank, ratio, k))
     got = index.retriv(feats)

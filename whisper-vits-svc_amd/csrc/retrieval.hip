@@ -3,8 +3,9 @@
 // content frame and mixes their 1/d^2-weighted mean into the frame.  Here the candidate scores of ALL stored vectors
 // come from one svcmi_conv_gemm_f32 launch (dots = X * Bank^T, the only O(t*n*d) work), and this file holds the
 // HBM-bound rest: per-row squared norms of the bank, and one block per query frame that streams its row of dots once
-// (coalesced), keeps a per-thread sorted shortlist, merges the shortlists through LDS, re-measures the k winners with
-// exact differences (so the weights do not inherit the |x|^2 + |b|^2 - 2xb cancellation) and writes the blended frame.
+// (coalesced), keeps a per-thread sorted shortlist, merges the shortlists through LDS into 8 candidates, re-measures those with
+// exact differences (so neither the choice of the k nearest nor the weights inherit the |x|^2 + |b|^2 - 2xb
+// cancellation) and writes the blended frame.
 #include "svcmi_rt.h"
 #include "../../include/svcmi.h"
 
@@ -87,9 +88,12 @@ __global__ __launch_bounds__(KNN_TPB) void knn_blend_kernel(const float* x, int 
 #pragma unroll
     for (int q = 0; q < KNN_KMAX; ++q) { cand_s[q * KNN_TPB + tid] = bs[q]; cand_i[q * KNN_TPB + tid] = bi[q]; }
 
-    // k rounds of block arg-min over the shortlist heads; the owner of the winner advances its head
+    // kc rounds of block arg-min over the shortlist heads; the owner of the winner advances its head.  kc = KNN_KMAX >= k
+    // candidates are kept: fp32 scores of near-equidistant neighbours (1e-6 relative apart) can swap the k-th and
+    // (k+1)-th, so the final k are chosen below from exact distances.
+    const int kc = n < KNN_KMAX ? n : KNN_KMAX;
     int head = 0;
-    for (int r = 0; r < k; ++r) {
+    for (int r = 0; r < kc; ++r) {
         float s = head < KNN_KMAX ? cand_s[head * KNN_TPB + tid] : __builtin_inff();
         int i = head < KNN_KMAX ? cand_i[head * KNN_TPB + tid] : KNN_NONE;
         const float my_s = s;
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(KNN_TPB) void knn_blend_kernel(const float* x, int 
         __syncthreads();
     }
 
-    // exact squared distances of the winners
+    // exact squared distances of the candidates
     float acc[KNN_KMAX];
 #pragma unroll
     for (int q = 0; q < KNN_KMAX; ++q) acc[q] = 0.f;
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(KNN_TPB) void knn_blend_kernel(const float* x, int 
         const float4 v = *reinterpret_cast<const float4*>(xr + c);
 #pragma unroll
         for (int q = 0; q < KNN_KMAX; ++q) {
-            if (q < k) {
+            if (q < kc) {
                 const float4 b = *reinterpret_cast<const float4*>(bank + (long long)sel[q] * ldb + c);
                 const float dx = v.x - b.x, dy = v.y - b.y, dz = v.z - b.z, dw = v.w - b.w;
                 acc[q] += (dx * dx + dy * dy) + (dz * dz + dw * dw);
@@ -132,15 +136,22 @@ __global__ __launch_bounds__(KNN_TPB) void knn_blend_kernel(const float* x, int 
         if (lane == 0) red_s[wave * KNN_KMAX + q] = t;
     }
     __syncthreads();
-    if (tid == 0) {      // weight = (1/d)^2, normalised over the k neighbours (index.py:86-88)
-        float w[KNN_KMAX], wsum = 0.f;
+    if (tid == 0) {
+        float dist[KNN_KMAX];
+        int id[KNN_KMAX];
+        for (int q = 0; q < kc; ++q) {      // insertion sort by (exact distance, index): the k nearest, ascending like faiss
+            float dq = (red_s[q] + red_s[KNN_KMAX + q]) + (red_s[2 * KNN_KMAX + q] + red_s[3 * KNN_KMAX + q]);
+            int iq = sel[q], pos = q;
+            while (pos > 0 && knn_less(dq, iq, dist[pos - 1], id[pos - 1])) { dist[pos] = dist[pos - 1]; id[pos] = id[pos - 1]; --pos; }
+            dist[pos] = dq; id[pos] = iq;
+        }
+        float w[KNN_KMAX], wsum = 0.f;      // weight = (1/d)^2, normalised over the k neighbours (index.py:86-88)
         for (int q = 0; q < k; ++q) {
-            const float dist = (red_s[q] + red_s[KNN_KMAX + q]) + (red_s[2 * KNN_KMAX + q] + red_s[3 * KNN_KMAX + q]);
-            const float inv = 1.0f / dist;
+            const float inv = 1.0f / dist[q];
             w[q] = inv * inv;
             wsum += w[q];
         }
-        for (int q = 0; q < k; ++q) selw[q] = w[q] / wsum;
+        for (int q = 0; q < k; ++q) { selw[q] = w[q] / wsum; sel[q] = id[q]; }
     }
     __syncthreads();
     const float keep = 1.0f - ratio;

@@ -40,6 +40,7 @@ class KnnFeatureIndex:
         self.bank_sq = self.ops.row_sqnorm(self.bank)
         self._ratio = float(ratio)
         self._n_nearest = int(n_nearest_vectors)
+        self._bank_block = max(64, ((1 << 27) - 1) // self.bank.shape[1] // 64 * 64)
 
     @property
     def ntotal(self):
@@ -68,7 +69,9 @@ class KnnFeatureIndex:
         dots = torch.empty(rows, ldd, dtype=torch.float32, device=x.device)
         for s in range(0, t, rows):
             e = min(t, s + rows)
-            self.ops.conv(x[None, s:e], self.bank, out=dots[None, :e - s], n_out=n)
+            for b0 in range(0, n, self._bank_block):      # one GEMM launch addresses < 2^27 weight elements
+                b1 = min(n, b0 + self._bank_block)
+                self.ops.conv(x[None, s:e], self.bank[b0:b1], out=dots[None, :e - s, b0:b1], n_out=b1 - b0)
             self.ops.knn_blend(x[s:e], self.bank, dots[:e - s], self.bank_sq, self._n_nearest, self._ratio, out=out[s:e])
         return out.cpu().numpy() if as_numpy else out.to(src_device)
 
