@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SVCMI_ABI_VERSION 11
+#define SVCMI_ABI_VERSION 12
 
 enum svcmi_status { SVCMI_OK = 0, SVCMI_EINVAL = -1, SVCMI_EUNSUPPORTED = -2, SVCMI_EALIGN = -3 };
 
@@ -186,13 +186,26 @@ int svcmi_upsample_noise_f32(const float* x, const float* w_up, const float* b_u
                              int32_t taps, int32_t pad, int32_t u, int32_t cp, int64_t src_len, int32_t nz_k,
                              int32_t nz_stride, int32_t nz_pad, int32_t ldw_nz, void* stream);
 
+/* Output layer of the generator in one launch (vits_decoder/generator.py:196-199: activation_post, conv_post, tanh):
+ *   y[b, t] = tanh( sum_{k < ksize} sum_{ci < c} w[k*ld + ci] * S[b, t + k - (ksize-1)/2, ci] ),  S = SnakeAlias(x) zero-padded
+ * x: [batch][len][ld] time-major, w: conv_post.weight packed as one row (tap-major, ld floats per tap; no bias),
+ * y: [batch][len].  Supported: c == 10, ld == 12, ksize == 7 (svcmi_snake_post_supported); other widths use
+ * svcmi_snake_alias_f32 + svcmi_conv_gemm_f32. */
+int svcmi_snake_post_supported(int32_t c, int32_t ld, int32_t ksize);
+int svcmi_snake_post_f32(const float* x, const float* w, float* y, const float* alpha_log, const float* beta_log,
+                         const float* filt, int32_t batch, int32_t len, int32_t c, int32_t ld, int32_t ksize, void* stream);
+
 /* Development knob for the tuning scripts: "amp_tt" in {0 (default), 1, 2, 4} = time steps per thread of
  * svcmi_snake_conv_f32.  Results never depend on it.  Returns 0, or SVCMI_EINVAL for an unknown name/value. */
 int svcmi_tune_set(const char* name, int32_t value);
 
 /* WaveNet gate, vits/commons.py:126-133 with input_b == 0 (vits/modules.py:190-193):
- *   out[r, c] = tanh(a[r, c]) * sigmoid(a[r, h + c]),  c < h. */
-int svcmi_wn_gate_f32(const float* a, float* out, int64_t rows, int32_t h, int32_t lda, int32_t ldo, void* stream);
+ *   out[b, t, c] = tanh(v[b, t, c]) * sigmoid(v[b, t, h + c]),  c < h,  v = bias + sum_s a[b][s][t][:]
+ * a: `splits` slabs per batch item, [batch][splits][t][lda] -- the raw split-K partials of the in_layer convolution
+ * (SVCMI_CONV_PARTIALS, lda == 2h) summed here in slab order with the layer bias, so that the reduce pass, the bias and the
+ * gate are one launch; or the finished activations with splits == 1 (bias may be NULL). */
+int svcmi_wn_gate_f32(const float* a, const float* bias, float* out, int32_t batch, int32_t t, int32_t h, int32_t lda,
+                      int32_t ldo, int32_t splits, void* stream);
 
 /* WaveNet residual/skip bookkeeping, vits/modules.py:196-203, from rs = res_skip_layer(acts):
  *   !last: x = (x + rs[:, :h]) * mask ; skip (+)= rs[:, h:2h]        last: skip (+)= rs[:, :h]; skip *= mask

@@ -340,6 +340,23 @@ def check_snake_conv(ops, c_, device):
     assert float(got[..., c:].abs().max()) == 0.0 if ld > c else True
 
 
+def check_snake_post(ops, device, B=2, n=700):
+    """Fused output layer (SnakeAlias -> conv_post 10 -> 1, k = 7, no bias -> tanh) vs oracle SnakeAlias + torch conv1d."""
+    g = _g(4242 + n)
+    c, ld, k = 10, 12, 7
+    x = torch.zeros(B, n, ld)
+    x[..., :c] = torch.randn(B, n, c, generator=g) * 1.5
+    al, be = torch.zeros(ld), torch.zeros(ld)
+    al[:c], be[:c] = torch.randn(c, generator=g) * 0.3, torch.randn(c, generator=g) * 0.3
+    filt = W.kaiser_sinc_filter().view(-1)
+    w = torch.randn(1, c, k, generator=g) / math.sqrt(c * k)
+    s = O.snake_alias(x[..., :c].transpose(1, 2), al[:c], be[:c], filt)
+    ref = torch.tanh(F.conv1d(s, w, None, padding=(k - 1) // 2))[:, 0]
+    assert ops.snake_post_supported(c, ld, k) and not ops.snake_post_supported(2, 4, k)
+    got = ops.snake_post(x.to(device), al.to(device), be.to(device), filt.to(device), PW.pack_conv(w, cin_pad=ld).to(device), c=c, ksize=k)
+    _close(got, ref, 2e-5, f"snake_post n={n}")
+
+
 def check_flow_glue(ops, device):
     g = _g(11)
     B, T, H = 2, 13, 8
@@ -347,6 +364,9 @@ def check_flow_glue(ops, device):
     mask = (torch.arange(T)[None, :] < lengths[:, None]).float().unsqueeze(-1)
     a = torch.randn(B, T, 2 * H, generator=g)
     _close(ops.wn_gate(a.to(device)), torch.tanh(a[..., :H]) * torch.sigmoid(a[..., H:]), 1e-6, "gate")
+    slabs, gb = torch.randn(B, 3, T, 2 * H, generator=g), torch.randn(2 * H, generator=g)      # split-K slabs + bias
+    v = (slabs[:, 0] + slabs[:, 1]) + slabs[:, 2] + gb
+    _close(ops.wn_gate(slabs.to(device), bias=gb.to(device)), torch.tanh(v[..., :H]) * torch.sigmoid(v[..., H:]), 1e-6, "gate slabs")
     # update, not last
     rs, x, skip = torch.randn(B, T, 2 * H, generator=g), torch.randn(B, T, H, generator=g), torch.randn(B, T, H, generator=g)
     xd, sd = x.clone().to(device), skip.clone().to(device)

@@ -69,6 +69,11 @@ def test_knn_blend(ops, t, n, d, k, ratio):
     K.check_knn_blend(ops, "cuda", t, n, d, k, ratio)
 
 
+@pytest.mark.parametrize("n", [5, 700, 320000])
+def test_snake_post(ops, n):
+    K.check_snake_post(ops, "cuda", B=1 if n > 100000 else 2, n=n)
+
+
 def test_viterbi_decode(ops):
     K.check_viterbi(ops, "cuda", frames=1100, batch_frames=512)
 

@@ -64,6 +64,11 @@ def test_knn_blend(ops, t, n, d, k, ratio):
     K.check_knn_blend(ops, "cpu", t, n, d, k, ratio)
 
 
+@pytest.mark.parametrize("n", [5, 700])
+def test_snake_post(ops, n):
+    K.check_snake_post(ops, "cpu", B=2, n=n)
+
+
 def test_viterbi_decode(ops):
     K.check_viterbi(ops, "cpu", frames=40, batch_frames=16)
 

@@ -62,29 +62,12 @@ struct AmpArgs {
     float alpha;
 };
 
-// CP = padded channels (row length of x / y / res and of a weight tap), CR = real channels, KS = taps, G = channel
-// groups, TT = time steps per thread in the convolution (accumulators: TT x CO).  Small TT = small tiles = many
-// blocks: the activation phase is a long dependent chain per work item and needs >= 4 waves per SIMD to hide.
-template <int CP, int CR, int KS, int G, int TT>
-__global__ __launch_bounds__(TPB) void snake_conv_kernel(AmpArgs p) {
-    constexpr int TSUB = 4 / G;                       // time sub-tiles per block
-    constexpr int TB = TSUB * 64 * TT;                // output rows per block
-    constexpr int LS = (CP / 4) % 2 ? CP : CP + 4;    // LDS row stride: 4 * odd floats
-    constexpr int ROWS = TB + (KS - 1) * DMAX;
-    static_assert(G * CO >= CR && CP % 4 == 0 && CP >= CR, "channel split");
-    __shared__ __attribute__((aligned(16))) float S[ROWS * LS];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = SVCMI_UNIFORM((int)(tid >> 6));
-    const int b = blockIdx.y;
-    const int n = p.n, ld = p.ld, d = p.dil;
-    const int halo = (KS - 1) * d / 2;
-    const int t_blk = blockIdx.x * TB;                // first output row of the block
-    const int rows = TB + 2 * halo;                   // S rows used: S row r <-> time t_blk - halo + r
-    const float* xb = p.x + (long long)b * n * ld;
-
-    // ---- phase A: S = SnakeAlias(x) for the tile + halo; zero outside [0, n) and in the pad channels
-    {
+// S = SnakeAlias(x) for the rows [t_blk - halo, t_blk - halo + rows) of one batch item: zero outside [0, n) (the
+// convolution's zero padding) and in the pad channels.  Shared by the AMP half-step and the output layer.
+template <int CP, int CR, int LS>
+__device__ __forceinline__ void snake_tile(float* S, const float* xb, const float* alpha_log, const float* beta_log,
+                                           const float* filt, int n, int ld, int t_blk, int halo, int rows, int tid) {
+    struct { const float* alpha_log; const float* beta_log; const float* filt; } p = {alpha_log, beta_log, filt};
         float f[12];
 #pragma unroll
         for (int k = 0; k < 12; ++k) f[k] = p.filt[k];
@@ -139,7 +122,30 @@ __global__ __launch_bounds__(TPB) void snake_conv_kernel(AmpArgs p) {
             for (int r = 0; r < RT; ++r)
                 if (r0 + r < rows) S[(r0 + r) * LS + ch] = out[r];
         }
-    }
+}
+
+// CP = padded channels (row length of x / y / res and of a weight tap), CR = real channels, KS = taps, G = channel
+// groups, TT = time steps per thread in the convolution (accumulators: TT x CO).  Small TT = small tiles = many
+// blocks: the activation phase is a long dependent chain per work item and needs >= 4 waves per SIMD to hide.
+template <int CP, int CR, int KS, int G, int TT>
+__global__ __launch_bounds__(TPB) void snake_conv_kernel(AmpArgs p) {
+    constexpr int TSUB = 4 / G;                       // time sub-tiles per block
+    constexpr int TB = TSUB * 64 * TT;                // output rows per block
+    constexpr int LS = (CP / 4) % 2 ? CP : CP + 4;    // LDS row stride: 4 * odd floats
+    constexpr int ROWS = TB + (KS - 1) * DMAX;
+    static_assert(G * CO >= CR && CP % 4 == 0 && CP >= CR, "channel split");
+    __shared__ __attribute__((aligned(16))) float S[ROWS * LS];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = SVCMI_UNIFORM((int)(tid >> 6));
+    const int b = blockIdx.y;
+    const int n = p.n, ld = p.ld, d = p.dil;
+    const int halo = (KS - 1) * d / 2;
+    const int t_blk = blockIdx.x * TB;                // first output row of the block
+    const int rows = TB + 2 * halo;                   // S rows used: S row r <-> time t_blk - halo + r
+    const float* xb = p.x + (long long)b * n * ld;
+
+    snake_tile<CP, CR, LS>(S, xb, p.alpha_log, p.beta_log, p.filt, n, ld, t_blk, halo, rows, tid);
     __syncthreads();
 
     // ---- phase B: direct convolution from LDS with SGPR weights
@@ -271,6 +277,52 @@ __global__ __launch_bounds__(TPB) void upsample_noise_kernel(UpArgs p) {
     for (int n = 0; n < N; n += 4) *reinterpret_cast<float4*>(yr + n) = make_float4(acc[n], acc[n + 1], acc[n + 2], acc[n + 3]);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Output layer of the generator in one launch (vits_decoder/generator.py:196-199): activation_post -> conv_post (C -> 1
+// channel, 7 taps, no bias) -> tanh.  As SnakeAlias + a GEMM padded from 1 to 64 output columns this was 19 + 90 us
+// for 45 MFLOP; here the activated tile goes to LDS as above and a lane owns TT output samples.
+struct PostArgs {
+    const float* x; const float* w; float* y; const float* alpha_log; const float* beta_log; const float* filt;
+    int n, ld;
+};
+
+template <int CP, int CR, int KS, int TT>
+__global__ __launch_bounds__(TPB) void snake_post_kernel(PostArgs p) {
+    constexpr int TB = TPB * TT;
+    constexpr int LS = (CP / 4) % 2 ? CP : CP + 4;
+    constexpr int ROWS = TB + KS - 1;
+    __shared__ __attribute__((aligned(16))) float S[ROWS * LS];
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const int t_blk = blockIdx.x * TB;
+    snake_tile<CP, CR, LS>(S, p.x + (long long)b * p.n * p.ld, p.alpha_log, p.beta_log, p.filt, p.n, p.ld, t_blk, (KS - 1) / 2,
+                           ROWS, tid);
+    __syncthreads();
+    float acc[TT];
+#pragma unroll
+    for (int j = 0; j < TT; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < KS; ++tap) {
+#pragma unroll
+        for (int c4 = 0; c4 < (CR + 3) / 4; ++c4) {
+            const float4 wv = *reinterpret_cast<const float4*>(p.w + tap * CP + 4 * c4);      // uniform: scalar load
+#pragma unroll
+            for (int j = 0; j < TT; ++j) {
+                const float4 xin = *reinterpret_cast<const float4*>(S + (tid + TPB * j + tap) * LS + 4 * c4);
+                acc[j] = fmaf(wv.x, xin.x, acc[j]);
+                if (4 * c4 + 1 < CR) acc[j] = fmaf(wv.y, xin.y, acc[j]);
+                if (4 * c4 + 2 < CR) acc[j] = fmaf(wv.z, xin.z, acc[j]);
+                if (4 * c4 + 3 < CR) acc[j] = fmaf(wv.w, xin.w, acc[j]);
+            }
+        }
+    }
+    float* yb = p.y + (long long)b * p.n;
+#pragma unroll
+    for (int j = 0; j < TT; ++j) {
+        const int t = t_blk + tid + TPB * j;
+        if (t < p.n) yb[t] = tanhf(acc[j]);
+    }
+}
+
 template <int CP, int CR, int G, int TT>
 int launch_amp(const AmpArgs& a, int batch, int ksize, void* stream) {
     constexpr int TB = (4 / G) * 64 * TT;
@@ -316,6 +368,22 @@ extern "C" int svcmi_snake_conv_f32(const float* x, const float* w, const float*
     if (c == 10) return tt == 1 ? launch_amp<12, 10, 1, 1>(a, batch, ksize, stream) : tt == 2 ? launch_amp<12, 10, 1, 2>(a, batch, ksize, stream) : launch_amp<12, 10, 1, 4>(a, batch, ksize, stream);
     if (c == 20) return tt == 1 ? launch_amp<20, 20, 2, 1>(a, batch, ksize, stream) : tt == 2 ? launch_amp<20, 20, 2, 2>(a, batch, ksize, stream) : launch_amp<20, 20, 2, 4>(a, batch, ksize, stream);
     return tt == 1 ? launch_amp<40, 40, 4, 1>(a, batch, ksize, stream) : tt == 2 ? launch_amp<40, 40, 4, 2>(a, batch, ksize, stream) : launch_amp<40, 40, 4, 4>(a, batch, ksize, stream);
+}
+
+extern "C" int svcmi_snake_post_supported(int32_t c, int32_t ld, int32_t ksize) { return c == 10 && ld == 12 && ksize == 7; }
+
+extern "C" int svcmi_snake_post_f32(const float* x, const float* w, float* y, const float* alpha_log, const float* beta_log,
+                                    const float* filt, int32_t batch, int32_t len, int32_t c, int32_t ld, int32_t ksize, void* stream) {
+    if (!x || !w || !y || !alpha_log || !beta_log || !filt || batch <= 0 || len <= 0) return SVCMI_EINVAL;
+    if (!svcmi_snake_post_supported(c, ld, ksize)) return SVCMI_EUNSUPPORTED;
+    if (((uintptr_t)w & 15) || ((uintptr_t)x & 7)) return SVCMI_EALIGN;
+    if (batch > 65535) return SVCMI_EUNSUPPORTED;
+    PostArgs a;
+    a.x = x; a.w = w; a.y = y; a.alpha_log = alpha_log; a.beta_log = beta_log; a.filt = filt; a.n = len; a.ld = ld;
+    constexpr int TT = 2;
+    SVCMI_LAUNCH((snake_post_kernel<12, 10, 7, TT>), dim3((unsigned)((len + TPB * TT - 1) / (TPB * TT)), (unsigned)batch), dim3(TPB), 0,
+                 stream, a);
+    return SVCMI_LAST_ERROR();
 }
 
 extern "C" int svcmi_upsample_noise_supported(int32_t u, int32_t cp, int32_t cin) {

@@ -11,14 +11,31 @@ constexpr int TPB = 256;
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
 
-__global__ __launch_bounds__(TPB) void wn_gate_kernel(const float* a, float* out, long long rows, int h, int lda, int ldo) {
+// a = bias + sum of `splits` slabs laid out [batch][splits][t][2h] (the raw split-K partials of the in_layer convolution,
+// SVCMI_CONV_PARTIALS) -- or the finished [batch][t][lda] activations when splits == 1 and bias == NULL.
+__global__ __launch_bounds__(TPB) void wn_gate_kernel(const float* a, const float* bias, float* out, int batch, int t, int h,
+                                                      int lda, int ldo, int splits, long long slab_stride, long long a_bs) {
     const int h4 = h >> 2;
-    const long long total = rows * h4;
+    const long long total = (long long)batch * t * h4;
     for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
         const long long r = i / h4;
         const int c = (int)(i - r * h4) * 4;
-        const float4 ta = *reinterpret_cast<const float4*>(a + r * lda + c);
-        const float4 sa = *reinterpret_cast<const float4*>(a + r * lda + h + c);
+        const int b = (int)(r / t), tt = (int)(r - (long long)b * t);
+        const float* ap = a + (long long)b * a_bs + (long long)tt * lda + c;
+        float4 ta = *reinterpret_cast<const float4*>(ap);
+        float4 sa = *reinterpret_cast<const float4*>(ap + h);
+        for (int s = 1; s < splits; ++s) {       // fixed slab order: deterministic
+            const float4 t2 = *reinterpret_cast<const float4*>(ap + s * slab_stride);
+            const float4 s2 = *reinterpret_cast<const float4*>(ap + s * slab_stride + h);
+            ta.x += t2.x; ta.y += t2.y; ta.z += t2.z; ta.w += t2.w;
+            sa.x += s2.x; sa.y += s2.y; sa.z += s2.z; sa.w += s2.w;
+        }
+        if (bias) {
+            const float4 tb = *reinterpret_cast<const float4*>(bias + c);
+            const float4 sb = *reinterpret_cast<const float4*>(bias + h + c);
+            ta.x += tb.x; ta.y += tb.y; ta.z += tb.z; ta.w += tb.w;
+            sa.x += sb.x; sa.y += sb.y; sa.z += sb.z; sa.w += sb.w;
+        }
         float4 o;
         o.x = tanhf(ta.x) * sigmoidf_(sa.x);
         o.y = tanhf(ta.y) * sigmoidf_(sa.y);
@@ -185,10 +202,14 @@ inline bool mis16(const void* p) { return ((uintptr_t)p & 15) != 0; }
 
 }  // namespace
 
-extern "C" int svcmi_wn_gate_f32(const float* a, float* out, int64_t rows, int32_t h, int32_t lda, int32_t ldo, void* stream) {
-    if (!a || !out || rows <= 0 || h <= 0) return SVCMI_EINVAL;
-    if (h % 4 || lda % 4 || ldo % 4 || mis16(a) || mis16(out)) return SVCMI_EALIGN;
-    SVCMI_LAUNCH(wn_gate_kernel, dim3(blocks_for(rows * (h / 4))), dim3(TPB), 0, stream, a, out, (long long)rows, h, lda, ldo);
+extern "C" int svcmi_wn_gate_f32(const float* a, const float* bias, float* out, int32_t batch, int32_t t, int32_t h, int32_t lda,
+                                 int32_t ldo, int32_t splits, void* stream) {
+    if (!a || !out || batch <= 0 || t <= 0 || h <= 0 || splits < 1 || lda < 2 * h || ldo < h) return SVCMI_EINVAL;
+    if (splits > 1 && lda != 2 * h) return SVCMI_EINVAL;       // slabs are dense [t][2h]
+    if (h % 4 || lda % 4 || ldo % 4 || mis16(a) || mis16(out) || mis16(bias)) return SVCMI_EALIGN;
+    const long long slab = (long long)t * lda;
+    SVCMI_LAUNCH(wn_gate_kernel, dim3(blocks_for((long long)batch * t * (h / 4))), dim3(TPB), 0, stream, a, bias, out, batch, t, h,
+                 lda, ldo, splits, slab, slab * splits);
     return SVCMI_LAST_ERROR();
 }
 

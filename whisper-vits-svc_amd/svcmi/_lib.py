@@ -8,7 +8,7 @@ DEFAULT_LIB = os.path.join(HERE, "libsvcmi.so")
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_MISH, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4, 5
 CONV_ACCUMULATE, CONV_MASK_IN, CONV_MASK_OUT, CONV_PARTIALS = 1, 2, 4, 8
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class ConvDesc(Structure):
@@ -40,7 +40,7 @@ SIGNATURES = {
     "svcmi_upsample_noise_supported": (c_int, [_I, _I, _I]),
     "svcmi_upsample_noise_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _L, _I, _I, _I, _I, _P]),
     "svcmi_tune_set": (c_int, [c_char_p, _I]),
-    "svcmi_wn_gate_f32": (c_int, [_P, _P, _L, _I, _I, _I, _P]),
+    "svcmi_wn_gate_f32": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "svcmi_wn_update_f32": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "svcmi_coupling_pre_f32": (c_int, [_P, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P]),
     "svcmi_coupling_post_f32": (c_int, [_P, _I, _I, _P, _I, _P, _P, _I, _I, _I, _P]),
@@ -58,6 +58,8 @@ SIGNATURES = {
     "svcmi_viterbi_decode": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "svcmi_row_sqnorm_f32": (c_int, [_P, _I, _L, _I, _P, _P]),
     "svcmi_knn_blend_f32": (c_int, [_P, _I, _P, _I, _P, _L, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "svcmi_snake_post_supported": (c_int, [_I, _I, _I]),
+    "svcmi_snake_post_f32": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "svcmi_source2wav_i16": (c_int, [_P, _P, _L, _P]),
 }
 

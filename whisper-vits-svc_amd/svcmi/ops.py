@@ -208,6 +208,18 @@ class Ops:
                    self._stream(), work={"flops": 2.0 * B * L * c * c * ksize, "bytes": 8.0 * B * L * c})
         return out
 
+    def snake_post_supported(self, c, ld, ksize):
+        return bool(self.lib.svcmi_snake_post_supported(c, ld, ksize))
+
+    def snake_post(self, x, alpha_log, beta_log, filt, w, *, c, ksize):
+        """Output layer: tanh(conv_post(SnakeAlias(x))) with one output channel; x [B, L, ld], w [1, >= ksize*ld] -> [B, L]."""
+        self._chk(x, alpha_log, beta_log, filt, w)
+        B, L, ld = x.shape
+        out = torch.empty(B, L, dtype=torch.float32, device=x.device)
+        self._call("svcmi_snake_post_f32", _ptr(x), _ptr(w), _ptr(out), _ptr(alpha_log), _ptr(beta_log), _ptr(filt), B, L, c, ld,
+                   ksize, self._stream(), work={"flops": 2.0 * B * L * c * ksize, "bytes": 4.0 * B * L * (c + 1)})
+        return out
+
     def pitch2source(self, f0, rand_ini, noise, merge_w, merge_b, hop, sr):
         """f0 [B,T], rand_ini [B,11], noise [B,T*hop,11] -> source [B, T*hop]."""
         self._chk(f0, rand_ini, noise, merge_w)
@@ -295,13 +307,20 @@ class Ops:
         return out
 
     # ------------------------------------------------------------------ flow / prior glue
-    def wn_gate(self, a, out=None):
-        self._chk(a, out)
-        B, T, H2 = a.shape
+    def wn_gate(self, a, out=None, bias=None):
+        """a [B, T, 2H] -> tanh(a[..., :H]) * sigmoid(a[..., H:]); or a [B, S, T, 2H] = split-K slabs of the in_layer
+        convolution (``conv(partials=True)``) summed here together with ``bias``."""
+        self._chk(a, out, bias)
+        if a.dim() == 4:
+            B, S, T, H2 = a.shape
+            assert a.is_contiguous()
+        else:
+            (B, T, H2), S = a.shape, 1
+            assert a.stride(0) == T * a.stride(1)
         H = H2 // 2
         if out is None:
             out = torch.empty(B, T, H, dtype=torch.float32, device=a.device)
-        self._call("svcmi_wn_gate_f32", _ptr(a), _ptr(out), B * T, H, a.stride(1), out.stride(1), self._stream())
+        self._call("svcmi_wn_gate_f32", _ptr(a), _ptr(bias), _ptr(out), B, T, H, a.stride(-2), out.stride(1), S, self._stream())
         return out
 
     def wn_update(self, rs, x, skip, lengths, first, last):

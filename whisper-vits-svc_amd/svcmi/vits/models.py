@@ -10,6 +10,7 @@ Same constructor, ``state_dict``/``load_state_dict`` key names, ``eval``/``to``,
 Internally everything is time-major ``[B, T, C]`` fp32.
 """
 import math
+import os
 from collections import OrderedDict
 
 import torch
@@ -29,6 +30,7 @@ class SynthesizerInfer:
         self._device = None
         self.training = False
         self.parallel_blocks = True      # run the AMP blocks of a generator stage on parallel HIP streams
+        self.heavy_first = os.environ.get("SVCMI_AMP_ORDER", "asc") == "desc"
         self._streams, self._streams_dev = None, None
 
     # ------------------------------------------------------------------ nn.Module-like surface
@@ -156,6 +158,10 @@ class SynthesizerInfer:
         ops.conv(vec, w.hub_w, w.hub_b, ksize=5, pad=2, res=x, lengths=lengths, mask_out=True, out=x)
         ops.embed_pitch(x, pit, w.pit_emb, lengths)
         scale = 1.0 / math.sqrt(w.H // w.n_heads)
+        Bq, Tq = x.shape[0], x.shape[1]
+        f2_nk = (w.enc[0]["f2_w"].shape[1] + 31) // 32      # K-steps of the second FFN convolution
+        f2_blocks = Bq * ((Tq + 63) // 64) * ((w.H + 63) // 64)
+        f2_split = 1 if f2_blocks >= 256 else max(1, min(f2_nk // 10, (288 + f2_blocks // 2) // f2_blocks))
         for L in w.enc:
             qkv = ops.conv(x, L["qkv_w"], L["qkv_b"])
             a = ops.attention(qkv, w.n_heads, scale, rel_k=L["rel_k"], rel_v=L["rel_v"], window=K.ENC_WINDOW, lengths=lengths)
@@ -163,8 +169,11 @@ class SynthesizerInfer:
             x = ops.layernorm(x, L["g1"], L["b1"], res=y)
             pl = (K.ENC_FFN_KERNEL - 1) // 2
             h = ops.conv(x, L["f1_w"], L["f1_b"], ksize=K.ENC_FFN_KERNEL, pad=pl, act=ACT_RELU, lengths=lengths, mask_in=True, mask_out=True)
-            y = ops.conv(h, L["f2_w"], L["f2_b"], ksize=K.ENC_FFN_KERNEL, pad=pl, lengths=lengths, mask_out=True)
-            x = ops.layernorm(x, L["g2"], L["b2"], res=y)
+            # second FFN convolution: raw split-K slabs -> one launch that sums them with the bias and the residual and
+            # applies norm_layers_2 (the `* x_mask` of attentions.py:209 only affects rows past the length, which no valid
+            # row ever reads: keys are masked in the attention, inputs in the convolutions)
+            p = ops.conv(h, L["f2_w"], None, ksize=K.ENC_FFN_KERNEL, pad=pl, partials=True, split_k=f2_split)
+            x = ops.splitk_layernorm(p, L["f2_b"], x, L["g2"], L["b2"])
         stats = ops.conv(x, w.proj_w, w.proj_b, lengths=lengths, mask_in=True, mask_out=True)
         return ops.sample_prior(stats, noise, lengths)
 
@@ -173,19 +182,28 @@ class SynthesizerInfer:
         ``x`` [B,T,I] is updated in place."""
         B, T, _ = x.shape
         spk3 = spk.view(B, 1, -1)
-        half = w.half
-        skip = torch.empty(B, T, w.H, dtype=torch.float32, device=x.device)
+        half, H = w.half, w.H
+        # WN state as rows of (h | skip): the res_skip convolution then does `h = (h + rs[:, :H]) * mask; skip += rs[:, H:]`
+        # (modules.py:196-203) in its own epilogue (ACCUMULATE | MASK_OUT into the 2H-wide row), and the in_layer convolution
+        # hands its raw split-K slabs to the gate kernel, which adds them, the bias, and applies tanh * sigmoid: 3 launches
+        # per WN layer.  Masking `skip` every layer instead of once at the end only touches rows past the length.
+        hs = torch.empty(B, T, 2 * H, dtype=torch.float32, device=x.device)
+        h, skip = hs[:, :, :H], hs[:, :, H:]
+        nk = (K.FLOW_KERNEL * H + 31) // 32
+        blocks = B * ((T + 63) // 64) * ((2 * H + 63) // 64)
+        split = 1 if blocks >= 256 else max(1, min(nk // 8, (288 + blocks // 2) // blocks))
         for Lr in w.flow:
             msvs = ops.conv(spk3, Lr["snac_w"], Lr["snac_b"]).view(B, 2 * half)
             x0n = ops.coupling_pre(x, Lr["x0_off"], msvs, lengths, half)
-            h = ops.conv(x0n, Lr["pre_w"], Lr["pre_b"], lengths=lengths, mask_out=True)
+            ops.conv(x0n, Lr["pre_w"], Lr["pre_b"], lengths=lengths, mask_out=True, out=hs)
             n = len(Lr["wn"])
             for l, Wl in enumerate(Lr["wn"]):
-                a = ops.conv(h, Wl["in_w"], Wl["in_b"], ksize=K.FLOW_KERNEL, pad=(K.FLOW_KERNEL - 1) // 2)
-                acts = ops.wn_gate(a)
-                rs = ops.conv(acts, Wl["rs_w"], Wl["rs_b"])
-                ops.wn_update(rs, h, skip, lengths, first=(l == 0), last=(l == n - 1))
-            m = ops.conv(skip, Lr["post_w"], Lr["post_b"], lengths=lengths, mask_out=True)
+                a = ops.conv(h, Wl["in_w"], None, ksize=K.FLOW_KERNEL, pad=(K.FLOW_KERNEL - 1) // 2, ldx=2 * H, c_in=H,
+                             partials=True, split_k=split)
+                acts = ops.wn_gate(a, bias=Wl["in_b"])
+                ops.conv(acts, Wl["rs_w"], Wl["rs_b"], lengths=lengths, mask_out=True, accumulate=True,
+                         out=skip if l == n - 1 else hs)
+            m = ops.conv(skip, Lr["post_w"], Lr["post_b"], lengths=lengths, mask_out=True, ldx=2 * H, c_in=H)
             ops.coupling_post(x, Lr["x1_off"], m, msvs, lengths, half)
         return x
 
@@ -196,9 +214,11 @@ class SynthesizerInfer:
             self._streams_dev = dev
         return self._streams[:n]
 
-    def _amp_block(self, w, ops, st, blk, y, acc, bufs, j, nb, wait_for=None):
+    def _amp_block(self, w, ops, st, blk, y, acc, bufs, j, nb, done=None):
         """AMPBlock.forward (vits_decoder/bigv.py:50-58) + the (sum of blocks)/nb of generator.py:188-194:
-        for d in dilations: x = x + conv2(act(conv1_d(act(x)))); the last iteration lands in ``acc``."""
+        for d in dilations: x = x + conv2(act(conv1_d(act(x)))); the last iteration lands in ``acc``.
+        A generator: it yields once, right before the final convolution -- everything before that point is independent
+        of the other blocks of the stage; the final `acc (+)= ...` waits for ``done[-1]`` (the previous block's event)."""
         xj, tmp, tmp2 = bufs
         k = blk["k"]
         xc = y
@@ -214,8 +234,10 @@ class SynthesizerInfer:
                 a = ops.snake_alias(xc, blk["a1"][q][0], blk["a1"][q][1], w.filt, out=tmp)
                 b = ops.conv(a, blk["c1"][q][0], blk["c1"][q][1], ksize=k, dilation=d, pad=(k * d - d) // 2, out=tmp2)
                 a2 = ops.snake_alias(b, blk["a2"][q][0], blk["a2"][q][1], w.filt, out=a)
-            if last and wait_for is not None:
-                torch.cuda.current_stream().wait_event(wait_for)       # acc += ... in block order
+            if last:
+                yield
+                if done:
+                    torch.cuda.current_stream().wait_event(done[-1])       # acc += ... in block order
             out, alpha, accum = (acc, 1.0 / nb, j > 0) if last else (xj, 1.0, False)
             if fused:
                 ops.snake_conv(b, blk["a2"][q][0], blk["a2"][q][1], w.filt, blk["c2"][q][0], blk["c2"][q][1],
@@ -258,25 +280,34 @@ class SynthesizerInfer:
             bufs = [tuple(torch.empty_like(y) for _ in range(3)) for _ in range(nb if streams else 1)]
             main = torch.cuda.current_stream() if streams else None
             done = []
-            for j, blk in enumerate(st["blocks"]):
-                if streams:
+            if not streams:
+                for j, blk in enumerate(st["blocks"]):
+                    for _ in self._amp_block(w, ops, st, blk, y, acc, bufs[0], j, nb):
+                        pass
+            else:
+                # heads (all but the final convolution) are enqueued heaviest block first -- the k = 11 chain is the stage's
+                # critical path -- then the tails in block order, which fixes the summation order of `acc`
+                order = sorted(range(nb), key=lambda j: -st["blocks"][j]["k"]) if self.heavy_first else list(range(nb))
+                chains = {}
+                for j in order:
                     streams[j].wait_stream(main)
-                    ctx = torch.cuda.stream(streams[j])
-                    ctx.__enter__()
-                try:
-                    self._amp_block(w, ops, st, blk, y, acc, bufs[j if streams else 0], j, nb,
-                                    wait_for=done[-1] if (streams and done) else None)
-                    if streams:
+                    with torch.cuda.stream(streams[j]):
+                        chains[j] = self._amp_block(w, ops, st, st["blocks"][j], y, acc, bufs[j], j, nb, done=done)
+                        next(chains[j])
+                for j in range(nb):
+                    with torch.cuda.stream(streams[j]):
+                        for _ in chains[j]:
+                            pass
                         ev = torch.cuda.Event()
                         ev.record(streams[j])
                         done.append(ev)
-                finally:
-                    if streams:
-                        ctx.__exit__(None, None, None)
             if streams:
                 for sj in streams:
                     main.wait_stream(sj)
             x = acc
+        c_last = w.stages[-1]["c"]
+        if ops.snake_post_supported(c_last, x.shape[2], 7) and w.post_w.shape[1] >= 7 * x.shape[2]:
+            return ops.snake_post(x, w.post_a[0], w.post_a[1], w.filt, w.post_w, c=c_last, ksize=7).view(B, 1, -1)
         a = ops.snake_alias(x, w.post_a[0], w.post_a[1], w.filt)
         o = ops.conv(a, w.post_w, None, ksize=7, pad=3, act=ACT_TANH, n_out=1)
         return o.view(B, 1, -1)

@@ -114,7 +114,8 @@ class VitsWeights:
                 post_w, post_b = post_w.flip(0), post_b.flip(0)
                 m_w, v_w, m_b, v_b = m_w.flip(0), v_w.flip(0), m_b.flip(0), v_b.flip(0)
             layer = dict(x0_off=half if flipped else 0, x1_off=0 if flipped else half,
-                         pre_w=f(pack_conv(pre_w)), pre_b=f(sd[p + ".pre.bias"]),
+                         # pre writes (h | skip) rows of 2H: the H zero output channels clear the skip accumulator
+                         pre_w=f(pack_conv(pre_w, n_pad=2 * H)), pre_b=f(pad_vec(sd[p + ".pre.bias"], 2 * H)),
                          post_w=f(pack_conv(post_w)), post_b=f(post_b),
                          snac_w=f(pack_conv(torch.cat([m_w, v_w], 0).unsqueeze(-1))), snac_b=f(torch.cat([m_b, v_b], 0)),
                          wn=[])
