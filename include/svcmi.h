@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SVCMI_ABI_VERSION 12
+#define SVCMI_ABI_VERSION 13
 
 enum svcmi_status { SVCMI_OK = 0, SVCMI_EINVAL = -1, SVCMI_EUNSUPPORTED = -2, SVCMI_EALIGN = -3 };
 
@@ -104,6 +104,13 @@ typedef struct svcmi_conv_desc {
 
 int svcmi_conv_gemm_f32(const svcmi_conv_desc* d, void* stream);
 
+/* Up to 3 convolutions of one geometry (same batch, t_out, n_out, c_in and gather alignment; taps, dilation, padding, operands
+ * and epilogues free) in ONE launch -- the three AMP blocks of a generator stage at the same step (vits_decoder/generator.py:
+ * 188-194 runs them one after the other).  The grid holds the blocks of all problems, longest K first, so medium-sized
+ * problems fill the chip several blocks deep without multi-stream concurrency.  No split-K, no SVCMI_CONV_PARTIALS, no
+ * x_row_shift; tile override bits of descs[0] apply to all.  Outputs of different problems must not overlap. */
+int svcmi_conv_gemm_group_f32(const svcmi_conv_desc* descs, int32_t count, void* stream);
+
 /* LayerNorm over the channel dim of time-major rows, optional pre-add:
  *   y[r,:] = (v - mean(v)) / sqrt(var(v) + eps) * gamma + beta,   v = x[r,:] + (res ? res[r,:] : 0)
  * rows = batch*rows_per_batch contiguous rows of stride ldx/ldr/ldy.  gamma/beta (NULL = 1/0) are
@@ -154,6 +161,14 @@ int svcmi_attention_f32(const float* q, const float* k, const float* v, float* o
  * alpha_log/beta_log: [c]; filt: the 12 taps (filter.py:28-57).  SURVEY.md A.5. */
 int svcmi_snake_alias_f32(const float* x, float* y, const float* alpha_log, const float* beta_log,
                           const float* filt, int32_t batch, int32_t len, int32_t c, int32_t ld, void* stream);
+/* The same activation for up to 3 tensors of one shape in one launch (x[i] -> y[i] with alpha_log[i] / beta_log[i]): the AMP
+ * blocks of a generator stage at the same step.  The pointer arrays are host arrays read during the call. */
+int svcmi_snake_alias_group_f32(const float* const* x, float* const* y, const float* const* alpha_log,
+                                const float* const* beta_log, const float* filt, int32_t count, int32_t batch,
+                                int32_t len, int32_t c, int32_t ld, void* stream);
+/* y[i] = ((xs[0][i] + xs[1][i]) + xs[2][i]) / count, count <= 3: the `xs / num_kernels` of vits_decoder/generator.py:188-194
+ * when the AMP blocks ran side by side in grouped launches.  n % 4 == 0, 16-byte aligned pointers; y may alias xs[0]. */
+int svcmi_block_mean_f32(const float* const* xs, int32_t count, float* y, int64_t n, void* stream);
 
 /* Fused AMP half-step for the narrow generator stages (vits_decoder/bigv.py:50-58: `xt = act(x); xt = conv(xt)`):
  *   y[b,t,n] = alpha * ( bias[n] + sum_{k<ksize} sum_{ci<c} w[n, k*ld + ci] * S[b, t + (k - (ksize-1)/2)*dilation, ci]
@@ -171,6 +186,18 @@ int svcmi_snake_conv_f32(const float* x, const float* w, const float* bias, cons
                          const float* alpha_log, const float* beta_log, const float* filt,
                          int32_t batch, int32_t len, int32_t c, int32_t ld, int32_t ldw, int32_t ksize,
                          int32_t dilation, float alpha, int32_t accumulate, void* stream);
+
+/* The same half-step for up to 3 AMP blocks of a stage in one launch (own taps / dilation / weights / activation
+ * parameters / tensors; shared shape batch x len x ld and channel count c).  Problems are run most-taps-first.  Outputs of
+ * different problems must not overlap.  Same support matrix as svcmi_snake_conv_f32. */
+typedef struct svcmi_snake_conv_desc {
+    const float* x; const float* w; const float* bias; const float* res; float* y;
+    const float* alpha_log; const float* beta_log;
+    int32_t ldw, ksize, dilation, accumulate;
+    float alpha;
+} svcmi_snake_conv_desc;
+int svcmi_snake_conv_group_f32(const svcmi_snake_conv_desc* descs, int32_t count, const float* filt, int32_t batch,
+                               int32_t len, int32_t c, int32_t ld, void* stream);
 
 /* Stage entry of the narrow generator stages in one launch (vits_decoder/generator.py:183-186):
  *   y[b, u*q + r, co] = b_up[r*cp+co] + sum_{k<taps} sum_{ci<c_in} x[b, q + k - pad, ci] * w_up[r*cp+co, k*c_in + ci]      (ups[i], polyphase)

@@ -340,6 +340,59 @@ def check_snake_conv(ops, c_, device):
     assert float(got[..., c:].abs().max()) == 0.0 if ld > c else True
 
 
+def check_grouped_launches(ops, device, B=2, n=333, c=40, ld=40):
+    """Grouped GEMM / SnakeAlias launches (3 problems per grid) are bit-identical to the single launches, and
+    block_mean = ((a + b) + c) / 3."""
+    g = _g(77 + n + c)
+    filt = W.kaiser_sinc_filter().view(-1).to(device)
+    xs = [torch.randn(B, n, ld, generator=g).to(device) for _ in range(3)]
+    als = [(torch.randn(ld, generator=g) * 0.3).to(device) for _ in range(3)]
+    bes = [(torch.randn(ld, generator=g) * 0.3).to(device) for _ in range(3)]
+    want = [ops.snake_alias(x, a, b, filt) for x, a, b in zip(xs, als, bes)]
+    got = ops.snake_alias_group(xs, als, bes, filt, [torch.empty_like(x) for x in xs])
+    for w_, g_ in zip(want, got):
+        assert torch.equal(w_, g_)
+    ks, ds = (3, 7, 11), (1, 3, 5)
+    ws = [PW.pack_conv(torch.randn(c, c, k, generator=g) / math.sqrt(c * k), ld, ld).to(device) for k in ks]
+    bs = [torch.randn(ld, generator=g).to(device) for _ in ks]
+    rs = [torch.randn(B, n, ld, generator=g).to(device) for _ in ks]
+    for n_prob in (1, 2, 3):
+        want = [ops.conv(xs[j], ws[j], bs[j], ksize=ks[j], dilation=ds[j], pad=(ks[j] - 1) * ds[j] // 2, res=rs[j], split_k=1,
+                         tile=(6 if c % 80 == 0 else 4 if c == 40 else 1)) for j in range(n_prob)]
+        got = ops.conv_group([dict(x=xs[j], w=ws[j], bias=bs[j], ksize=ks[j], dilation=ds[j], pad=(ks[j] - 1) * ds[j] // 2, res=rs[j],
+                                   out=torch.full((B, n, ld), 7.0).to(device)) for j in range(n_prob)])
+        for j in range(n_prob):
+            assert torch.equal(want[j], got[j]), (n_prob, j, float((want[j] - got[j]).abs().max()))
+    m = ops.block_mean(want)
+    assert torch.equal(m.cpu(), ((want[0].cpu() + want[1].cpu()) + want[2].cpu()) / 3.0)
+
+
+def check_snake_conv_group(ops, device, c=20, ld=20, B=2, n=300):
+    """Grouped fused half-steps (3 / 7 / 11 taps in one launch) equal the single launches bit for bit."""
+    g = _g(500 + c + n)
+    filt = W.kaiser_sinc_filter().view(-1).to(device)
+    probs, want = [], []
+    for k, d in ((3, 1), (11, 5), (7, 3)):
+        x = torch.zeros(B, n, ld)
+        x[..., :c] = torch.randn(B, n, c, generator=g)
+        res = torch.zeros(B, n, ld)
+        res[..., :c] = torch.randn(B, n, c, generator=g)
+        al, be = torch.zeros(ld), torch.zeros(ld)
+        al[:c], be[:c] = torch.randn(c, generator=g) * 0.3, torch.randn(c, generator=g) * 0.3
+        w = PW.pack_conv(torch.randn(c, c, k, generator=g) / math.sqrt(c * k), ld, ld).to(device)
+        bias = PW.pad_vec(torch.randn(c, generator=g), ld).to(device)
+        pr = dict(x=x.to(device), alpha_log=al.to(device), beta_log=be.to(device), w=w, bias=bias, ksize=k, dilation=d,
+                  res=res.to(device), alpha=0.5)
+        want.append(ops.snake_conv(pr["x"], pr["alpha_log"], pr["beta_log"], filt, w, bias, c=c, ksize=k, dilation=d, res=pr["res"], alpha=0.5))
+        probs.append(dict(pr, out=torch.full((B, n, ld), 7.0).to(device)))
+    for n_prob in (1, 2, 3):
+        for pr in probs:
+            pr["out"].fill_(7.0)
+        got = ops.snake_conv_group(probs[:n_prob], filt, c=c)
+        for j in range(n_prob):
+            assert torch.equal(got[j], want[j]), (n_prob, j, float((got[j] - want[j]).abs().max()))
+
+
 def check_snake_post(ops, device, B=2, n=700):
     """Fused output layer (SnakeAlias -> conv_post 10 -> 1, k = 7, no bias -> tanh) vs oracle SnakeAlias + torch conv1d."""
     g = _g(4242 + n)

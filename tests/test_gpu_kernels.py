@@ -69,6 +69,16 @@ def test_knn_blend(ops, t, n, d, k, ratio):
     K.check_knn_blend(ops, "cuda", t, n, d, k, ratio)
 
 
+@pytest.mark.parametrize("n,c,B", [(333, 40, 2), (20000, 80, 1), (5000, 160, 1), (80000, 40, 1), (70, 16, 3)])
+def test_grouped_launches(ops, n, c, B):
+    K.check_grouped_launches(ops, "cuda", B=B, n=n, c=c, ld=c)
+
+
+@pytest.mark.parametrize("c,ld,n", [(10, 12, 300), (20, 20, 300), (40, 40, 300), (20, 20, 160000), (10, 12, 320000)])
+def test_snake_conv_group(ops, c, ld, n):
+    K.check_snake_conv_group(ops, "cuda", c=c, ld=ld, B=1 if n > 1000 else 2, n=n)
+
+
 @pytest.mark.parametrize("n", [5, 700, 320000])
 def test_snake_post(ops, n):
     K.check_snake_post(ops, "cuda", B=1 if n > 100000 else 2, n=n)

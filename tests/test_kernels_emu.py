@@ -64,6 +64,16 @@ def test_knn_blend(ops, t, n, d, k, ratio):
     K.check_knn_blend(ops, "cpu", t, n, d, k, ratio)
 
 
+@pytest.mark.parametrize("n,c", [(150, 40), (70, 80), (90, 16)])
+def test_grouped_launches(ops, n, c):
+    K.check_grouped_launches(ops, "cpu", B=2, n=n, c=c, ld=c)
+
+
+@pytest.mark.parametrize("c,ld", [(10, 12), (20, 20)])
+def test_snake_conv_group(ops, c, ld):
+    K.check_snake_conv_group(ops, "cpu", c=c, ld=ld, B=2, n=150)
+
+
 @pytest.mark.parametrize("n", [5, 700])
 def test_snake_post(ops, n):
     K.check_snake_post(ops, "cpu", B=2, n=n)

@@ -58,7 +58,7 @@ __device__ __forceinline__ float snake_s_at(const float* xc, int ld, int n, int 
 struct AmpArgs {
     const float* x; const float* w; const float* bias; const float* res; float* y;
     const float* alpha_log; const float* beta_log; const float* filt;
-    int n, ld, ldw, dil, accumulate;
+    int n, ld, ldw, dil, accumulate, ks;
     float alpha;
 };
 
@@ -127,14 +127,22 @@ __device__ __forceinline__ void snake_tile(float* S, const float* xb, const floa
 // CP = padded channels (row length of x / y / res and of a weight tap), CR = real channels, KS = taps, G = channel
 // groups, TT = time steps per thread in the convolution (accumulators: TT x CO).  Small TT = small tiles = many
 // blocks: the activation phase is a long dependent chain per work item and needs >= 4 waves per SIMD to hide.
-template <int CP, int CR, int KS, int G, int TT>
-__global__ __launch_bounds__(TPB) void snake_conv_kernel(AmpArgs p) {
-    constexpr int TSUB = 4 / G;                       // time sub-tiles per block
-    constexpr int TB = TSUB * 64 * TT;                // output rows per block
-    constexpr int LS = (CP / 4) % 2 ? CP : CP + 4;    // LDS row stride: 4 * odd floats
-    constexpr int ROWS = TB + (KS - 1) * DMAX;
+template <int CP, int G, int TT, int KS>
+struct AmpTile {
+    static constexpr int TSUB = 4 / G;                       // time sub-tiles per block
+    static constexpr int TB = TSUB * 64 * TT;                // output rows per block
+    static constexpr int LS = (CP / 4) % 2 ? CP : CP + 4;    // LDS row stride: 4 * odd floats
+    static constexpr int ROWS = TB + (KS - 1) * DMAX;
+};
+
+// KS_T = 0: taps from p.ks at run time (the grouped launch: one code path for 3 / 7 / 11 taps; three inlined
+// specialisations in one kernel cost 250 VGPRs).
+template <int CP, int CR, int KS_T, int G, int TT>
+__device__ __forceinline__ void snake_conv_body(const AmpArgs& p, float* S) {
+    using TL = AmpTile<CP, G, TT, KS_T ? KS_T : 11>;
+    const int KS = KS_T ? KS_T : p.ks;
+    constexpr int TSUB = TL::TSUB, TB = TL::TB, LS = TL::LS;
     static_assert(G * CO >= CR && CP % 4 == 0 && CP >= CR, "channel split");
-    __shared__ __attribute__((aligned(16))) float S[ROWS * LS];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = SVCMI_UNIFORM((int)(tid >> 6));
@@ -210,6 +218,27 @@ __global__ __launch_bounds__(TPB) void snake_conv_kernel(AmpArgs p) {
             for (int c = G * CO; c < CP; c += 2) *reinterpret_cast<float2*>(yb + (long long)t * ld + c) = make_float2(0.f, 0.f);
         }
     }
+}
+
+template <int CP, int CR, int KS, int G, int TT>
+__global__ __launch_bounds__(TPB) void snake_conv_kernel(AmpArgs p) {
+    using TL = AmpTile<CP, G, TT, KS>;
+    __shared__ __attribute__((aligned(16))) float S[TL::ROWS * TL::LS];
+    snake_conv_body<CP, CR, KS, G, TT>(p, S);
+}
+
+// The same half-step of up to 3 AMP blocks (3 / 7 / 11 taps, own weights / activations / tensors) in one launch: blockIdx.z
+// selects the problem, longest first.  One grid then carries 3x the blocks, which is what fills the chip at these widths.
+constexpr int AMP_GROUP = 3;
+struct AmpGroupArgs {
+    AmpArgs p[AMP_GROUP];
+};
+
+template <int CP, int CR, int G, int TT>
+__global__ __launch_bounds__(TPB) void snake_conv_group_kernel(AmpGroupArgs g) {
+    using TL = AmpTile<CP, G, TT, 11>;
+    __shared__ __attribute__((aligned(16))) float S[TL::ROWS * TL::LS];
+    snake_conv_body<CP, CR, 0, G, TT>(g.p[blockIdx.z], S);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -363,11 +392,49 @@ extern "C" int svcmi_snake_conv_f32(const float* x, const float* w, const float*
     if (batch > 65535) return SVCMI_EUNSUPPORTED;
     AmpArgs a;
     a.x = x; a.w = w; a.bias = bias; a.res = res; a.y = y; a.alpha_log = alpha_log; a.beta_log = beta_log; a.filt = filt;
-    a.n = len; a.ld = ld; a.ldw = ldw; a.dil = dilation; a.accumulate = accumulate; a.alpha = alpha;
+    a.n = len; a.ld = ld; a.ldw = ldw; a.dil = dilation; a.accumulate = accumulate; a.alpha = alpha; a.ks = ksize;
     const int tt = g_amp_tt ? g_amp_tt : 2;      // measured best of {1, 2, 4} on MI355X for all three widths (scripts/microbench.py amp)
     if (c == 10) return tt == 1 ? launch_amp<12, 10, 1, 1>(a, batch, ksize, stream) : tt == 2 ? launch_amp<12, 10, 1, 2>(a, batch, ksize, stream) : launch_amp<12, 10, 1, 4>(a, batch, ksize, stream);
     if (c == 20) return tt == 1 ? launch_amp<20, 20, 2, 1>(a, batch, ksize, stream) : tt == 2 ? launch_amp<20, 20, 2, 2>(a, batch, ksize, stream) : launch_amp<20, 20, 2, 4>(a, batch, ksize, stream);
     return tt == 1 ? launch_amp<40, 40, 4, 1>(a, batch, ksize, stream) : tt == 2 ? launch_amp<40, 40, 4, 2>(a, batch, ksize, stream) : launch_amp<40, 40, 4, 4>(a, batch, ksize, stream);
+}
+
+extern "C" int svcmi_snake_conv_group_f32(const svcmi_snake_conv_desc* descs, int32_t count, const float* filt, int32_t batch,
+                                          int32_t len, int32_t c, int32_t ld, void* stream) {
+    if (!descs || !filt || count < 1 || count > AMP_GROUP || batch <= 0 || len <= 0) return SVCMI_EINVAL;
+    if (batch > 65535) return SVCMI_EUNSUPPORTED;
+    int order[AMP_GROUP] = {0, 1, 2};
+    for (int i = 0; i < count; ++i)           // most taps first (blockIdx.z = 0 is dispatched first)
+        for (int j = i + 1; j < count; ++j)
+            if (descs[order[j]].ksize > descs[order[i]].ksize) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
+    AmpGroupArgs g;
+    for (int i = 0; i < count; ++i) {
+        const svcmi_snake_conv_desc& d = descs[order[i]];
+        if (!d.x || !d.w || !d.y || !d.alpha_log || !d.beta_log || d.x == d.y) return SVCMI_EINVAL;
+        if (!svcmi_snake_conv_supported(c, ld, d.ksize, d.dilation)) return SVCMI_EUNSUPPORTED;
+        if (d.ldw < d.ksize * ld || d.ldw % 4 != 0) return SVCMI_EINVAL;
+        if (((uintptr_t)d.w & 15) || ((uintptr_t)d.x & 7) || ((uintptr_t)d.y & 7) || ((uintptr_t)d.res & 7)) return SVCMI_EALIGN;
+        AmpArgs& a = g.p[i];
+        a.x = d.x; a.w = d.w; a.bias = d.bias; a.res = d.res; a.y = d.y; a.alpha_log = d.alpha_log; a.beta_log = d.beta_log;
+        a.filt = filt; a.n = len; a.ld = ld; a.ldw = d.ldw; a.dil = d.dilation; a.accumulate = d.accumulate; a.alpha = d.alpha;
+        a.ks = d.ksize;
+    }
+    for (int i = count; i < AMP_GROUP; ++i) g.p[i] = g.p[0];
+    constexpr int TT = 2;
+    if (c == 10) {
+        constexpr int TB = AmpTile<12, 1, TT, 3>::TB;
+        SVCMI_LAUNCH((snake_conv_group_kernel<12, 10, 1, TT>), dim3((unsigned)((len + TB - 1) / TB), (unsigned)batch, (unsigned)count),
+                     dim3(TPB), 0, stream, g);
+    } else if (c == 20) {
+        constexpr int TB = AmpTile<20, 2, TT, 3>::TB;
+        SVCMI_LAUNCH((snake_conv_group_kernel<20, 20, 2, TT>), dim3((unsigned)((len + TB - 1) / TB), (unsigned)batch, (unsigned)count),
+                     dim3(TPB), 0, stream, g);
+    } else {
+        constexpr int TB = AmpTile<40, 4, TT, 3>::TB;
+        SVCMI_LAUNCH((snake_conv_group_kernel<40, 40, 4, TT>), dim3((unsigned)((len + TB - 1) / TB), (unsigned)batch, (unsigned)count),
+                     dim3(TPB), 0, stream, g);
+    }
+    return SVCMI_LAST_ERROR();
 }
 
 extern "C" int svcmi_snake_post_supported(int32_t c, int32_t ld, int32_t ksize) { return c == 10 && ld == 12 && ksize == 7; }

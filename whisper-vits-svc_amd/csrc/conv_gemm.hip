@@ -99,8 +99,9 @@ constexpr unsigned OOB = 0x40000000u;   // added to an offset that must read as 
 //   P16 = true : waves 4 x 1, wave tile (16*WM) x (16*WN), v_mfma_f32_16x16x4_f32   -> block (64*WM) x (16*WN):
 //                right-sized N for the 40 / 80 / 160-channel generator stages (a 64-multiple pads them by 60 / 60 / 20 %),
 //                and since fp32 MFMA time is proportional to the padded tile, that padding is pure loss.
+// `grid_blocks` / `block_id`: the launch geometry of THIS problem (a grouped launch runs several problems back to back in one grid).
 template <int WM, int WN, int MODE, bool P16>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
+__device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid_blocks, const int block_id) {
     constexpr int BM = 64 * WM, BN = P16 ? 16 * WN : 64 * WN;
     constexpr int BNL = (BN + 31) / 32 * 32;          // B rows held in LDS (whole 8-row x 4-wave DMA rounds)
     constexpr int A_PER = BM / 32, B_PER = BNL / 32;  // 1-KiB LDS-DMA pieces (8 rows x 32 k) per wave per K-step
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
     // XCD-aware bijective enumeration: XCD g owns a contiguous range of the (z, n-tile, m-tile) order, m fastest
     int bx, by, bz;
     {
-        const int total = (int)gridDim.x, id = (int)blockIdx.x;
+        const int total = grid_blocks, id = block_id;
         const int q8 = total >> 3, r8 = total & 7, xcd = id & 7, slot = id >> 3;
         const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
         bx = L % p.mt;
@@ -422,6 +423,28 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
     }
 }
 
+template <int WM, int WN, int MODE, bool P16>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
+    conv_gemm_body<WM, WN, MODE, P16>(p, (int)gridDim.x, (int)blockIdx.x);
+}
+
+// Grouped launch: up to GROUP_MAX problems of identical tile policy / gather mode in ONE grid, blocks of problem 0 first.  The
+// generator runs the three AMP blocks of a stage (same shapes, 3 / 7 / 11 taps) this way: one launch carries 3x the blocks
+// of a single convolution, so the 20000 x 80 and 80000 x 40 problems fill the 256 CUs several blocks deep without relying
+// on multi-stream concurrency, and the long-K problem goes first so the short ones fill the tail.
+constexpr int GROUP_MAX = 3;
+struct GroupArgs {
+    ConvArgs p[GROUP_MAX];
+    int first[GROUP_MAX + 1];      // first[i] = first block of problem i; first[count..] = grid size
+};
+
+template <int WM, int WN, int MODE, bool P16>
+__global__ __launch_bounds__(256) void conv_gemm_group_kernel(GroupArgs g) {
+    const int id = (int)blockIdx.x;
+    const int gi = id >= g.first[2] ? 2 : (id >= g.first[1] ? 1 : 0);      // block-uniform: the arguments stay scalar loads
+    conv_gemm_body<WM, WN, MODE, P16>(g.p[gi], g.first[gi + 1] - g.first[gi], id - g.first[gi]);
+}
+
 // y = epilogue(sum over slices, fixed order).  One thread per 4 consecutive n (n_out % 4 handled by a scalar tail).
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs p, int batch) {
     const long long total = (long long)batch * p.t_out * p.n_out;
@@ -467,9 +490,32 @@ int launch(const ConvArgs& a_in, int batch, int mode, void* stream) {
     return rc;
 }
 
+template <int WM, int WN, bool P16>
+int launch_group(GroupArgs& g, int count, int batch, int mode, void* stream) {
+    constexpr int BM = 64 * WM, BN = P16 ? 16 * WN : 64 * WN;
+    long long blocks = 0;
+    for (int i = 0; i < GROUP_MAX; ++i) {
+        g.first[i] = (int)blocks;
+        if (i < count) {
+            ConvArgs& a = g.p[i];
+            a.mt = (a.t_out + BM - 1) / BM;
+            a.nt = (a.n_out + BN - 1) / BN;
+            blocks += (long long)a.mt * a.nt * batch;
+            if (blocks > 0x7fffffffLL) return SVCMI_EUNSUPPORTED;
+        }
+    }
+    g.first[GROUP_MAX] = (int)blocks;
+    dim3 grid((unsigned)blocks);
+    if (mode == MODE_CHUNK) SVCMI_LAUNCH((conv_gemm_group_kernel<WM, WN, MODE_CHUNK, P16>), grid, dim3(256), 0, stream, g);
+    else if (mode == MODE_VEC) SVCMI_LAUNCH((conv_gemm_group_kernel<WM, WN, MODE_VEC, P16>), grid, dim3(256), 0, stream, g);
+    else return SVCMI_EUNSUPPORTED;
+    return SVCMI_LAST_ERROR();
+}
+
 }  // namespace
 
-extern "C" int svcmi_conv_gemm_f32(const svcmi_conv_desc* d, void* stream) {
+// Validation + argument block + gather mode of one convolution (shared by the single and the grouped entry points).
+static int prepare(const svcmi_conv_desc* d, ConvArgs& a, int& mode) {
     if (!d || !d->x || !d->w || !d->y) return SVCMI_EINVAL;
     /* 32-bit buffer offsets with a 2^30 out-of-range sentinel: each operand buffer stays below 2^29 bytes */
     if ((long long)d->t_in * d->ldx >= (1LL << 27) || (long long)d->n_out * d->ldw >= (1LL << 27)) return SVCMI_EUNSUPPORTED;
@@ -485,7 +531,6 @@ extern "C" int svcmi_conv_gemm_f32(const svcmi_conv_desc* d, void* stream) {
     // magic-number division q / c_in is exact while q * c_in < 2^32 (q < ksize*c_in)
     if ((long long)d->ksize * d->c_in * d->c_in >= 0x100000000LL || (long long)d->ksize * d->c_in >= 0x7fffffffLL) return SVCMI_EUNSUPPORTED;
 
-    ConvArgs a;
     a.x = d->x; a.w = d->w; a.bias = d->bias; a.res = d->res; a.y = d->y; a.lengths = d->lengths;
     a.ws = d->workspace;
     a.cnt = nullptr;
@@ -497,9 +542,15 @@ extern "C" int svcmi_conv_gemm_f32(const svcmi_conv_desc* d, void* stream) {
     a.ktot = d->ksize * d->c_in;
     a.magic = d->c_in == 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d->c_in - 1) / (unsigned)d->c_in);
     const bool vec = (d->c_in % 4 == 0) && (d->ldx % 4 == 0) && (d->x_bstride % 4 == 0) && (((uintptr_t)d->x & 15) == 0);
-    int mode = !vec ? MODE_SCALAR : (d->c_in % BK == 0 ? MODE_CHUNK : MODE_VEC);
+    mode = !vec ? MODE_SCALAR : (d->c_in % BK == 0 ? MODE_CHUNK : MODE_VEC);
     if (d->x_row_shift) mode = mode == MODE_CHUNK ? MODE_CHUNK_RS : MODE_SCALAR;   // the fused row repeat: CHUNK_RS or per-element
+    return SVCMI_OK;
+}
 
+extern "C" int svcmi_conv_gemm_f32(const svcmi_conv_desc* d, void* stream) {
+    ConvArgs a;
+    int mode;
+    if (int rc = prepare(d, a, mode)) return rc;
     // Tile: fill the 256 CUs first, then grow the tile for operand reuse (or honour the override).
     const long long mt64 = (d->t_out + 63) / 64, nt64 = (d->n_out + 63) / 64;
     long long blocks64 = mt64 * nt64 * d->batch;
@@ -563,4 +614,35 @@ extern "C" int svcmi_conv_gemm_f32(const svcmi_conv_desc* d, void* stream) {
         case SVCMI_CONV_TILE_128x64: return launch<2, 1, false>(a, d->batch, mode, stream);
         default: return launch<1, 1, false>(a, d->batch, mode, stream);
     }
+}
+
+extern "C" int svcmi_conv_gemm_group_f32(const svcmi_conv_desc* descs, int32_t count, void* stream) {
+    if (!descs || count < 1 || count > GROUP_MAX) return SVCMI_EINVAL;
+    GroupArgs g;
+    int order[GROUP_MAX] = {0, 1, 2};
+    for (int i = 0; i < count; ++i)           // longest K first: the hardware starts blocks in grid order
+        for (int j = i + 1; j < count; ++j)
+            if (descs[order[j]].ksize > descs[order[i]].ksize) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
+    int mode = -1;
+    const svcmi_conv_desc& d0 = descs[0];
+    for (int i = 0; i < count; ++i) {
+        const svcmi_conv_desc& d = descs[order[i]];
+        int m;
+        if (int rc = prepare(&d, g.p[i], m)) return rc;
+        if (mode >= 0 && m != mode) return SVCMI_EUNSUPPORTED;
+        mode = m;
+        // one tile policy for the whole grid: same geometry, no split-K / raw partials (the group itself supplies the blocks)
+        if (d.batch != d0.batch || d.t_out != d0.t_out || d.n_out != d0.n_out || d.c_in != d0.c_in) return SVCMI_EINVAL;
+        if ((d.flags & SVCMI_CONV_PARTIALS) || d.split_k > 1 || d.x_row_shift) return SVCMI_EUNSUPPORTED;
+        g.p[i].split = 1;
+    }
+    for (int i = count; i < GROUP_MAX; ++i) g.p[i] = g.p[0];
+    if (mode != MODE_CHUNK && mode != MODE_VEC) return SVCMI_EUNSUPPORTED;
+    const int tile = d0.flags & SVCMI_CONV_TILE_MASK;
+    const int n16 = (d0.n_out + 15) / 16;
+    // 16x16x4 tiles right-sized to the channel count (40 -> 48, 80 / 160 -> 80 columns); everything else 64 x 64
+    if (tile == SVCMI_CONV_TILE_P16_64x48 || (!tile && n16 == 3)) return launch_group<1, 3, true>(g, count, d0.batch, mode, stream);
+    if (tile == SVCMI_CONV_TILE_P16_64x80 || (!tile && (n16 == 5 || d0.n_out % 80 == 0))) return launch_group<1, 5, true>(g, count, d0.batch, mode, stream);
+    if (tile && tile != SVCMI_CONV_TILE_64x64) return SVCMI_EUNSUPPORTED;
+    return launch_group<1, 1, false>(g, count, d0.batch, mode, stream);
 }

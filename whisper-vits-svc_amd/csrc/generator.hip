@@ -47,20 +47,29 @@ __device__ __forceinline__ float snake_s_at(const float* xc, int ld, int n, int 
     return snake_fn(2.f * y, a, inv_b);
 }
 
-__global__ __launch_bounds__(TPB) void snake_alias_kernel(const float* x, float* y, const float* alpha_log,
-                                                          const float* beta_log, const float* filt,
-                                                          int n, int c, int ld) {
-    const int b = blockIdx.y;
+// Up to 3 activations of one shape per launch (blockIdx.z): the AMP blocks of a generator stage have their own alpha / beta
+// and, after the first step, their own input.
+constexpr int SNAKE_GROUP = 3;
+struct SnakeArgs {
+    const float* x[SNAKE_GROUP]; float* y[SNAKE_GROUP]; const float* alpha_log[SNAKE_GROUP]; const float* beta_log[SNAKE_GROUP];
+    const float* filt;
+    int n, c, ld;
+};
+
+__global__ __launch_bounds__(TPB) void snake_alias_kernel(SnakeArgs p) {
+    const int b = blockIdx.y, gi = blockIdx.z;
+    const int n = p.n, c = p.c, ld = p.ld;
+    const float* filt = p.filt;
     const long long e = (long long)blockIdx.x * TPB + threadIdx.x;
     const int ch = (int)(e % c);
     const long long run = e / c;
     const long long t0l = run * RT;
     if (t0l >= n) return;                       // no barriers in this kernel
     const int t0 = (int)t0l;
-    const float a = expf(alpha_log[ch]);
-    const float inv_b = 1.0f / (expf(beta_log[ch]) + 1e-9f);
-    const float* xc = x + (long long)b * n * ld + ch;
-    float* yc = y + (long long)b * n * ld + ch;
+    const float a = expf(p.alpha_log[gi][ch]);
+    const float inv_b = 1.0f / (expf(p.beta_log[gi][ch]) + 1e-9f);
+    const float* xc = p.x[gi] + (long long)b * n * ld + ch;
+    float* yc = p.y[gi] + (long long)b * n * ld + ch;
 
     float f[12];
 #pragma unroll
@@ -99,6 +108,18 @@ __global__ __launch_bounds__(TPB) void snake_alias_kernel(const float* x, float*
 #pragma unroll
         for (int k = 0; k < 12; ++k) z = fmaf(f[k], s[2 * r + k], z);
         if (t0 + r < n) yc[(long long)(t0 + r) * ld] = z;
+    }
+}
+
+// y = ((x0 + x1) + x2) / count -- `xs = xs + resblock(x)` ... `x = xs / num_kernels` (vits_decoder/generator.py:188-194), float4 stream
+__global__ __launch_bounds__(TPB) void block_mean_kernel(const float* x0, const float* x1, const float* x2, float* y, long long n4,
+                                                         float count) {
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n4; i += (long long)gridDim.x * TPB) {
+        float4 a = reinterpret_cast<const float4*>(x0)[i];
+        if (x1) { const float4 b = reinterpret_cast<const float4*>(x1)[i]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+        if (x2) { const float4 b = reinterpret_cast<const float4*>(x2)[i]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+        a.x /= count; a.y /= count; a.z /= count; a.w /= count;
+        reinterpret_cast<float4*>(y)[i] = a;
     }
 }
 
@@ -190,15 +211,41 @@ __global__ __launch_bounds__(TPB) void source2wav_kernel(const float* x, int16_t
 
 }  // namespace
 
-extern "C" int svcmi_snake_alias_f32(const float* x, float* y, const float* alpha_log, const float* beta_log,
-                                     const float* filt, int32_t batch, int32_t len, int32_t c, int32_t ld, void* stream) {
-    if (!x || !y || !alpha_log || !beta_log || !filt || batch <= 0 || len <= 0 || c <= 0 || ld < c) return SVCMI_EINVAL;
-    if (x == y) return SVCMI_EINVAL;            // halo reads: not an in-place op
+extern "C" int svcmi_snake_alias_group_f32(const float* const* x, float* const* y, const float* const* alpha_log,
+                                           const float* const* beta_log, const float* filt, int32_t count, int32_t batch,
+                                           int32_t len, int32_t c, int32_t ld, void* stream) {
+    if (!x || !y || !alpha_log || !beta_log || !filt || count < 1 || count > SNAKE_GROUP) return SVCMI_EINVAL;
+    if (batch <= 0 || len <= 0 || c <= 0 || ld < c) return SVCMI_EINVAL;
     if (batch > 65535) return SVCMI_EUNSUPPORTED;
+    SnakeArgs a;
+    for (int i = 0; i < SNAKE_GROUP; ++i) {
+        const int j = i < count ? i : 0;
+        if (!x[j] || !y[j] || !alpha_log[j] || !beta_log[j]) return SVCMI_EINVAL;
+        if (x[j] == y[j]) return SVCMI_EINVAL;            // halo reads: not an in-place op
+        a.x[i] = x[j]; a.y[i] = y[j]; a.alpha_log[i] = alpha_log[j]; a.beta_log[i] = beta_log[j];
+    }
+    a.filt = filt; a.n = len; a.c = c; a.ld = ld;
     const long long runs = ((long long)len + RT - 1) / RT;
     const long long threads = runs * c;
-    SVCMI_LAUNCH(snake_alias_kernel, dim3((unsigned)((threads + TPB - 1) / TPB), batch), dim3(TPB), 0, stream, x, y,
-                 alpha_log, beta_log, filt, len, c, ld);
+    SVCMI_LAUNCH(snake_alias_kernel, dim3((unsigned)((threads + TPB - 1) / TPB), batch, count), dim3(TPB), 0, stream, a);
+    return SVCMI_LAST_ERROR();
+}
+
+extern "C" int svcmi_snake_alias_f32(const float* x, float* y, const float* alpha_log, const float* beta_log,
+                                     const float* filt, int32_t batch, int32_t len, int32_t c, int32_t ld, void* stream) {
+    return svcmi_snake_alias_group_f32(&x, &y, &alpha_log, &beta_log, filt, 1, batch, len, c, ld, stream);
+}
+
+extern "C" int svcmi_block_mean_f32(const float* const* xs, int32_t count, float* y, int64_t n, void* stream) {
+    if (!xs || !y || count < 1 || count > 3 || n <= 0) return SVCMI_EINVAL;
+    for (int i = 0; i < count; ++i)
+        if (!xs[i]) return SVCMI_EINVAL;
+    if (n % 4) return SVCMI_EINVAL;
+    if (((uintptr_t)y & 15) || ((uintptr_t)xs[0] & 15) || (count > 1 && ((uintptr_t)xs[1] & 15)) || (count > 2 && ((uintptr_t)xs[2] & 15))) return SVCMI_EALIGN;
+    long long nb = (n / 4 + TPB - 1) / TPB;
+    if (nb > 4096) nb = 4096;
+    SVCMI_LAUNCH(block_mean_kernel, dim3((unsigned)nb), dim3(TPB), 0, stream, xs[0], count > 1 ? xs[1] : nullptr,
+                 count > 2 ? xs[2] : nullptr, y, (long long)(n / 4), (float)count);
     return SVCMI_LAST_ERROR();
 }
 

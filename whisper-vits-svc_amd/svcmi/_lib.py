@@ -8,7 +8,14 @@ DEFAULT_LIB = os.path.join(HERE, "libsvcmi.so")
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_MISH, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4, 5
 CONV_ACCUMULATE, CONV_MASK_IN, CONV_MASK_OUT, CONV_PARTIALS = 1, 2, 4, 8
-ABI_VERSION = 12
+ABI_VERSION = 13
+
+
+class SnakeConvDesc(Structure):
+    """svcmi_snake_conv_desc"""
+    _fields_ = [("x", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("res", c_void_p), ("y", c_void_p),
+                ("alpha_log", c_void_p), ("beta_log", c_void_p),
+                ("ldw", c_int32), ("ksize", c_int32), ("dilation", c_int32), ("accumulate", c_int32), ("alpha", c_float)]
 
 
 class ConvDesc(Structure):
@@ -60,6 +67,10 @@ SIGNATURES = {
     "svcmi_knn_blend_f32": (c_int, [_P, _I, _P, _I, _P, _L, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "svcmi_snake_post_supported": (c_int, [_I, _I, _I]),
     "svcmi_snake_post_f32": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "svcmi_conv_gemm_group_f32": (c_int, [_P, _I, _P]),
+    "svcmi_snake_conv_group_f32": (c_int, [_P, _I, _P, _I, _I, _I, _I, _P]),
+    "svcmi_snake_alias_group_f32": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "svcmi_block_mean_f32": (c_int, [_P, _I, _P, _L, _P]),
     "svcmi_source2wav_i16": (c_int, [_P, _P, _L, _P]),
 }
 

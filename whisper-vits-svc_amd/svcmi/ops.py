@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_GELU, ACT_MISH, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, CONV_ACCUMULATE, CONV_MASK_IN,  # noqa: F401
-                   CONV_MASK_OUT, CONV_PARTIALS, ConvDesc, SvcmiError)
+                   CONV_MASK_OUT, CONV_PARTIALS, ConvDesc, SnakeConvDesc, SvcmiError)
 
 
 def _ptr(t):
@@ -66,7 +66,7 @@ class Ops:
         return torch.empty(*shape, dtype=dtype, device=like.device if like is not None else ("cuda" if self.on_gpu else "cpu"))
 
     # ------------------------------------------------------------------ conv / linear
-    def conv(self, x, w, bias=None, *, ksize=1, stride=1, dilation=1, pad=0, t_out=None, act=ACT_NONE,
+    def _conv_desc(self, x, w, bias=None, *, ksize=1, stride=1, dilation=1, pad=0, t_out=None, act=ACT_NONE,
              res=None, alpha=1.0, accumulate=False, lengths=None, mask_in=False, mask_out=False, out=None,
              x_row_shift=0, c_in=None, ldx=None, t_in=None, n_out=None, x_bstride=None, tile=0, split_k=0, partials=False):
         """y[b,t,n] = epilogue(sum_k sum_ci x[b, t*stride + k*dilation - pad, ci] * w[n, k*c_in + ci]).
@@ -110,11 +110,30 @@ class Ops:
                 d.counters, d.counters_len = ws[1].data_ptr(), ws[1].numel()
         else:
             d.split_k, d.workspace, d.workspace_floats = 1, 0, 0
-        self._call("svcmi_conv_gemm_f32", ctypes.byref(d), self._stream(),
-                   work={"flops": 2.0 * B * t_out * N * ksize * c_in})
-        if partials:      # [B, split, t_out, N] view of this stream's workspace; valid until the next split-K launch on it
-            return ws[0][:B * split_k * t_out * N].view(B, split_k, t_out, N)
+        return d, out, (ws if (split_k != 1 or partials) else None), B, t_out, N, 2.0 * B * t_out * N * ksize * c_in
+
+    def conv(self, x, w, bias=None, **kw):
+        """y[b,t,n] = epilogue(sum_k sum_ci x[b, t*stride + k*dilation - pad, ci] * w[n, k*c_in + ci]).
+        ``x`` is [B, T, C]; ``w`` is [N, ldw] packed (weights.pack_conv).  Keywords: see ``_conv_desc``."""
+        d, out, ws, B, t_out, N, flops = self._conv_desc(x, w, bias, **kw)
+        self._call("svcmi_conv_gemm_f32", ctypes.byref(d), self._stream(), work={"flops": flops})
+        if kw.get("partials"):      # [B, split, t_out, N] view of this stream's workspace; valid until the next split-K launch on it
+            return ws[0][:B * d.split_k * t_out * N].view(B, d.split_k, t_out, N)
         return out
+
+    def conv_group(self, problems):
+        """Up to 3 convolutions of one geometry in one launch (svcmi_conv_gemm_group_f32).  ``problems``: dicts of ``conv``
+        arguments (x, w, bias + keywords; ``out`` required to differ).  Returns the outputs."""
+        descs = (ConvDesc * len(problems))()
+        outs, flops = [], 0.0
+        for i, pr in enumerate(problems):
+            pr = dict(pr)
+            d, out, _, _, _, _, fl = self._conv_desc(pr.pop("x"), pr.pop("w"), pr.pop("bias", None), split_k=1, **pr)
+            descs[i] = d
+            outs.append(out)
+            flops += fl
+        self._call("svcmi_conv_gemm_group_f32", descs, len(problems), self._stream(), work={"flops": flops})
+        return outs
 
     # ------------------------------------------------------------------ norm / attention
     def layernorm(self, x, gamma=None, beta=None, *, res=None, eps=1e-5, per_batch_affine=False, out=None):
@@ -172,6 +191,26 @@ class Ops:
                    B, L, Cc, x.stride(1), self._stream(), work={"bytes": 8.0 * B * L * Cc})
         return out
 
+    def snake_alias_group(self, xs, alpha_logs, beta_logs, filt, outs):
+        """SnakeAlias of up to 3 same-shape tensors (own alpha / beta each) in one launch."""
+        self._chk(*xs, *alpha_logs, *beta_logs, filt, *outs)
+        n = len(xs)
+        B, L, Cc = xs[0].shape
+        arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+        self._call("svcmi_snake_alias_group_f32", arr(xs), arr(outs), arr(alpha_logs), arr(beta_logs), _ptr(filt), n,
+                   B, L, Cc, xs[0].stride(1), self._stream(), work={"bytes": 8.0 * n * B * L * Cc})
+        return outs
+
+    def block_mean(self, xs, out=None):
+        """((xs[0] + xs[1]) + xs[2]) / len(xs) for contiguous same-shape tensors."""
+        self._chk(*xs, out)
+        if out is None:
+            out = torch.empty_like(xs[0])
+        arr = (ctypes.c_void_p * len(xs))(*[t.data_ptr() for t in xs])
+        self._call("svcmi_block_mean_f32", arr, len(xs), _ptr(out), xs[0].numel(), self._stream(),
+                   work={"bytes": 4.0 * (len(xs) + 1) * xs[0].numel()})
+        return out
+
     def upsample_noise_supported(self, u, cp, cin):
         return bool(self.lib.svcmi_upsample_noise_supported(u, cp, cin))
 
@@ -219,6 +258,24 @@ class Ops:
         self._call("svcmi_snake_post_f32", _ptr(x), _ptr(w), _ptr(out), _ptr(alpha_log), _ptr(beta_log), _ptr(filt), B, L, c, ld,
                    ksize, self._stream(), work={"flops": 2.0 * B * L * c * ksize, "bytes": 4.0 * B * L * (c + 1)})
         return out
+
+    def snake_conv_group(self, problems, filt, *, c):
+        """The fused half-step for up to 3 AMP blocks in one launch.  ``problems``: dicts with x, alpha_log, beta_log, w, bias,
+        ksize, dilation (1), res (None), alpha (1.0), accumulate (False), out."""
+        descs = (SnakeConvDesc * len(problems))()
+        B, L, ld = problems[0]["x"].shape
+        flops = 0.0
+        for i, pr in enumerate(problems):
+            self._chk(pr["x"], pr["alpha_log"], pr["beta_log"], pr["w"], pr.get("bias"), pr.get("res"), pr["out"])
+            d = descs[i]
+            d.x, d.w, d.bias, d.res, d.y = _ptr(pr["x"]), _ptr(pr["w"]), _ptr(pr.get("bias")), _ptr(pr.get("res")), _ptr(pr["out"])
+            d.alpha_log, d.beta_log = _ptr(pr["alpha_log"]), _ptr(pr["beta_log"])
+            d.ldw, d.ksize, d.dilation = pr["w"].shape[1], pr["ksize"], pr.get("dilation", 1)
+            d.accumulate, d.alpha = int(pr.get("accumulate", False)), float(pr.get("alpha", 1.0))
+            flops += 2.0 * B * L * c * c * pr["ksize"]
+        self._call("svcmi_snake_conv_group_f32", descs, len(problems), _ptr(filt), B, L, c, ld, self._stream(),
+                   work={"flops": flops, "bytes": 8.0 * len(problems) * B * L * c})
+        return [pr["out"] for pr in problems]
 
     def pitch2source(self, f0, rand_ini, noise, merge_w, merge_b, hop, sr):
         """f0 [B,T], rand_ini [B,11], noise [B,T*hop,11] -> source [B, T*hop]."""

@@ -30,6 +30,8 @@ class SynthesizerInfer:
         self._device = None
         self.training = False
         self.parallel_blocks = True      # run the AMP blocks of a generator stage on parallel HIP streams
+        self.grouped_blocks = os.environ.get("SVCMI_AMP_GROUPED", "1") != "0"      # wide stages: grouped launches
+        self._stop_after = None          # tuning aid (scripts/stage_times.py), never set in production
         self.heavy_first = os.environ.get("SVCMI_AMP_ORDER", "asc") == "desc"
         self._streams, self._streams_dev = None, None
 
@@ -148,7 +150,11 @@ class SynthesizerInfer:
         if noise is None:
             noise = torch.randn(B, w.I, T, device=pit.device)
         z_p = self._prior_encoder(w, ops, ppg50, vec, pit, lengths, noise, ppg_row_shift=1)
+        if self._stop_after == "prior":      # scripts/stage_times.py: truncated pipelines for in-situ stage timing
+            return z_p
         z = self._flow_reverse(w, ops, z_p, spk, lengths)
+        if self._stop_after == "flow":
+            return z
         return self._generator(w, ops, z, spk, source.view(B, T * w.hop))
 
     # ------------------------------------------------------------------ stages (time-major)
@@ -247,6 +253,42 @@ class SynthesizerInfer:
                          alpha=alpha, accumulate=accum, out=out)
             xc = xj
 
+    def _amp_stage_grouped(self, w, ops, st, y, acc):
+        """The nb AMP blocks of a wide stage in lock-step: at every step the blocks' activations go out as ONE grouped
+        SnakeAlias launch and their convolutions as ONE grouped GEMM launch (3x the blocks per grid, longest K first), then
+        `acc = ((o_0 + o_1) + o_2) / nb` exactly as generator.py:188-194 sums them.  12 + 1 launches per stage instead of
+        36-48, and no reliance on multi-stream concurrency.  Returns False when the stage does not fit the scheme."""
+        blocks = st["blocks"]
+        nb = len(blocks)
+        nd = len(blocks[0]["d"])
+        if not (2 <= nb <= 3) or any(len(b["d"]) != nd for b in blocks) or y.shape[2] % 4:
+            return False
+        fused = [ops.snake_conv_preferred(st["c"], st["cp"], b["k"], d) for b in blocks for d in b["d"]]
+        if any(fused) and not all(fused):
+            return False
+        xj = [torch.empty_like(y) for _ in range(nb)]
+        t1 = [torch.empty_like(y) for _ in range(nb)]
+        t2 = [torch.empty_like(y) for _ in range(nb)]
+        xc = [y] * nb
+        for q in range(nd if all(fused) else 0):      # narrow stages: activation + convolution are one VALU kernel (csrc/amp_fused.hip)
+            ops.snake_conv_group([dict(x=xc[j], alpha_log=b["a1"][q][0], beta_log=b["a1"][q][1], w=b["c1"][q][0], bias=b["c1"][q][1],
+                                       ksize=b["k"], dilation=b["d"][q], out=t1[j]) for j, b in enumerate(blocks)], w.filt, c=st["c"])
+            outs = t2 if q == nd - 1 else xj
+            ops.snake_conv_group([dict(x=t1[j], alpha_log=b["a2"][q][0], beta_log=b["a2"][q][1], w=b["c2"][q][0], bias=b["c2"][q][1],
+                                       ksize=b["k"], res=xc[j], out=outs[j]) for j, b in enumerate(blocks)], w.filt, c=st["c"])
+            xc = outs
+        for q in range(0 if all(fused) else nd):
+            ops.snake_alias_group(xc, [b["a1"][q][0] for b in blocks], [b["a1"][q][1] for b in blocks], w.filt, t1)
+            ops.conv_group([dict(x=t1[j], w=b["c1"][q][0], bias=b["c1"][q][1], ksize=b["k"], dilation=b["d"][q],
+                                 pad=(b["k"] * b["d"][q] - b["d"][q]) // 2, out=t2[j]) for j, b in enumerate(blocks)])
+            ops.snake_alias_group(t2, [b["a2"][q][0] for b in blocks], [b["a2"][q][1] for b in blocks], w.filt, t1)
+            outs = t2 if q == nd - 1 else xj          # t2 is free again once the second activation has read it
+            ops.conv_group([dict(x=t1[j], w=b["c2"][q][0], bias=b["c2"][q][1], ksize=b["k"], pad=(b["k"] - 1) // 2,
+                                 res=xc[j], out=outs[j]) for j, b in enumerate(blocks)])
+            xc = outs
+        ops.block_mean(xc, out=acc)
+        return True
+
     def _generator(self, w, ops, z, spk, source):
         """Generator.inference, vits_decoder/generator.py:175-200 (+ SpeakerAdapter :36-47, AMPBlock bigv.py:50-58).
         z [B,T,U] time-major, source [B, hop*T] -> [B,1,hop*T]."""
@@ -254,6 +296,8 @@ class SynthesizerInfer:
         sb = ops.conv(spk.view(B, 1, -1), w.ad_w, w.ad_b).view(B, 2 * U)
         x = ops.layernorm(z, sb[:, :U], sb[:, U:], per_batch_affine=True)
         x = ops.conv(x, w.pre_conv_w, w.pre_conv_b, ksize=7, pad=3, act=ACT_MISH)
+        if self._stop_after == "gen_pre":
+            return x
         for st in w.stages:
             t_in = x.shape[1]
             if ops.upsample_noise_supported(st["u"], st["cp"], x.shape[2]):
@@ -276,6 +320,11 @@ class SynthesizerInfer:
             # an independent chain.  On the GPU they go to separate HIP streams (forked from / joined to the current
             # one, also under graph capture) so that the many medium-sized launches of a stage overlap; the
             # `acc (+)= (conv + x)/nb` of block j waits for block j-1's, which keeps the summation order fixed.
+            if self.grouped_blocks and self._amp_stage_grouped(w, ops, st, y, acc):
+                x = acc
+                if self._stop_after == ("stage", w.stages.index(st)):
+                    return x
+                continue
             streams = self._block_streams(nb) if (self.parallel_blocks and ops.on_gpu) else None
             bufs = [tuple(torch.empty_like(y) for _ in range(3)) for _ in range(nb if streams else 1)]
             main = torch.cuda.current_stream() if streams else None
@@ -305,6 +354,8 @@ class SynthesizerInfer:
                 for sj in streams:
                     main.wait_stream(sj)
             x = acc
+            if self._stop_after == ("stage", w.stages.index(st)):
+                return x
         c_last = w.stages[-1]["c"]
         if ops.snake_post_supported(c_last, x.shape[2], 7) and w.post_w.shape[1] >= 7 * x.shape[2]:
             return ops.snake_post(x, w.post_a[0], w.post_a[1], w.filt, w.post_w, c=c_last, ksize=7).view(B, 1, -1)
