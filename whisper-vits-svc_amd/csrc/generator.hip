@@ -14,12 +14,19 @@ constexpr int RT = 8;   // outputs per thread along time
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// cold path of sin_sq as a real call: inlined, the 26 unrolled copies of libm's large-argument reduction made the kernel
+// 5600 instructions (45 KB) for ~1200 hot ones
+__device__ __attribute__((noinline)) float sin_sq_huge(float x) {
+    const float sl = sinf(x);
+    return sl * sl;
+}
+
 // sin^2(x) without the libm call: sin^2 has period pi, so x is reduced to r = x - n*pi in [-pi/2, pi/2] with a
 // two-constant Cody-Waite step (the FMAs keep n*PI_HI exact), sin(r) is a degree-11 odd minimax polynomial and
 // the result is squared.  Max abs error 2.6e-7 for |x| <= 1e5 (fp32 libm sin, squared: 1.3e-7); ~14 VALU ops
 // instead of an inlined sinf (whose 26 unrolled copies per thread overflowed the instruction cache).
 __device__ __forceinline__ float sin_sq(float x) {
-    if (fabsf(x) > 1.0e5f) { const float sl = sinf(x); return sl * sl; }   // never taken for audio-scale activations
+    if (__builtin_expect(fabsf(x) > 1.0e5f, 0)) return sin_sq_huge(x);   // never taken for audio-scale activations
     const float n = rintf(x * 0.31830987f);
     float r = fmaf(-n, 3.1415927f, x);
     r = fmaf(-n, -8.742278e-08f, r);
