@@ -61,6 +61,51 @@ def main():
         gemm(ops, "whisper_mlp1", 500, 1280, 5120, tiles=(1, 2, 3), splits=(1,))
         gemm(ops, "whisper_mlp2", 500, 5120, 1280, res=True, tiles=(1, 3), splits=(8, 1))
         gemm(ops, "square4096", 4096, 4096, 4096, tiles=(1, 2, 3), splits=(1,))
+    if "kscale" in what:      # fixed overhead vs per-K-step cost of the Whisper tiles: time against K at constant M x N
+        for cin in (320, 640, 1280, 2560, 5120):
+            gemm(ops, "mlp1_K", 500, cin, 5120, tiles=(6,), splits=(1,))
+        for cin in (320, 640, 1280, 2560, 5120):
+            gemm(ops, "qkv_K", 500, cin, 3840, tiles=(1,), splits=(1,))
+        for T in (256, 512, 1024):
+            gemm(ops, "mlp1_M", T, 1280, 5120, tiles=(6,), splits=(1,))
+    if "group" in what:       # the grouped AMP-stage GEMMs: tile policy x ring depth
+        for (C, n, tls) in ((160, 5000, (0, 1, 7)), (80, 20000, (0, 7)), (40, 80000, (0, 5))):
+            g = torch.Generator().manual_seed(0)
+            xs = [torch.randn(1, n, C, generator=g).cuda() for _ in range(3)]
+            rs = [torch.randn(1, n, C, generator=g).cuda() for _ in range(3)]
+            outs = [torch.empty(1, n, C, device="cuda") for _ in range(3)]
+            ws = [PW.pack_conv(torch.randn(C, C, k, generator=g) / math.sqrt(C * k)).cuda() for k in (3, 7, 11)]
+            bs = [torch.randn(C, generator=g).cuda() for _ in range(3)]
+            fl = sum(2.0 * n * C * C * k for k in (3, 7, 11))
+            for d in (1, 5):
+                for tile in tls:
+                    for nst in (3, 2):
+                        assert ops.lib.svcmi_tune_set(b"group_nst", nst) == 0
+                        probs = [dict(x=xs[j], w=ws[j], bias=bs[j], ksize=k, dilation=d, pad=(k - 1) * d // 2, res=rs[j], out=outs[j],
+                                      tile=tile) for j, k in enumerate((3, 7, 11))]
+                        us = timeit(lambda: ops.conv_group(probs))
+                        print(f"group C={C} n={n} d={d} tile={tile} nst={nst}: {us:8.1f} us  {fl / us / 1e6:7.1f} TF/s", flush=True)
+        ops.lib.svcmi_tune_set(b"group_nst", 0)
+    if "ampgroup" in what:    # grouped fused SnakeAlias+conv half-steps of the narrow stages: time steps per thread
+        filt = torch.tensor([0.00202896, 0.00938947, -0.02554346, -0.05765738, 0.12857258, 0.44320980, 0.44320980,
+                             0.12857258, -0.05765738, -0.02554346, 0.00938947, 0.00202896], device="cuda")
+        for (C, n) in ((20, 160000), (10, 320000)):
+            ld = (C + 3) // 4 * 4
+            probs = []
+            for k in (3, 7, 11):
+                probs.append(dict(x=torch.randn(1, n, ld, device="cuda"), alpha_log=torch.randn(ld, device="cuda") * 0.3,
+                                  beta_log=torch.randn(ld, device="cuda") * 0.3, w=PW.pack_conv(torch.randn(C, C, k) / math.sqrt(C * k), ld, ld).cuda(),
+                                  bias=torch.randn(ld, device="cuda"), ksize=k, dilation=1, res=torch.randn(1, n, ld, device="cuda"),
+                                  out=torch.empty(1, n, ld, device="cuda")))
+            fl = sum(2.0 * n * C * C * k for k in (3, 7, 11))
+            for d in (1, 5):
+                for pr in probs:
+                    pr["dilation"] = d
+                for tt in (1, 2, 4):
+                    assert ops.lib.svcmi_tune_set(b"amp_tt", tt) == 0
+                    us = timeit(lambda: ops.snake_conv_group(probs, filt, c=C))
+                    print(f"ampgroup C={C} n={n} d={d} tt={tt}: {us:8.1f} us  {fl / us / 1e6:6.1f} TF/s", flush=True)
+        ops.lib.svcmi_tune_set(b"amp_tt", 0)
     if "small" in what:       # the short-K / few-tile GEMMs of the prior encoder, flow and widest decoder stage
         sp = (1, 0, 2, 3, 4)
         for k, d in ((3, 1), (7, 3), (11, 5)):

@@ -358,7 +358,7 @@ def check_grouped_launches(ops, device, B=2, n=333, c=40, ld=40):
     rs = [torch.randn(B, n, ld, generator=g).to(device) for _ in ks]
     for n_prob in (1, 2, 3):
         want = [ops.conv(xs[j], ws[j], bs[j], ksize=ks[j], dilation=ds[j], pad=(ks[j] - 1) * ds[j] // 2, res=rs[j], split_k=1,
-                         tile=(6 if c % 80 == 0 else 4 if c == 40 else 1)) for j in range(n_prob)]
+                         tile=(6 if c == 80 else 4 if c == 40 else 1)) for j in range(n_prob)]
         got = ops.conv_group([dict(x=xs[j], w=ws[j], bias=bs[j], ksize=ks[j], dilation=ds[j], pad=(ks[j] - 1) * ds[j] // 2, res=rs[j],
                                    out=torch.full((B, n, ld), 7.0).to(device)) for j in range(n_prob)])
         for j in range(n_prob):

@@ -406,6 +406,23 @@ extern "C" int svcmi_snake_conv_f32(const float* x, const float* w, const float*
     return tt == 1 ? launch_amp<40, 40, 4, 1>(a, batch, ksize, stream) : tt == 2 ? launch_amp<40, 40, 4, 2>(a, batch, ksize, stream) : launch_amp<40, 40, 4, 4>(a, batch, ksize, stream);
 }
 
+template <int TT>
+static void launch_amp_group(const AmpGroupArgs& g, int count, int batch, int len, int c, void* stream) {
+    if (c == 10) {
+        constexpr int TB = AmpTile<12, 1, TT, 3>::TB;
+        SVCMI_LAUNCH((snake_conv_group_kernel<12, 10, 1, TT>), dim3((unsigned)((len + TB - 1) / TB), (unsigned)batch, (unsigned)count),
+                     dim3(TPB), 0, stream, g);
+    } else if (c == 20) {
+        constexpr int TB = AmpTile<20, 2, TT, 3>::TB;
+        SVCMI_LAUNCH((snake_conv_group_kernel<20, 20, 2, TT>), dim3((unsigned)((len + TB - 1) / TB), (unsigned)batch, (unsigned)count),
+                     dim3(TPB), 0, stream, g);
+    } else {
+        constexpr int TB = AmpTile<40, 4, TT, 3>::TB;
+        SVCMI_LAUNCH((snake_conv_group_kernel<40, 40, 4, TT>), dim3((unsigned)((len + TB - 1) / TB), (unsigned)batch, (unsigned)count),
+                     dim3(TPB), 0, stream, g);
+    }
+}
+
 extern "C" int svcmi_snake_conv_group_f32(const svcmi_snake_conv_desc* descs, int32_t count, const float* filt, int32_t batch,
                                           int32_t len, int32_t c, int32_t ld, void* stream) {
     if (!descs || !filt || count < 1 || count > AMP_GROUP || batch <= 0 || len <= 0) return SVCMI_EINVAL;
@@ -427,20 +444,10 @@ extern "C" int svcmi_snake_conv_group_f32(const svcmi_snake_conv_desc* descs, in
         a.ks = d.ksize;
     }
     for (int i = count; i < AMP_GROUP; ++i) g.p[i] = g.p[0];
-    constexpr int TT = 2;
-    if (c == 10) {
-        constexpr int TB = AmpTile<12, 1, TT, 3>::TB;
-        SVCMI_LAUNCH((snake_conv_group_kernel<12, 10, 1, TT>), dim3((unsigned)((len + TB - 1) / TB), (unsigned)batch, (unsigned)count),
-                     dim3(TPB), 0, stream, g);
-    } else if (c == 20) {
-        constexpr int TB = AmpTile<20, 2, TT, 3>::TB;
-        SVCMI_LAUNCH((snake_conv_group_kernel<20, 20, 2, TT>), dim3((unsigned)((len + TB - 1) / TB), (unsigned)batch, (unsigned)count),
-                     dim3(TPB), 0, stream, g);
-    } else {
-        constexpr int TB = AmpTile<40, 4, TT, 3>::TB;
-        SVCMI_LAUNCH((snake_conv_group_kernel<40, 40, 4, TT>), dim3((unsigned)((len + TB - 1) / TB), (unsigned)batch, (unsigned)count),
-                     dim3(TPB), 0, stream, g);
-    }
+    const int tt = g_amp_tt ? g_amp_tt : (c == 10 ? 1 : 2);      // measured (scripts/microbench.py ampgroup): 68.5 / 71.3 / 81.1 us at 10 channels, 106 / 89 / 109 at 20
+    if (tt == 4) launch_amp_group<4>(g, count, batch, len, c, stream);
+    else if (tt == 1) launch_amp_group<1>(g, count, batch, len, c, stream);
+    else launch_amp_group<2>(g, count, batch, len, c, stream);
     return SVCMI_LAST_ERROR();
 }
 
@@ -485,8 +492,11 @@ extern "C" int svcmi_upsample_noise_f32(const float* x, const float* w_up, const
 }
 
 // Development knob (scripts/microbench.py): returns 0 if the name is known.
+extern "C" int svcmi_conv_tune_set(const char* name, int32_t value);      // conv_gemm.hip: "group_nst"
+
 extern "C" int svcmi_tune_set(const char* name, int32_t value) {
     if (!name) return SVCMI_EINVAL;
+    if (svcmi_conv_tune_set(name, value) == 0) return 0;
     const char* k = "amp_tt";
     int i = 0;
     while (k[i] && name[i] == k[i]) ++i;

@@ -100,7 +100,7 @@ constexpr unsigned OOB = 0x40000000u;   // added to an offset that must read as 
 //                right-sized N for the 40 / 80 / 160-channel generator stages (a 64-multiple pads them by 60 / 60 / 20 %),
 //                and since fp32 MFMA time is proportional to the padded tile, that padding is pure loss.
 // `grid_blocks` / `block_id`: the launch geometry of THIS problem (a grouped launch runs several problems back to back in one grid).
-template <int WM, int WN, int MODE, bool P16>
+template <int WM, int WN, int MODE, bool P16, int NSTO = 0>
 __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid_blocks, const int block_id) {
     constexpr int BM = 64 * WM, BN = P16 ? 16 * WN : 64 * WN;
     constexpr int BNL = (BN + 31) / 32 * 32;          // B rows held in LDS (whole 8-row x 4-wave DMA rounds)
@@ -109,7 +109,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
     // LDS ring of NST operand tiles (48 / 72 / 64 KiB per block): tile it+NST-1 is in flight while tile
     // `it` is consumed, so a K-step never waits a full HBM/L2 round trip -- what short K ranges (split-K slices,
     // the k=1 projections of the prior encoder / flow, k=3 convolutions) would otherwise pay on every step.
-    constexpr int NST = P16 ? ((BM + BNL) > 192 ? 2 : 3) : ((WM * WN == 1) ? 3 : (WM * WN == 2 ? 3 : 2));
+    constexpr int NST = NSTO ? NSTO : (P16 ? ((BM + BNL) > 192 ? 2 : 3) : ((WM * WN == 1) ? 3 : (WM * WN == 2 ? 3 : 2)));
     static_assert(BM * CLD <= NST * (BM + BNL) * BK, "C tile must fit in the operand buffers");
     __shared__ __attribute__((aligned(16))) float smem[NST * (BM + BNL) * BK + 4];   // + the split-K ticket word
     float* const As0 = smem;                          // As[slot] = As0 + slot*BM*BK, rows of 32 floats, chunk-swizzled
@@ -438,11 +438,13 @@ struct GroupArgs {
     int first[GROUP_MAX + 1];      // first[i] = first block of problem i; first[count..] = grid size
 };
 
-template <int WM, int WN, int MODE, bool P16>
+// NSTO: ring depth override -- the grouped problems have 4 .. 55 K-steps and thousands of blocks, where a 2-deep ring
+// (one more resident block per CU) can beat the 3-deep one tuned for the long-K Whisper GEMMs.
+template <int WM, int WN, int MODE, bool P16, int NSTO>
 __global__ __launch_bounds__(256) void conv_gemm_group_kernel(GroupArgs g) {
     const int id = (int)blockIdx.x;
     const int gi = id >= g.first[2] ? 2 : (id >= g.first[1] ? 1 : 0);      // block-uniform: the arguments stay scalar loads
-    conv_gemm_body<WM, WN, MODE, P16>(g.p[gi], g.first[gi + 1] - g.first[gi], id - g.first[gi]);
+    conv_gemm_body<WM, WN, MODE, P16, NSTO>(g.p[gi], g.first[gi + 1] - g.first[gi], id - g.first[gi]);
 }
 
 // y = epilogue(sum over slices, fixed order).  One thread per 4 consecutive n (n_out % 4 handled by a scalar tail).
@@ -490,6 +492,8 @@ int launch(const ConvArgs& a_in, int batch, int mode, void* stream) {
     return rc;
 }
 
+int g_group_nst = 0;        // tuning knob (svcmi_tune_set("group_nst", 0 | 2 | 3)): ring depth of the grouped launches, 0 = default
+
 template <int WM, int WN, bool P16>
 int launch_group(GroupArgs& g, int count, int batch, int mode, void* stream) {
     constexpr int BM = 64 * WM, BN = P16 ? 16 * WN : 64 * WN;
@@ -506,9 +510,17 @@ int launch_group(GroupArgs& g, int count, int batch, int mode, void* stream) {
     }
     g.first[GROUP_MAX] = (int)blocks;
     dim3 grid((unsigned)blocks);
-    if (mode == MODE_CHUNK) SVCMI_LAUNCH((conv_gemm_group_kernel<WM, WN, MODE_CHUNK, P16>), grid, dim3(256), 0, stream, g);
-    else if (mode == MODE_VEC) SVCMI_LAUNCH((conv_gemm_group_kernel<WM, WN, MODE_VEC, P16>), grid, dim3(256), 0, stream, g);
-    else return SVCMI_EUNSUPPORTED;
+    // measured (scripts/microbench.py group): the 16x16x4 tiles gain 7 % (80 channels) / 11 % (40) from the 2-deep ring (3 resp.
+    // 4 resident blocks per CU), the 64 x 64 tile does not
+    const int nst = g_group_nst ? g_group_nst : (P16 ? 2 : 3);
+    if (mode != MODE_CHUNK && mode != MODE_VEC) return SVCMI_EUNSUPPORTED;
+    if (nst == 2) {
+        if (mode == MODE_CHUNK) SVCMI_LAUNCH((conv_gemm_group_kernel<WM, WN, MODE_CHUNK, P16, 2>), grid, dim3(256), 0, stream, g);
+        else SVCMI_LAUNCH((conv_gemm_group_kernel<WM, WN, MODE_VEC, P16, 2>), grid, dim3(256), 0, stream, g);
+    } else {
+        if (mode == MODE_CHUNK) SVCMI_LAUNCH((conv_gemm_group_kernel<WM, WN, MODE_CHUNK, P16, 3>), grid, dim3(256), 0, stream, g);
+        else SVCMI_LAUNCH((conv_gemm_group_kernel<WM, WN, MODE_VEC, P16, 3>), grid, dim3(256), 0, stream, g);
+    }
     return SVCMI_LAST_ERROR();
 }
 
@@ -640,9 +652,21 @@ extern "C" int svcmi_conv_gemm_group_f32(const svcmi_conv_desc* descs, int32_t c
     if (mode != MODE_CHUNK && mode != MODE_VEC) return SVCMI_EUNSUPPORTED;
     const int tile = d0.flags & SVCMI_CONV_TILE_MASK;
     const int n16 = (d0.n_out + 15) / 16;
-    // 16x16x4 tiles right-sized to the channel count (40 -> 48, 80 / 160 -> 80 columns); everything else 64 x 64
+    // 16x16x4 tiles right-sized to the channel count (40 -> 48, 80 -> 80 columns); everything else 64 x 64
+    if (tile == SVCMI_CONV_TILE_P16_128x48) return launch_group<2, 3, true>(g, count, d0.batch, mode, stream);
+    if (tile == SVCMI_CONV_TILE_P16_128x80) return launch_group<2, 5, true>(g, count, d0.batch, mode, stream);
     if (tile == SVCMI_CONV_TILE_P16_64x48 || (!tile && n16 == 3)) return launch_group<1, 3, true>(g, count, d0.batch, mode, stream);
-    if (tile == SVCMI_CONV_TILE_P16_64x80 || (!tile && (n16 == 5 || d0.n_out % 80 == 0))) return launch_group<1, 5, true>(g, count, d0.batch, mode, stream);
+    // (160 channels: two 64x80 tiles lose to three 64x64 ones, 84 vs 75.5 us per grouped launch)
+    if (tile == SVCMI_CONV_TILE_P16_64x80 || (!tile && n16 == 5)) return launch_group<1, 5, true>(g, count, d0.batch, mode, stream);
     if (tile && tile != SVCMI_CONV_TILE_64x64) return SVCMI_EUNSUPPORTED;
     return launch_group<1, 1, false>(g, count, d0.batch, mode, stream);
+}
+
+// Development knob of the grouped launches (reached through svcmi_tune_set): results never depend on it.
+extern "C" int svcmi_conv_tune_set(const char* name, int32_t value) {
+    const char* k = "group_nst";
+    int i = 0;
+    while (k[i] && name[i] == k[i]) ++i;
+    if (k[i] == 0 && name[i] == 0 && (value == 0 || value == 2 || value == 3)) { g_group_nst = value; return 0; }
+    return SVCMI_EINVAL;
 }
