@@ -55,6 +55,27 @@ def check_vits_golden(ops, device, tag, hp, tol=TIGHT):
     return errs
 
 
+def check_generator_widths_against_oracle(ops, device, T=5, B=2, tol=TIGHT):
+    """The base.yaml generator widths (320 -> 160, 80, 40, 20, 10 channels: 64x64 / 64x80 / 64x48 grouped GEMM tiles, the grouped
+    fused VALU kernels at 20 / 10 channels, the streaming ups+noise kernels and the fused output layer) on a short ragged batch
+    with the small prior encoder / flow of the tiny config, against the oracle."""
+    hp = C.tiny_hp()
+    hp["gen"] = dict(hp["gen"], upsample_initial_channel=320)
+    m, sd = make_model(hp, ops, device)
+    d = I.synth_clip(T=T, hp=hp, seed=21, B=B)
+    lens = d["lengths"].clone()
+    if B > 1:
+        lens[-1] = max(1, T - 2)
+    src = m.pitch2source(d["pit"], noise=(d["rand_ini"], d["src_noise"]))
+    wav = m.inference(d["ppg"], d["vec"], d["pit"], d["spk"], lens, src, noise=d["enc_noise"])
+    with torch.no_grad():
+        o_src = O.pitch2source(sd, hp, d["pit"], d["rand_ini"], d["src_noise"])
+        o_wav = O.synth_inference(sd, hp, d["ppg"], d["vec"], d["pit"], d["spk"], lens, o_src, d["enc_noise"])
+    errs = dict(source=maxerr(src, o_src), wave=maxerr(wav, o_wav))
+    assert errs["source"] <= 5e-5 and errs["wave"] <= min(tol * 5, WAVE_TOL), errs
+    return errs
+
+
 def check_whisper_golden(ops, device, tag, dims, tol=TIGHT):
     from svcmi.whisper.inference import load_model
     g = golden(tag)

@@ -88,6 +88,10 @@ def test_svc_infer_with_knn_retrieval(ops):
     print(E.check_svc_infer_retrieval(ops, "cuda", T=300))
 
 
+def test_generator_base_widths_match_oracle(ops):
+    print(E.check_generator_widths_against_oracle(ops, "cuda", T=37, B=3))
+
+
 def test_full_10s_clip_against_oracle(ops):
     """configs[1]: B=1, 10 s, base.yaml decoder; pitch2source + inference vs the CPU oracle, same noise."""
     hp = C.base_hp()
