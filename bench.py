@@ -253,6 +253,7 @@ def main():
                            "traffic_source": traffic_src, "launches_per_step": gm["launches"],
                            "avg_launch_us": round(1000.0 * gm["ms"] / gm["launches"], 2),
                            "algorithmic_gflop_per_step": round(gm["flops"] / 1e9, 1),
+                           "algorithmic_bytes_per_launch": int(gm["bytes"] / gm["launches"]),
                            "share_of_step_kernel_time": round(gm["ms"] / total_ms, 3)}
         out["kernel_time_ms"] = {k.replace("svcmi_", ""): round(v["ms"], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
         sn = agg.get("svcmi_snake_alias_f32")

@@ -66,3 +66,58 @@ def test_single_process_broadcast_is_identity():
     sd = {"x": torch.arange(6.0).view(2, 3)}
     out = D.broadcast_state_dict(sd, device="cpu")
     assert torch.equal(out["x"], sd["x"])
+
+
+# ---------------------------------------------------------------------------------------------- folder conversion driver
+class _StubConverter:
+    """Stands in for the GPU models: the driver logic (sharding, outputs, stats) is what this test is about."""
+
+    class _Hp:
+        class data:
+            sampling_rate = 32000
+
+    hp = _Hp()
+
+    def __init__(self, args, device, rank, world):
+        self.rank = rank
+
+    def convert(self, wav_path):
+        import numpy as np
+        n = os.path.getsize(wav_path)
+        return np.full(n, float(self.rank), dtype=np.float32)
+
+
+def _batch_worker(rank, world, port, folder, cwd, q):
+    os.chdir(cwd)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from svcmi import svc_inference_batch as SB
+    args = SB.build_parser().parse_args(["--config", "c", "--model", "m", "--wave", folder, "--spk", "s"])
+    mine = SB.run_batch(args, converter_factory=_StubConverter, backend="gloo")
+    q.put((rank, mine))
+    torch.distributed.destroy_process_group()
+
+
+def test_folder_conversion_shards_files_over_ranks(tmp_path):
+    from scipy.io.wavfile import read
+    folder = tmp_path / "waves"
+    folder.mkdir()
+    sizes = {"a.wav": 900, "b.wav": 100, "c.wav": 500, "d.wav": 450, "e.wav": 50, "notes.txt": 10}
+    for name, n in sizes.items():
+        (folder / name).write_bytes(b"\0" * n)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_batch_worker, args=(r, 2, port, str(folder), str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res[0] + res[1]) == ["a.wav", "b.wav", "c.wav", "d.wav", "e.wav"]        # every .wav exactly once
+    load = lambda fs: sum(sizes[f] for f in fs)
+    assert abs(load(res[0]) - load(res[1])) <= 900                                          # LPT balance
+    for r in (0, 1):
+        for f in res[r]:
+            sr, x = read(tmp_path / "_svc_out" / f)
+            assert sr == 32000 and len(x) == sizes[f] and float(x[0]) == float(r)

@@ -2,6 +2,8 @@
 reference (tests/golden, made by oracle/make_golden.py) and against the oracle at the full 10 s
 configuration (BASELINE.json configs[1]).  Tolerance: north_star's 1e-3 max-abs on the waveform;
 the fp32 kernels are expected ~1e-5 and the tests print what they reach."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -237,3 +239,37 @@ def test_cli_main_wav_to_wav(ops, tmp_path, monkeypatch):
     sr, written = wavfile.read("svc_out.wav")
     assert sr == hp.data.sampling_rate and np.array_equal(written, out)
     assert wavfile.read("svc_out_pit.wav")[1].dtype == np.int16
+
+
+def test_batch_folder_driver_single_rank(ops, tmp_path, monkeypatch):
+    """svc_inference_batch.py:15-52 as one process with resident models: every .wav of a folder -> _svc_out/<file>, equal to
+    converting the file through the single-file CLI path with the same seeds."""
+    import json
+    import yaml
+    from scipy.io import wavfile
+    from oracle import audio_oracle as A
+    from svcmi import svc_inference_batch as SB
+    monkeypatch.chdir(tmp_path)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    hp = C.tiny_hp()
+    os.makedirs("waves")
+    for i, secs in enumerate((1.0, 1.5)):
+        audio = (A.synth_audio(int(16000 * secs), 8 + i) * 0.5).numpy()
+        wavfile.write(f"waves/u{i}.wav", 16000, (audio * 32767).astype(np.int16))
+    torch.save({"model_g": W.make_vits_state(hp, seed=1234)}, "svc.pth")
+    torch.save(W.make_whisper_state({**C.WHISPER_TINY_TEST, "n_audio_state": hp.vits.ppg_dim, "n_audio_head": 4}), "whisper.pt")
+    torch.save(W.make_hubert_state(dict(C.HUBERT_TINY_TEST, proj=hp.vits.vec_dim)), "hubert.pt")
+    torch.save(W.make_crepe_state("tiny"), "crepe.pth")
+    np.save("spk.npy", I.synth_spk(hp.vits.spk_dim, seed=7).numpy())
+    with open("cfg.yaml", "w") as f:
+        yaml.safe_dump(json.loads(json.dumps(hp)), f)
+    args = SB.build_parser().parse_args(["--config", "cfg.yaml", "--model", "svc.pth", "--wave", "waves", "--spk", "spk.npy",
+                                         "--whisper", "whisper.pt", "--hubert", "hubert.pt", "--crepe", "crepe.pth"])
+    mine = SB.run_batch(args)
+    assert mine == ["u0.wav", "u1.wav"]
+    for f, secs in (("u0.wav", 1.0), ("u1.wav", 1.5)):
+        sr, x = wavfile.read(os.path.join("_svc_out", f))
+        assert sr == hp.data.sampling_rate and x.dtype == np.float32 and np.isfinite(x).all()
+        assert abs(len(x) - int(secs * hp.data.sampling_rate)) <= 2 * hp.data.hop_length
+    assert not [f for f in os.listdir("_svc_out") if f.startswith(".rank")]          # intermediates removed

@@ -110,13 +110,15 @@ class Ops:
                 d.counters, d.counters_len = ws[1].data_ptr(), ws[1].numel()
         else:
             d.split_k, d.workspace, d.workspace_floats = 1, 0, 0
-        return d, out, (ws if (split_k != 1 or partials) else None), B, t_out, N, 2.0 * B * t_out * N * ksize * c_in
+        # algorithmic work: every operand element once (input rows, the weight matrix, the output (+ residual / accumulate))
+        nbytes = 4.0 * (B * (t_in >> x_row_shift) * c_in + N * ksize * c_in + B * t_out * N * (1 + (res is not None) + bool(accumulate)))
+        return d, out, (ws if (split_k != 1 or partials) else None), B, t_out, N, {"flops": 2.0 * B * t_out * N * ksize * c_in, "bytes": nbytes}
 
     def conv(self, x, w, bias=None, **kw):
         """y[b,t,n] = epilogue(sum_k sum_ci x[b, t*stride + k*dilation - pad, ci] * w[n, k*c_in + ci]).
         ``x`` is [B, T, C]; ``w`` is [N, ldw] packed (weights.pack_conv).  Keywords: see ``_conv_desc``."""
-        d, out, ws, B, t_out, N, flops = self._conv_desc(x, w, bias, **kw)
-        self._call("svcmi_conv_gemm_f32", ctypes.byref(d), self._stream(), work={"flops": flops})
+        d, out, ws, B, t_out, N, work = self._conv_desc(x, w, bias, **kw)
+        self._call("svcmi_conv_gemm_f32", ctypes.byref(d), self._stream(), work=work)
         if kw.get("partials"):      # [B, split, t_out, N] view of this stream's workspace; valid until the next split-K launch on it
             return ws[0][:B * d.split_k * t_out * N].view(B, d.split_k, t_out, N)
         return out
@@ -125,14 +127,14 @@ class Ops:
         """Up to 3 convolutions of one geometry in one launch (svcmi_conv_gemm_group_f32).  ``problems``: dicts of ``conv``
         arguments (x, w, bias + keywords; ``out`` required to differ).  Returns the outputs."""
         descs = (ConvDesc * len(problems))()
-        outs, flops = [], 0.0
+        outs, work = [], {"flops": 0.0, "bytes": 0.0}
         for i, pr in enumerate(problems):
             pr = dict(pr)
-            d, out, _, _, _, _, fl = self._conv_desc(pr.pop("x"), pr.pop("w"), pr.pop("bias", None), split_k=1, **pr)
+            d, out, _, _, _, _, wk = self._conv_desc(pr.pop("x"), pr.pop("w"), pr.pop("bias", None), split_k=1, **pr)
             descs[i] = d
             outs.append(out)
-            flops += fl
-        self._call("svcmi_conv_gemm_group_f32", descs, len(problems), self._stream(), work={"flops": flops})
+            work = {k: work[k] + wk[k] for k in work}
+        self._call("svcmi_conv_gemm_group_f32", descs, len(problems), self._stream(), work=work)
         return outs
 
     # ------------------------------------------------------------------ norm / attention

@@ -1,0 +1,120 @@
+"""Folder-of-wavs conversion, the reference's ``svc_inference_batch.py`` (:15-52), as the multi-GPU form of the hot path.
+
+The reference runs Whisper over every file, then starts ``python svc_inference.py`` once per file (each child reloads
+HuBERT, CREPE and the synthesizer).  Here the four models are loaded ONCE per process, and with ``torchrun --nproc-per-node N``
+the files are assigned to the N ranks by longest-processing-time (cost = file size ~ duration): one process per GPU, rank 0
+reads the checkpoints and ships them to the other ranks as one flat RCCL broadcast each (``svcmi.dist``), no collective
+afterwards -- utterances are independent.  Outputs land in ``./_svc_out/<file>`` like the reference's.
+
+    python -m svcmi.svc_inference_batch --config configs/base.yaml --model sovits5.0.pth --wave test_waves/ --spk singer.npy
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m svcmi.svc_inference_batch ...
+"""
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import dist as D
+
+OUT_PATH = "./_svc_out"
+
+
+def list_waves(wave_path):
+    """:29-31 (sorted, so every rank sees the same order)."""
+    assert os.path.isdir(wave_path), f"{wave_path} is not folder"
+    return sorted(f for f in os.listdir(wave_path) if f.endswith(".wav"))
+
+
+def _load_on_rank0(path, rank):
+    return torch.load(path, map_location="cpu") if rank == 0 else None
+
+
+class Converter:
+    """The four models of the wav -> wav path, resident on one GPU."""
+
+    def __init__(self, args, device, rank=0, world=1):
+        from .hubert import inference as hubert_inf
+        from .pitch import inference as pitch_inf
+        from .svc_inference import load_config
+        from .vits.models import SynthesizerInfer
+        from .whisper import inference as whisper_inf
+        self.args, self.device = args, device
+        self.hp = load_config(args.config)
+        bc = lambda sd: D.broadcast_state_dict(sd, 0, device) if world > 1 else sd
+        wck = _load_on_rank0(args.whisper, rank)
+        dims = [wck["dims"] if rank == 0 else None]
+        if world > 1:
+            torch.distributed.broadcast_object_list(dims, src=0)
+        self.whisper = whisper_inf.load_model({"dims": dims[0], "model_state_dict": bc(wck["model_state_dict"] if rank == 0 else None)}, device)
+        self.hubert = hubert_inf.load_model(bc(_load_on_rank0(args.hubert, rank)), device)
+        self.crepe = pitch_inf.load_crepe(bc(_load_on_rank0(args.crepe, rank)), device)
+        ck = _load_on_rank0(args.model, rank)
+        self.model = SynthesizerInfer(self.hp.data.filter_length // 2 + 1, self.hp.data.segment_size // self.hp.data.hop_length, self.hp)
+        sd = bc({k: v for k, v in ck["model_g"].items() if k in self.model.state_dict()} if rank == 0 else None)
+        self.model.load_state_dict({k: v.cpu() for k, v in sd.items()}, strict=False)
+        self.model.eval()
+        self.model.to(device)
+        self.spk = torch.FloatTensor(np.load(args.spk))
+        self.tmp = os.path.join(OUT_PATH, f".rank{rank}")
+
+    def convert(self, wav_path):
+        """One file through PPG / vec / F0 extraction and svc_infer; returns np.float32 audio at hp.data.sampling_rate."""
+        from .hubert import inference as hubert_inf
+        from .pitch import inference as pitch_inf
+        from .svc_inference import DummyRetrieval, shift_pitch, svc_infer
+        from .whisper import inference as whisper_inf
+        ppg_p, vec_p = self.tmp + ".ppg.npy", self.tmp + ".vec.npy"
+        whisper_inf.pred_ppg(self.whisper, wav_path, ppg_p, self.device)
+        hubert_inf.pred_vec(self.hubert, wav_path, vec_p, self.device)
+        pit = pitch_inf.compute_f0_sing(wav_path, self.device, model=self.crepe)
+        ppg = torch.FloatTensor(np.repeat(np.load(ppg_p), 2, 0))
+        vec = torch.FloatTensor(np.repeat(np.load(vec_p), 2, 0))
+        pit = torch.FloatTensor(shift_pitch(np.asarray(pit), self.args.shift))
+        os.remove(ppg_p)
+        os.remove(vec_p)
+        return svc_infer(self.model, DummyRetrieval(), self.spk, pit, ppg, vec, self.hp, self.device, write_pit_wav=False)
+
+
+def run_batch(args, converter_factory=Converter, backend=None):
+    """Shard the folder over the ranks, convert, write ``_svc_out/<file>``.  Returns this rank's file list."""
+    from scipy.io.wavfile import write
+    rank, local_rank, world = D.init_from_env(backend=backend)
+    os.makedirs(OUT_PATH, exist_ok=True)
+    waves = list_waves(args.wave)
+    cost = [os.path.getsize(os.path.join(args.wave, f)) for f in waves]
+    mine = D.shard_utterances(cost, world)[rank]
+    device = torch.device("cuda", local_rank) if torch.cuda.is_available() else torch.device("cpu")
+    conv = converter_factory(args, device, rank, world)
+    t0, audio_s = time.perf_counter(), 0.0
+    sr = conv.hp.data.sampling_rate
+    for i in mine:
+        out = conv.convert(os.path.join(args.wave, waves[i]))
+        write(os.path.join(OUT_PATH, waves[i]), sr, out)
+        audio_s += len(out) / sr
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    rates = D.gather_stats(audio_s / max(time.perf_counter() - t0, 1e-9))
+    if rank == 0:
+        print(f"converted {len(waves)} files on {world} rank(s): {sum(rates):.1f} audio-seconds/s ({', '.join(f'{r:.1f}' for r in rates)})")
+    return [waves[i] for i in mine]
+
+
+def build_parser():
+    import argparse
+    p = argparse.ArgumentParser(description="svcmi drop-in for the reference's svc_inference_batch.py")
+    p.add_argument("--config", type=str, required=True, help="yaml file for config.")
+    p.add_argument("--model", type=str, required=True, help="path of model for evaluation")
+    p.add_argument("--wave", type=str, required=True, help="Path of raw audio (a folder of .wav files).")
+    p.add_argument("--spk", type=str, required=True, help="Path of speaker.")
+    p.add_argument("--shift", type=int, default=0, help="Pitch shift key.")
+    p.add_argument("--whisper", type=str, default=os.path.join("whisper_pretrain", "large-v2.pt"))
+    p.add_argument("--hubert", type=str, default=os.path.join("hubert_pretrain", "hubert-soft-0d54a1f4.pt"))
+    p.add_argument("--crepe", type=str, default=os.path.join("crepe", "assets", "full.pth"))
+    return p
+
+
+if __name__ == "__main__":
+    run_batch(build_parser().parse_args())
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
