@@ -99,7 +99,6 @@ def roofline_pass(wl):
     """Instrumented pass: every launch bracketed by HIP events on the launch stream.  A spin kernel is queued
     first so the host runs ahead and the device executes the launches back-to-back (no host-induced gaps)."""
     ops = wl.ops
-    wl.model.parallel_blocks = False      # one stream: event pairs then bracket exactly one kernel each
     wl.step()
     torch.cuda.synchronize()
     ops.timeline = []
@@ -107,7 +106,6 @@ def roofline_pass(wl):
     wl.step()
     torch.cuda.synchronize()
     tl, ops.timeline = ops.timeline, None
-    wl.model.parallel_blocks = True
     agg = {}
     for name, work, e0, e1 in tl:
         a = agg.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})

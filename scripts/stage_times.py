@@ -2,7 +2,7 @@
 """In-situ wall time of each pipeline segment on the GPU box: the bench step is captured as HIP graphs that stop after
 successive segments (whisper | prior encoder | flow | generator pre | stage 0..4 | output layer) and the replay times are
 differenced.  Unlike a rocprofv3 trace this measures the un-instrumented graph, multi-stream overlap included.
-Usage: python scripts/stage_times.py [--serial]   (--serial: AMP blocks on one stream)"""
+Usage: python scripts/stage_times.py [--ungrouped [--streams]]"""
 import os
 import sys
 
@@ -35,7 +35,9 @@ def main():
     ops = Ops()
     hp = C.base_hp()
     wl = bench.Workload(ops, "cuda", 1, 10.0, W.make_whisper_state(C.WHISPER_LARGE_V2), W.make_vits_state(hp, seed=1234), hp, seed=100)
-    wl.model.parallel_blocks = "--serial" not in sys.argv
+    if "--ungrouped" in sys.argv:        # the pre-r01i structure: one launch per AMP block and step (serial, or forked streams)
+        wl.model.grouped_blocks = False
+        wl.model.parallel_blocks = "--streams" in sys.argv
     full_step = wl.step
 
     def whisper_only():

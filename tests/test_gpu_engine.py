@@ -273,3 +273,18 @@ def test_batch_folder_driver_single_rank(ops, tmp_path, monkeypatch):
         assert sr == hp.data.sampling_rate and x.dtype == np.float32 and np.isfinite(x).all()
         assert abs(len(x) - int(secs * hp.data.sampling_rate)) <= 2 * hp.data.hop_length
     assert not [f for f in os.listdir("_svc_out") if f.startswith(".rank")]          # intermediates removed
+
+
+@pytest.mark.parametrize("streams", [False, True])
+def test_ungrouped_generator_paths_agree(ops, streams):
+    """The fallback structure (one launch per AMP block and step, serial or on forked streams) against the grouped launches."""
+    hp = C.base_hp()
+    m, _ = E.make_model(hp, ops, "cuda")
+    d = I.synth_clip(T=60, hp=hp, seed=11, B=2)
+    src = m.pitch2source(d["pit"], noise=(d["rand_ini"], d["src_noise"]))
+    run = lambda: m.inference(d["ppg"], d["vec"], d["pit"], d["spk"], d["lengths"], src, noise=d["enc_noise"])
+    want = run()
+    m.grouped_blocks, m.parallel_blocks = False, streams
+    got = run()
+    torch.cuda.synchronize()
+    assert E.maxerr(got, want) <= 2e-5

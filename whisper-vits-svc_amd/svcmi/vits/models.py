@@ -10,7 +10,6 @@ Same constructor, ``state_dict``/``load_state_dict`` key names, ``eval``/``to``,
 Internally everything is time-major ``[B, T, C]`` fp32.
 """
 import math
-import os
 from collections import OrderedDict
 
 import torch
@@ -29,10 +28,9 @@ class SynthesizerInfer:
         self._w = None           # packed device weights
         self._device = None
         self.training = False
-        self.parallel_blocks = True      # run the AMP blocks of a generator stage on parallel HIP streams
-        self.grouped_blocks = os.environ.get("SVCMI_AMP_GROUPED", "1") != "0"      # wide stages: grouped launches
+        self.parallel_blocks = False     # fallback for stages the grouped scheme does not fit: AMP blocks on forked HIP streams
+        self.grouped_blocks = True       # the AMP blocks of a stage advance in lock-step through grouped launches
         self._stop_after = None          # tuning aid (scripts/stage_times.py), never set in production
-        self.heavy_first = os.environ.get("SVCMI_AMP_ORDER", "asc") == "desc"
         self._streams, self._streams_dev = None, None
 
     # ------------------------------------------------------------------ nn.Module-like surface
@@ -334,11 +332,10 @@ class SynthesizerInfer:
                     for _ in self._amp_block(w, ops, st, blk, y, acc, bufs[0], j, nb):
                         pass
             else:
-                # heads (all but the final convolution) are enqueued heaviest block first -- the k = 11 chain is the stage's
-                # critical path -- then the tails in block order, which fixes the summation order of `acc`
-                order = sorted(range(nb), key=lambda j: -st["blocks"][j]["k"]) if self.heavy_first else list(range(nb))
+                # heads (all but the final convolution) first, then the tails in block order, which fixes the summation
+                # order of `acc`
                 chains = {}
-                for j in order:
+                for j in range(nb):
                     streams[j].wait_stream(main)
                     with torch.cuda.stream(streams[j]):
                         chains[j] = self._amp_block(w, ops, st, st["blocks"][j], y, acc, bufs[j], j, nb, done=done)
