@@ -489,12 +489,15 @@ __global__ __launch_bounds__(64 * NS) void attention_kernel(AttnArgs p) {
     }
 }
 
+int g_attn_ns = 0;      // tuning knob (svcmi_tune_set("attn_ns", 0 | 1 | 2 | 4 | 8)); 0 = heuristic
+
 template <int D>
 int launch_attn(const AttnArgs& a, int batch, void* stream) {
     // key-split NS: ~2 waves per SIMD (1024 SIMDs), but keep >= 64 keys per wave
     const long long blocks = (long long)a.nq * a.heads * batch;
     int ns = 1;
     while (ns < 8 && blocks * ns < 2048 && a.t >= 128 * ns) ns *= 2;
+    if (g_attn_ns) ns = g_attn_ns;
     dim3 grid((unsigned)blocks);
     switch (ns) {
         case 1: SVCMI_LAUNCH((attention_kernel<D, 1>), grid, dim3(64), 0, stream, a); break;
@@ -582,4 +585,13 @@ extern "C" int svcmi_attention_f32(const float* q, const float* k, const float* 
         case 96: return launch_attn<96>(a, batch, stream);
         default: return SVCMI_EUNSUPPORTED;
     }
+}
+
+// Development knob (reached through svcmi_tune_set): results do not depend on it beyond fp32 re-association of the key split.
+extern "C" int svcmi_attn_tune_set(const char* name, int32_t value) {
+    const char* k = "attn_ns";
+    int i = 0;
+    while (k[i] && name[i] == k[i]) ++i;
+    if (k[i] == 0 && name[i] == 0 && (value == 0 || value == 1 || value == 2 || value == 4 || value == 8)) { g_attn_ns = value; return 0; }
+    return SVCMI_EINVAL;
 }
