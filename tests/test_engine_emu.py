@@ -35,7 +35,7 @@ def test_crepe_tiny_matches_oracle(ops):
 
 
 def test_svc_infer_with_knn_retrieval(ops):
-    print(E.check_svc_infer_retrieval(ops, "cpu", T=24, check_changed=False))
+    print(E.check_svc_infer_retrieval(ops, "cpu", T=10, check_changed=False))
 
 
 def test_generator_base_widths_match_oracle(ops):
