@@ -64,7 +64,7 @@ def test_knn_blend(ops, t, n, d, k, ratio):
     K.check_knn_blend(ops, "cpu", t, n, d, k, ratio)
 
 
-@pytest.mark.parametrize("n,c", [(150, 40), (70, 80), (90, 16)])
+@pytest.mark.parametrize("n,c", [(150, 40), (70, 80), (90, 16), (40, 32)])
 def test_grouped_launches(ops, n, c):
     K.check_grouped_launches(ops, "cpu", B=2, n=n, c=c, ld=c)
 
