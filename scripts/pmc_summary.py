@@ -12,8 +12,8 @@ import sys
 
 def short(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
-    m = re.match(r"([A-Za-z0-9_:]+)", name)
-    return m.group(1) if m else name[:40]
+    m = re.match(r"([A-Za-z0-9_:]+)(<[^>(]*>)?", name)      # keep the template arguments: tile policies are separate rows
+    return (m.group(1) + (m.group(2) or "").replace(" ", "")) if m else name[:40]
 
 
 def load(d):
