@@ -165,11 +165,13 @@ def main():
             rk = torch.randn(9, D, device="cuda") * 0.1 if rel else None
             rv = torch.randn(9, D, device="cuda") * 0.1 if rel else None
             out = torch.empty(1, T, H * D, device="cuda")
-            for ns in (0, 2, 4, 8):
-                assert ops.lib.svcmi_tune_set(b"attn_ns", ns) == 0
-                us = timeit(lambda: ops.attention(qkv, H, D ** -0.5, rel_k=rk, rel_v=rv, window=4 if rel else 0, out=out))
-                print(f"attn T={T} H={H} D={D} rel={rel} ns={ns}: {us:8.1f} us  {4.0 * T * T * H * D / us / 1e6:7.1f} TF/s", flush=True)
+            for q32 in ((0, 1) if not rel else (0,)):
+                for ns in (0, 2, 4, 8):
+                    assert ops.lib.svcmi_tune_set(b"attn_ns", ns) == 0 and ops.lib.svcmi_tune_set(b"attn_q32", q32) == 0
+                    us = timeit(lambda: ops.attention(qkv, H, D ** -0.5, rel_k=rk, rel_v=rv, window=4 if rel else 0, out=out))
+                    print(f"attn T={T} H={H} D={D} rel={rel} q32={q32} ns={ns}: {us:8.1f} us  {4.0 * T * T * H * D / us / 1e6:7.1f} TF/s", flush=True)
         ops.lib.svcmi_tune_set(b"attn_ns", 0)
+        ops.lib.svcmi_tune_set(b"attn_q32", -1)
 
 
 if __name__ == "__main__":

@@ -197,6 +197,14 @@ ATTN_CASES_SMALL = [
     dict(id="d32_rel_w2_T140_keysplit2", B=1, T=140, H=2, D=32, rel=True, W=2, lengths=[133]),
     dict(id="d96_rel_T260_keysplit4", B=2, T=260, H=2, D=96, rel=True, W=4, lengths=[260, 201]),
 ]
+# band-free cases forced through the two-query-tile kernel (the heuristic only picks it for >= 512 (head, q-tile) blocks)
+ATTN_CASES_Q32 = [
+    dict(id="q32_d32_plain_T70", B=1, T=70, H=3, D=32, q32=True),
+    dict(id="q32_d64_T130_ns2", B=1, T=130, H=2, D=64, q32=True, ns=2),
+    dict(id="q32_d64_ragged_T77", B=2, T=77, H=2, D=64, lengths=[77, 40], q32=True),
+    dict(id="q32_d16_T33_ns1", B=1, T=33, H=1, D=16, q32=True, ns=1),
+    dict(id="q32_d64_T300_ns4", B=1, T=300, H=2, D=64, q32=True, ns=4),
+]
 ATTN_CASES_LARGE = [
     dict(id="whisper_T500", B=1, T=500, H=20, D=64),
     dict(id="encp_T1000", B=1, T=1000, H=2, D=96, rel=True, W=4),
@@ -242,9 +250,13 @@ def check_attention(ops, c, device):
     scale = D ** -0.5
     want = attention_reference(qkv, H, scale, rel_k, rel_v, c.get("W", 0), lengths)
     dev = lambda t: None if t is None else t.to(device)
-    got = ops.attention(dev(qkv), H, scale, rel_k=dev(rel_k), rel_v=dev(rel_v), window=c.get("W", 0), lengths=dev(lengths))
-    if lengths is not None:   # rows past the length are "don't care" in the engine contract? No: they match too.
-        pass
+    if c.get("q32"):
+        assert ops.lib.svcmi_tune_set(b"attn_q32", 1) == 0 and ops.lib.svcmi_tune_set(b"attn_ns", c.get("ns", 0)) == 0
+    try:
+        got = ops.attention(dev(qkv), H, scale, rel_k=dev(rel_k), rel_v=dev(rel_v), window=c.get("W", 0), lengths=dev(lengths))
+    finally:
+        ops.lib.svcmi_tune_set(b"attn_q32", -1)
+        ops.lib.svcmi_tune_set(b"attn_ns", 0)
     _close(got, want, 2e-5, c["id"])
 
 

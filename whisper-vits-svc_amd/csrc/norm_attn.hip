@@ -489,16 +489,203 @@ __global__ __launch_bounds__(64 * NS) void attention_kernel(AttnArgs p) {
     }
 }
 
+// Plain (no relative-position band) attention with TWO 16-query tiles per wave: every K / V fragment a wave fetches feeds
+// twice the MFMAs (PMC: the one-tile kernel spends 47 % of its wave-cycles parked on memory at Whisper's T = 500 and
+// keeps the matrix pipe 22 % busy), and the four QK accumulators of a step are independent.  Same key split / merge.
+template <int D, int NS>
+__global__ __launch_bounds__(64 * NS) void attention_q32_kernel(AttnArgs p) {
+    constexpr int DS = D / 16, OLD = D + 4, QT = 2, QB = 16 * QT;
+    __shared__ __attribute__((aligned(16))) float smem[NS * QB * OLD + 2 * NS * QB];
+    float* const Opart = smem;                         // [NS][QB][OLD]
+    float* const Mpart = Opart + NS * QB * OLD;        // [NS][QB]
+    float* const Lpart = Mpart + NS * QB;              // [NS][QB]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = SVCMI_UNIFORM((int)(tid >> 6));
+    const int lq = lane & 15, g4 = lane >> 4;
+    int L;
+    {
+        const int total = (int)gridDim.x, id = (int)blockIdx.x;
+        const int q8 = total >> 3, r8 = total & 7, xcd = id & 7, slot = id >> 3;
+        L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    }
+    const int qt = L % p.nq, hb = L / p.nq;
+    const int h = hb % p.heads, b = hb / p.heads;
+    const int T = p.t;
+    const int len = p.lengths ? p.lengths[b] : T;
+    const int q0 = qt * QB;
+
+    float qf[QT][DS][4];
+#pragma unroll
+    for (int a = 0; a < QT; ++a) {
+        const int qi = q0 + 16 * a + lq;
+        const float* qp = p.q + (long long)b * p.q_bs + (long long)(qi < T ? qi : T - 1) * p.ldq + h * D + 4 * g4;
+#pragma unroll
+        for (int s = 0; s < DS; ++s) {
+            const float4 t4 = *reinterpret_cast<const float4*>(qp + 16 * s);
+            qf[a][s][0] = t4.x; qf[a][s][1] = t4.y; qf[a][s][2] = t4.z; qf[a][s][3] = t4.w;
+        }
+    }
+    svcmi_f32x4 oacc[QT][DS];
+    float mrun[QT], lrun[QT];
+#pragma unroll
+    for (int a = 0; a < QT; ++a) {
+        mrun[a] = NEG_BIG; lrun[a] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DS; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) oacc[a][dt][r] = 0.f;
+    }
+
+    const float* kb = p.k + (long long)b * p.k_bs + h * D + 4 * g4;
+    const float* vb = p.v + (long long)b * p.v_bs + h * D + lq;
+    const int per = ((T + NS - 1) / NS + 31) / 32 * 32;
+    const int jbeg = w * per;
+    const int jend = (jbeg + per) < T ? (jbeg + per) : T;
+
+    for (int kt = jbeg; kt < jend; kt += 32) {
+        svcmi_f32x4 sacc[QT][2];
+#pragma unroll
+        for (int a = 0; a < QT; ++a)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sacc[a][u][r] = 0.f;
+        {
+            const int k0 = kt + lq, k1 = kt + 16 + lq;
+            const float* kr0 = kb + (long long)(k0 < T ? k0 : T - 1) * p.ldk;
+            const float* kr1 = kb + (long long)(k1 < T ? k1 : T - 1) * p.ldk;
+#pragma unroll
+            for (int s = 0; s < DS; ++s) {
+                const float4 a0 = *reinterpret_cast<const float4*>(kr0 + 16 * s);
+                const float4 a1 = *reinterpret_cast<const float4*>(kr1 + 16 * s);
+                const float k0v[4] = {a0.x, a0.y, a0.z, a0.w}, k1v[4] = {a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int a = 0; a < QT; ++a) {
+                        sacc[a][0] = svcmi_mfma_16x16x4(k0v[c], qf[a][s][c], sacc[a][0]);
+                        sacc[a][1] = svcmi_mfma_16x16x4(k1v[c], qf[a][s][c], sacc[a][1]);
+                    }
+            }
+        }
+        float pv[QT][2][4];
+#pragma unroll
+        for (int a = 0; a < QT; ++a) {
+            const int qi = q0 + 16 * a + lq;
+            float sv[2][4];
+            float mt = NEG_BIG;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt + 16 * u + 4 * g4 + r;
+                    float v = sacc[a][u][r] * p.scale;
+                    if (qi >= len || key >= len) v = -1.0e4f;       // masked_fill(mask == 0, -1e4)
+                    if (key >= T) v = NEG_BIG;                      // beyond the sequence: weight 0
+                    sv[u][r] = v;
+                    mt = fmaxf(mt, v);
+                }
+            mt = fmaxf(mt, __shfl_xor(mt, 16));
+            mt = fmaxf(mt, __shfl_xor(mt, 32));
+            const float mnew = fmaxf(mrun[a], mt);
+            const float corr = expf(mrun[a] - mnew);
+            mrun[a] = mnew;
+            lrun[a] *= corr;
+#pragma unroll
+            for (int dt = 0; dt < DS; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) oacc[a][dt][r] *= corr;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pv[a][u][r] = expf(sv[u][r] - mnew);
+                    lrun[a] += pv[a][u][r];
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt + 16 * u + 4 * g4 + r;
+                const float* vr = vb + (long long)(key < T ? key : T - 1) * p.ldv;
+#pragma unroll
+                for (int dt = 0; dt < DS; ++dt) {
+                    const float vv = vr[16 * dt];
+#pragma unroll
+                    for (int a = 0; a < QT; ++a) oacc[a][dt] = svcmi_mfma_16x16x4(vv, pv[a][u][r], oacc[a][dt]);
+                }
+            }
+    }
+
+#pragma unroll
+    for (int a = 0; a < QT; ++a) {
+        const float lsum = quarter_sum(lrun[a]);
+        float* orow = Opart + (w * QB + 16 * a + lq) * OLD + 4 * g4;
+#pragma unroll
+        for (int dt = 0; dt < DS; ++dt)
+            *reinterpret_cast<float4*>(orow + 16 * dt) = make_float4(oacc[a][dt][0], oacc[a][dt][1], oacc[a][dt][2], oacc[a][dt][3]);
+        if (g4 == 0) {
+            Mpart[w * QB + 16 * a + lq] = mrun[a];
+            Lpart[w * QB + 16 * a + lq] = lsum;
+        }
+    }
+    __syncthreads();
+
+    float* ob = p.o + (long long)b * p.o_bs + h * D;
+    for (int item = tid; item < QB * (D / 4); item += 64 * NS) {
+        const int ql = item / (D / 4), c4 = (item - ql * (D / 4)) * 4;
+        float mall = Mpart[ql];
+#pragma unroll
+        for (int ww = 1; ww < NS; ++ww) mall = fmaxf(mall, Mpart[ww * QB + ql]);
+        float den = 0.f;
+        float4 num = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int ww = 0; ww < NS; ++ww) {
+            const float cw = expf(Mpart[ww * QB + ql] - mall);
+            den = fmaf(cw, Lpart[ww * QB + ql], den);
+            const float4 ov = *reinterpret_cast<const float4*>(Opart + (ww * QB + ql) * OLD + c4);
+            num.x = fmaf(cw, ov.x, num.x); num.y = fmaf(cw, ov.y, num.y);
+            num.z = fmaf(cw, ov.z, num.z); num.w = fmaf(cw, ov.w, num.w);
+        }
+        const int qrow = q0 + ql;
+        if (qrow < T) {
+            const float inv = 1.0f / den;
+            *reinterpret_cast<float4*>(ob + (long long)qrow * p.ldo + c4) = make_float4(num.x * inv, num.y * inv, num.z * inv, num.w * inv);
+        }
+    }
+}
+
 int g_attn_ns = 0;      // tuning knob (svcmi_tune_set("attn_ns", 0 | 1 | 2 | 4 | 8)); 0 = heuristic
 
+int g_attn_q32 = -1;    // tuning knob ("attn_q32", -1 = heuristic | 0 | 1): two query tiles per wave for band-free attention
+
 template <int D>
-int launch_attn(const AttnArgs& a, int batch, void* stream) {
+int launch_attn(const AttnArgs& a_in, int batch, void* stream) {
+    AttnArgs a = a_in;
+    // two query tiles per wave: measured (scripts/microbench.py attn) 149.7 vs 176.0 us at T = 1500 (20 heads, 2-way key split),
+    // but 33.5 vs 30.0 us at T = 500, where the launch is latency-bound -- so only for long sequences
+    const bool q32 = g_attn_q32 >= 0 ? (g_attn_q32 != 0 && !a.rel_k) : (!a.rel_k && D <= 64 && a.t >= 1024);
+    if (q32) a.nq = (a.t + 31) / 32;
     // key-split NS: ~2 waves per SIMD (1024 SIMDs), but keep >= 64 keys per wave
     const long long blocks = (long long)a.nq * a.heads * batch;
     int ns = 1;
     while (ns < 8 && blocks * ns < 2048 && a.t >= 128 * ns) ns *= 2;
+    if (q32 && g_attn_q32 < 0) ns = 2;
     if (g_attn_ns) ns = g_attn_ns;
     dim3 grid((unsigned)blocks);
+    if (q32) {
+        if constexpr (D <= 64) {
+            switch (ns) {
+                case 1: SVCMI_LAUNCH((attention_q32_kernel<D, 1>), grid, dim3(64), 0, stream, a); break;
+                case 2: SVCMI_LAUNCH((attention_q32_kernel<D, 2>), grid, dim3(128), 0, stream, a); break;
+                case 4: SVCMI_LAUNCH((attention_q32_kernel<D, 4>), grid, dim3(256), 0, stream, a); break;
+                default: SVCMI_LAUNCH((attention_q32_kernel<D, 8>), grid, dim3(512), 0, stream, a); break;
+            }
+            return SVCMI_LAST_ERROR();
+        }
+    }
     switch (ns) {
         case 1: SVCMI_LAUNCH((attention_kernel<D, 1>), grid, dim3(64), 0, stream, a); break;
         case 2: SVCMI_LAUNCH((attention_kernel<D, 2>), grid, dim3(128), 0, stream, a); break;
@@ -593,5 +780,9 @@ extern "C" int svcmi_attn_tune_set(const char* name, int32_t value) {
     int i = 0;
     while (k[i] && name[i] == k[i]) ++i;
     if (k[i] == 0 && name[i] == 0 && (value == 0 || value == 1 || value == 2 || value == 4 || value == 8)) { g_attn_ns = value; return 0; }
+    const char* k2 = "attn_q32";
+    i = 0;
+    while (k2[i] && name[i] == k2[i]) ++i;
+    if (k2[i] == 0 && name[i] == 0 && value >= -1 && value <= 1) { g_attn_q32 = value; return 0; }
     return SVCMI_EINVAL;
 }
