@@ -1,0 +1,73 @@
+"""Property tests (hypothesis) of the host-side arithmetic of the path: the chunk schedule with its halo trim, the Whisper /
+HuBERT window plans, the pitch shift and CSV round trip, and the LPT sharding -- the product's copies against the oracle's
+restatements and against the invariants the reference's loops rely on."""
+import numpy as np
+from hypothesis import given, settings, strategies as st
+
+from oracle import svc_oracle as O
+from svcmi import dist as D
+from svcmi.hubert.inference import window_plan as hubert_plan
+from svcmi.pitch import inference as PI
+from svcmi.svc_inference import chunk_schedule, shift_pitch
+from svcmi.whisper.inference import window_plan as whisper_plan
+
+
+@settings(max_examples=200, deadline=None)
+@given(st.integers(1, 20000), st.sampled_from([160, 320]))
+def test_chunk_schedule_tiles_the_output_exactly(T, hop):
+    plan = chunk_schedule(T, hop)
+    assert plan == O.chunk_schedule(T, hop)
+    if T > 2500 and 1 <= T % 2500 <= 10:
+        # quirk of svc_inference.py:108-115 kept as is: when T ends within the 10-frame halo past a chunk boundary, the chunk
+        # before the last already runs to the end, and the last chunk repeats those <= 10 frames
+        assert plan[-2][1] == plan[-1][1] == T
+        return
+    kept = 0
+    for i, (cs, ce, cso, ceo) in enumerate(plan):
+        assert 0 <= cs < ce <= T and ce - cs <= 2500 + 2 * 10
+        n = (ce - cs) * hop                         # samples the generator makes for the chunk
+        lo, hi = cso, n + ceo                       # python slice [cso:ceo] with negative ceo
+        assert 0 <= lo < hi <= n
+        # the kept samples of chunk i start where chunk i-1's stopped (svc_inference.py:101-131)
+        assert cs * hop + lo == kept
+        kept = cs * hop + hi
+    assert kept == T * hop - 1                       # the reference drops the very last sample ([..:-1] on the last chunk)
+
+
+@settings(max_examples=200, deadline=None)
+@given(st.integers(1, 16000 * 70))
+def test_window_plans_cover_the_audio(n):
+    wp = whisper_plan(n)
+    assert all(k == (b - a) // 320 for a, b, k in wp)            # kept PPG frames per window (whisper/inference.py:40)
+    for plan, win in (([w[:2] for w in wp], 15 * 16000), (hubert_plan(n), 20 * 16000)):
+        assert plan[0][0] == 0 and plan[-1][1] == n
+        for (a, b), (c, d) in zip(plan, plan[1:]):
+            assert b == c and b - a == win           # full windows, back to back
+        assert 0 < plan[-1][1] - plan[-1][0] <= win
+
+
+@settings(max_examples=100, deadline=None)
+@given(f0=st.lists(st.integers(0, 1200), min_size=1, max_size=50).filter(lambda v: any(x > 0 for x in v)), shift=st.integers(-12, 12))
+def test_pitch_shift_and_csv_round_trip(tmp_path_factory, f0, shift):
+    pit = np.asarray(f0, dtype=np.float64)
+    out = shift_pitch(pit, shift)
+    if shift == 0:
+        assert np.array_equal(out, pit)
+    else:
+        assert np.allclose(out, pit * 2 ** (shift / 12))          # svc_inference.py:185-200
+        assert np.array_equal(out == 0, pit == 0)                  # unvoiced frames stay unvoiced
+    path = tmp_path_factory.mktemp("csv") / "p.csv"
+    PI.save_csv_pitch(pit, str(path))
+    back = PI.load_csv_pitch(str(path))
+    assert back == [int(v) for v in pit]                           # pitch/inference.py:102-119: integer Hz per 10 ms frame
+
+
+@settings(max_examples=200, deadline=None)
+@given(st.lists(st.integers(1, 10 ** 6), min_size=0, max_size=60), st.integers(1, 8))
+def test_lpt_sharding_invariants(lengths, world):
+    shards = D.shard_utterances(lengths, world)
+    assert len(shards) == world
+    assert sorted(i for s in shards for i in s) == list(range(len(lengths)))
+    if lengths:
+        loads = [sum(lengths[i] for i in s) for s in shards]
+        assert max(loads) - min(loads) <= max(lengths)
