@@ -35,6 +35,10 @@ static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 
 typedef float svcmi_f32x16 __attribute__((vector_size(64)));
 typedef float svcmi_f32x4 __attribute__((vector_size(16)));
+typedef float svcmi_f32x2 __attribute__((vector_size(8)));
+static inline svcmi_f32x2 svcmi_fma2(svcmi_f32x2 a, svcmi_f32x2 b, svcmi_f32x2 c) { return svcmi_f32x2{fmaf(a[0], b[0], c[0]), fmaf(a[1], b[1], c[1])}; }
+static inline svcmi_f32x2 svcmi_splat2(float v) { return svcmi_f32x2{v, v}; }
+static inline float svcmi_sgpr_const(float v) { return v; }
 
 typedef void* hipStream_t;
 

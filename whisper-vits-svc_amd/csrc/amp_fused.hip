@@ -28,39 +28,7 @@ constexpr int RT = 8;        // SnakeAlias outputs per work item (run along time
 constexpr int CO = 10;       // output channels per thread
 constexpr int DMAX = 5;      // largest dilation (bigv.py dilations 1, 3, 5)
 
-__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
-
-// cold path of sin_sq as a real call: inlined, the 26 unrolled copies of libm's large-argument reduction made the kernel
-// 5600 instructions (45 KB) for ~1200 hot ones
-__device__ __attribute__((noinline)) float sin_sq_huge(float x) {
-    const float sl = sinf(x);
-    return sl * sl;
-}
-
-// sin^2 by range reduction to [-pi/2, pi/2] + degree-11 minimax polynomial (see generator.hip: sin_sq)
-__device__ __forceinline__ float sin_sq(float x) {
-    if (__builtin_expect(fabsf(x) > 1.0e5f, 0)) return sin_sq_huge(x);
-    const float n = rintf(x * 0.31830987f);
-    float r = fmaf(-n, 3.1415927f, x);
-    r = fmaf(-n, -8.742278e-08f, r);
-    const float u = r * r;
-    float p = -2.3840804885821854e-08f;
-    p = fmaf(p, u, 2.7522235086507862e-06f);
-    p = fmaf(p, u, -0.00019840795721393079f);
-    p = fmaf(p, u, 0.008333330042660236f);
-    p = fmaf(p, u, -0.1666666716337204f);
-    const float sn = fmaf(r * u, p, r);
-    return sn * sn;
-}
-__device__ __forceinline__ float snake_fn(float y, float a, float inv_b) { return fmaf(inv_b, sin_sq(y * a), y); }
-
-__device__ __forceinline__ float snake_s_at(const float* xc, int ld, int n, int u, const float* f, float a, float inv_b) {
-    const int tq = u >> 1, odd = u & 1;
-    float y = 0.f;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) y = fmaf(f[2 * j + 1 - odd], xc[(long long)clampi(tq + 2 + odd - j, 0, n - 1) * ld], y);
-    return snake_fn(2.f * y, a, inv_b);
-}
+#include "snake_math.h"
 
 struct AmpArgs {
     const float* x; const float* w; const float* bias; const float* res; float* y;
@@ -94,35 +62,11 @@ __device__ __forceinline__ void snake_tile(float* S, const float* xb, const floa
                 float xw[RT + 10];
 #pragma unroll
                 for (int i = 0; i < RT + 10; ++i) xw[i] = xc[(long long)clampi(t0 - 5 + i, 0, n - 1) * ld];
-                float s[2 * RT + 10];
-#pragma unroll
-                for (int m = 0; m < RT + 5; ++m) {
-                    float yo = 0.f, ye = 0.f;
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) {
-                        yo = fmaf(f[2 * j], xw[5 - j + m], yo);
-                        ye = fmaf(f[2 * j + 1], xw[5 - j + m], ye);
-                    }
-                    s[2 * m] = snake_fn(2.f * yo, a, inv_b);
-                    s[2 * m + 1] = snake_fn(2.f * ye, a, inv_b);
-                }
-                const int u0 = 2 * t0 - 5;
-                if (u0 < 0 || u0 + 2 * RT + 9 > 2 * n - 1) {
-                    const float s_first = snake_s_at(xc, ld, n, 0, f, a, inv_b);
-                    const float s_last = snake_s_at(xc, ld, n, 2 * n - 1, f, a, inv_b);
-#pragma unroll
-                    for (int j = 0; j < 2 * RT + 10; ++j) {
-                        const int u = u0 + j;
-                        s[j] = u < 0 ? s_first : (u > 2 * n - 1 ? s_last : s[j]);
-                    }
-                }
+                snake_run<RT>(xw, f, a, inv_b, xc, ld, n, t0, out);
 #pragma unroll
                 for (int r = 0; r < RT; ++r) {
-                    float z = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 12; ++k) z = fmaf(f[k], s[2 * r + k], z);
                     const int t = t0 + r;
-                    out[r] = (t >= 0 && t < n) ? z : 0.f;      // the convolution's zero padding
+                    if (t < 0 || t >= n) out[r] = 0.f;      // the convolution's zero padding
                 }
             }
 #pragma unroll

@@ -17,6 +17,16 @@
 
 typedef float svcmi_f32x16 __attribute__((ext_vector_type(16)));
 typedef float svcmi_f32x4 __attribute__((ext_vector_type(4)));
+typedef float svcmi_f32x2 __attribute__((ext_vector_type(2)));      // packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32)
+__device__ __forceinline__ svcmi_f32x2 svcmi_fma2(svcmi_f32x2 a, svcmi_f32x2 b, svcmi_f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ svcmi_f32x2 svcmi_splat2(float v) { return svcmi_f32x2{v, v}; }
+// A constant the compiler must keep in a scalar register: packed instructions cannot encode literals, and given a literal the
+// instruction selector prefers two scalar v_fmaak_f32 over one v_pk_fma_f32 -- an SGPR operand keeps the polynomial packed.
+__device__ __forceinline__ float svcmi_sgpr_const(float v) {
+    int i = __builtin_bit_cast(int, v);
+    asm("" : "+s"(i));
+    return __builtin_bit_cast(float, i);
+}
 
 // D = A(32x2) * B(2x32) + C, exact fp32 (v_mfma_f32_32x32x2_f32).  Lane l supplies
 // A[i=l&31][k=l>>5] and B[k=l>>5][j=l&31]; C/D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5).
