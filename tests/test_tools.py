@@ -136,3 +136,18 @@ def test_retrieval_cli_paths(tmp_path, monkeypatch):
     np.save(d / "b.npy", np.zeros((2, 8), np.float32))
     bank = FR.build_index_bank(tmp_path / "feat", tmp_path / "bank.npy")
     assert bank.shape == (5, 8) and np.array_equal(np.load(tmp_path / "bank.npy"), bank)
+
+
+def test_retrieval_oracle_search_matches_sklearn_brute_force():
+    """faiss is absent, so the search half of the retrieval oracle is cross-checked against an independent exhaustive
+    implementation (scikit-learn, squared-euclidean metric -- what faiss METRIC_L2 reports)."""
+    from sklearn.neighbors import NearestNeighbors
+    from oracle import retrieval_oracle as RO
+    rng = np.random.default_rng(3)
+    bank = rng.standard_normal((500, 24)).astype(np.float32)
+    x = rng.standard_normal((40, 24)).astype(np.float32)
+    nn = NearestNeighbors(n_neighbors=3, algorithm="brute", metric="sqeuclidean").fit(bank.astype(np.float64))
+    dist, ids = nn.kneighbors(x.astype(np.float64))
+    scores, got = RO.knn_search(x, bank, 3)
+    assert np.array_equal(got, ids)
+    assert np.allclose(scores, dist, rtol=1e-5)
