@@ -9,6 +9,8 @@
 Pure state-dict arithmetic on the host (torch CPU tensors / numpy), no kernels involved.
 """
 import collections
+import functools
+import operator
 import os
 
 import numpy as np
@@ -47,14 +49,10 @@ def save_pretrain(checkpoint_path, save_path):
 
 
 def average_model(model_list):
-    """svc_merge.py:17-25."""
-    out = collections.OrderedDict()
-    for key in model_list[0].keys():
-        key_sum = 0
-        for m in model_list:
-            key_sum = key_sum + m[key]
-        out[key] = torch.div(key_sum, float(len(model_list)))
-    return out
+    """svc_merge.py:17-25: per key, ``(0 + m_0 + m_1 + ...) / n`` in list order."""
+    n = float(len(model_list))
+    return collections.OrderedDict(
+        (key, torch.div(functools.reduce(operator.add, (m[key] for m in model_list), 0), n)) for key in model_list[0].keys())
 
 
 def merge_model(model1, model2, rate):
