@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SVCMI_ABI_VERSION 13
+#define SVCMI_ABI_VERSION 14
 
 enum svcmi_status { SVCMI_OK = 0, SVCMI_EINVAL = -1, SVCMI_EUNSUPPORTED = -2, SVCMI_EALIGN = -3 };
 
@@ -304,10 +304,12 @@ int svcmi_bn_maxpool2_f32(const float* x, const float* scale, const float* shift
 /* Viterbi decoding of the 360-bin pitch posteriorgram (crepe/decode.py:53-80; librosa.sequence.viterbi semantics: uniform
  * prior, log domain): prob [frames][360] = the network's sigmoid outputs; bins outside [minidx, maxidx) are excluded
  * (crepe/core.py:597-598); softmax over the rest in fp32, DP in fp64, independently per batch of `batch_frames` frames
- * (crepe/core.py:683-686).  log_trans: [360][360] doubles = log(transition + tiny).  lp_scratch: frames*360 floats,
- * ptr_scratch: frames*360 int16.  path: [frames] decoded bins. */
+ * (crepe/core.py:683-686).  log_trans: [360][360] doubles = log(transition + tiny).  band > 0 declares the matrix banded:
+ * every entry with |i - j| > band equals log_trans[0][359] (CREPE's transition: band = 11); the DP then evaluates 2*band + 1
+ * predecessors plus the best out-of-band one per state instead of all 360 (same result, ties to the lowest index).  band = 0:
+ * dense.  lp_scratch: frames*360 floats, ptr_scratch: frames*360 int16.  path: [frames] decoded bins. */
 int svcmi_viterbi_decode(const float* prob, const double* log_trans, float* lp_scratch, int16_t* ptr_scratch, int32_t* path,
-                         int32_t frames, int32_t batch_frames, int32_t minidx, int32_t maxidx, void* stream);
+                         int32_t frames, int32_t batch_frames, int32_t minidx, int32_t maxidx, int32_t band, void* stream);
 
 /* Feature retrieval (row N4; feature_retrieval/index.py:57-94 -- faiss search_and_reconstruct + the RVC weighting):
  *   row_sqnorm: out[r] = sum_c x[r, c]^2 (the |b|^2 term of the bank, computed once per index).

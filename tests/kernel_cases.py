@@ -119,15 +119,27 @@ def check_layernorm(ops, c, device):
     _close(ops.layernorm(x.to(device), gb.to(device), bb.to(device), per_batch_affine=True), want, 2e-5, "ln per-batch")
 
 
-def check_viterbi(ops, device, frames=70, batch_frames=32):
+def check_viterbi(ops, device, frames=70, batch_frames=32, jumps=False):
     """Device Viterbi (fp32 softmax, fp64 DP, per decoding batch) vs the host restatement of librosa.sequence.viterbi."""
     from svcmi.pitch import inference as PI
     g = _g(31 + frames)
     centre = 120 + 40 * torch.sin(torch.arange(frames) / 7.0)
-    prob = torch.sigmoid(-((torch.arange(360)[None, :] - centre[:, None]) / 6.0) ** 2 + 0.8 * torch.randn(frames, 360, generator=g))
+    if jumps:          # octave-like leaps far outside the 11-bin band, with sharp posteriors: the out-of-band predecessor wins
+        centre = centre + 150.0 * ((torch.arange(frames) // 9) % 2)
+    sharp = 40.0 if jumps else 1.0
+    prob = torch.sigmoid(sharp * -((torch.arange(360)[None, :] - centre[:, None]) / 6.0) ** 2 + 0.8 * torch.randn(frames, 360, generator=g))
     lo, hi = PI._frequency_to_bins(50.0), PI._frequency_to_bins(1000.0, ceil=True)
-    lt = torch.from_numpy(np.log(PI._transition() + np.finfo(np.float32).tiny))
-    got = ops.viterbi_decode(prob.to(device), lt.to(device), batch_frames, lo, hi).cpu().numpy()
+    # with CREPE's own matrix a leap costs log(tiny) = -87 nats against <= 1 nat of evidence per frame and never pays; the jump case
+    # uses a milder floor so that the out-of-band predecessor is actually taken
+    lt = torch.from_numpy(np.log(PI._transition() + (0.5 if jumps else np.finfo(np.float32).tiny)))
+    band = PI.transition_band(PI._transition())
+    assert band == 11
+    dense = ops.viterbi_decode(prob.to(device), lt.to(device), batch_frames, lo, hi).cpu().numpy()
+    got = ops.viterbi_decode(prob.to(device), lt.to(device), batch_frames, lo, hi, band=band).cpu().numpy()
+    assert np.array_equal(got, dense)                      # the banded DP is the dense one, bit for bit
+    if jumps:
+        assert np.abs(np.diff(got)).max() > 100            # the path really leaves the band
+        return
     want = []
     for i in range(0, frames, batch_frames):
         p = prob[i:i + batch_frames].t().clone()

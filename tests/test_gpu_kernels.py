@@ -84,8 +84,9 @@ def test_snake_post(ops, n):
     K.check_snake_post(ops, "cuda", B=1 if n > 100000 else 2, n=n)
 
 
-def test_viterbi_decode(ops):
-    K.check_viterbi(ops, "cuda", frames=1100, batch_frames=512)
+@pytest.mark.parametrize("jumps", [False, True])
+def test_viterbi_decode(ops, jumps):
+    K.check_viterbi(ops, "cuda", frames=1100, batch_frames=512, jumps=jumps)
 
 
 def test_flow_glue(ops):

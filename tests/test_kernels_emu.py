@@ -79,8 +79,9 @@ def test_snake_post(ops, n):
     K.check_snake_post(ops, "cpu", B=2, n=n)
 
 
-def test_viterbi_decode(ops):
-    K.check_viterbi(ops, "cpu", frames=40, batch_frames=16)
+@pytest.mark.parametrize("jumps", [False, True])
+def test_viterbi_decode(ops, jumps):
+    K.check_viterbi(ops, "cpu", frames=40, batch_frames=16, jumps=jumps)
 
 
 def test_flow_glue(ops):

@@ -206,17 +206,130 @@ __global__ __launch_bounds__(384) void viterbi_dp_kernel(const float* lp, const 
     }
 }
 
+// The same dynamic programme for a BANDED transition matrix (CREPE's: weight max(12 - |i - j|, 0), i.e. |i - j| <= 11 in band,
+// everything else log(0 + tiny) = one constant).  Per frame a state compares its 2*band + 1 in-band predecessors plus the
+// best out-of-band one, which is max(prev[0 .. k-band-1]) or max(prev[k+band+1 ..]) + that constant: the two running maxima
+// (value + lowest index attaining it) come from a prefix and a suffix scan done by waves 0 and 1 (6 states per lane, then a
+// shuffle scan over the lane totals).  25 candidates per state instead of 360: the dense kernel took 9.0 ms for the 501
+// frames of a 10 s clip.  Candidates are visited in ascending predecessor order with strict >, so ties resolve to the
+// lowest index exactly like the dense loop (sums that only become equal through rounding of `+ constant` excepted).
+constexpr int VBAND_MAX = 15;
+constexpr double VNEG = -1.0e300;
+
+__global__ __launch_bounds__(384) void viterbi_dp_banded_kernel(const float* lp, const double* log_trans, short* ptr, int* path,
+                                                                int t_total, int batch_frames, int band) {
+    __shared__ double val[2][VS];
+    __shared__ double pm_v[VS], sm_v[VS];
+    __shared__ short pm_i[VS], sm_i[VS];
+    const int k = threadIdx.x, lane = k & 63, wave = k >> 6;
+    const int f0 = blockIdx.x * batch_frames;
+    const int T = (t_total - f0) < batch_frames ? (t_total - f0) : batch_frames;
+    const float* lpb = lp + (long long)f0 * VS;
+    short* pb = ptr + (long long)f0 * VS;
+    const double c_out = log_trans[VS - 1];                  // row 0, column VS-1: out of band by construction
+    double ltb[2 * VBAND_MAX + 1];                           // log_trans[j][k] for j = k - band .. k + band
+#pragma unroll
+    for (int e = 0; e < 2 * VBAND_MAX + 1; ++e) {
+        const int j = k - band + e;
+        ltb[e] = (k < VS && e <= 2 * band && j >= 0 && j < VS) ? log_trans[(long long)j * VS + k] : 0.0;
+    }
+    if (k < VS) val[0][k] = (double)lpb[k] + log(1.0 / VS + 2.2250738585072014e-308);
+    __syncthreads();
+    for (int t = 1; t < T; ++t) {
+        const double* prev = val[(t - 1) & 1];
+        if (wave == 0) {                 // prefix maxima: pm[j] = max prev[0..j], lowest index on ties
+            const int j0 = 6 * lane;
+            double v = VNEG; int vi = 0;
+#pragma unroll
+            for (int e = 0; e < 6; ++e)
+                if (j0 + e < VS && prev[j0 + e] > v) { v = prev[j0 + e]; vi = j0 + e; }
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const double ov = __shfl_up(v, d);
+                const int oi = __shfl_up(vi, d);
+                if (lane >= d && !(v > ov)) { v = ov; vi = oi; }       // the earlier range wins ties
+            }
+            double xv = __shfl_up(v, 1); int xi = __shfl_up(vi, 1);     // exclusive prefix of this lane
+            if (lane == 0) { xv = VNEG; xi = 0; }
+#pragma unroll
+            for (int e = 0; e < 6; ++e)
+                if (j0 + e < VS) {
+                    if (prev[j0 + e] > xv) { xv = prev[j0 + e]; xi = j0 + e; }
+                    pm_v[j0 + e] = xv; pm_i[j0 + e] = (short)xi;
+                }
+        } else if (wave == 1) {          // suffix maxima: sm[j] = max prev[j..VS-1], lowest index on ties
+            const int j0 = 6 * lane;
+            double v = VNEG; int vi = VS - 1;
+#pragma unroll
+            for (int e = 5; e >= 0; --e)
+                if (j0 + e < VS && prev[j0 + e] >= v) { v = prev[j0 + e]; vi = j0 + e; }
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const double ov = __shfl_down(v, d);
+                const int oi = __shfl_down(vi, d);
+                if (lane + d < 64 && ov > v) { v = ov; vi = oi; }      // the earlier range (this lane) wins ties
+            }
+            double xv = __shfl_down(v, 1); int xi = __shfl_down(vi, 1);
+            if (lane == 63) { xv = VNEG; xi = VS - 1; }
+#pragma unroll
+            for (int e = 5; e >= 0; --e)
+                if (j0 + e < VS) {
+                    if (prev[j0 + e] >= xv) { xv = prev[j0 + e]; xi = j0 + e; }
+                    sm_v[j0 + e] = xv; sm_i[j0 + e] = (short)xi;
+                }
+        }
+        __syncthreads();
+        if (k < VS) {
+            double bv = VNEG; int bj = 0;
+            if (k - band - 1 >= 0) { bv = pm_v[k - band - 1] + c_out; bj = pm_i[k - band - 1]; }
+#pragma unroll
+            for (int e = 0; e < 2 * VBAND_MAX + 1; ++e) {
+                const int j = k - band + e;
+                if (e <= 2 * band && j >= 0 && j < VS) {
+                    const double c = prev[j] + ltb[e];
+                    if (c > bv) { bv = c; bj = j; }
+                }
+            }
+            if (k + band + 1 < VS) {
+                const double c = sm_v[k + band + 1] + c_out;
+                if (c > bv) { bv = c; bj = sm_i[k + band + 1]; }
+            }
+            val[t & 1][k] = (double)lpb[(long long)t * VS + k] + bv;
+            pb[(long long)t * VS + k] = (short)bj;
+        }
+        __syncthreads();
+    }
+    if (k == 0) {
+        const double* last = val[(T - 1) & 1];
+        int bj = 0;
+        for (int j = 1; j < VS; ++j)
+            if (last[j] > last[bj]) bj = j;
+        int cur = bj;
+        path[f0 + T - 1] = cur;
+        for (int t = T - 2; t >= 0; --t) {
+            cur = pb[(long long)(t + 1) * VS + cur];
+            path[f0 + t] = cur;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int svcmi_viterbi_decode(const float* prob, const double* log_trans, float* lp_scratch, int16_t* ptr_scratch, int32_t* path,
-                                    int32_t frames, int32_t batch_frames, int32_t minidx, int32_t maxidx, void* stream) {
+                                    int32_t frames, int32_t batch_frames, int32_t minidx, int32_t maxidx, int32_t band, void* stream) {
     if (!prob || !log_trans || !lp_scratch || !ptr_scratch || !path || frames <= 0 || batch_frames <= 0) return SVCMI_EINVAL;
-    if (minidx < 0 || maxidx > VS || minidx >= maxidx) return SVCMI_EINVAL;
+    if (minidx < 0 || maxidx > VS || minidx >= maxidx || band < 0) return SVCMI_EINVAL;
+    if (band > VBAND_MAX) return SVCMI_EUNSUPPORTED;
     SVCMI_LAUNCH(viterbi_loglik_kernel, dim3((unsigned)frames), dim3(64), 0, stream, prob, lp_scratch, minidx, maxidx);
     int rc = SVCMI_LAST_ERROR();
     if (rc) return rc;
-    SVCMI_LAUNCH(viterbi_dp_kernel, dim3((unsigned)((frames + batch_frames - 1) / batch_frames)), dim3(384), 0, stream,
-                 (const float*)lp_scratch, log_trans, (short*)ptr_scratch, path, frames, batch_frames);
+    const dim3 grid((unsigned)((frames + batch_frames - 1) / batch_frames));
+    if (band > 0 && 2 * band + 1 < VS)
+        SVCMI_LAUNCH(viterbi_dp_banded_kernel, grid, dim3(384), 0, stream, (const float*)lp_scratch, log_trans, (short*)ptr_scratch, path,
+                     frames, batch_frames, band);
+    else
+        SVCMI_LAUNCH(viterbi_dp_kernel, grid, dim3(384), 0, stream, (const float*)lp_scratch, log_trans, (short*)ptr_scratch, path, frames,
+                     batch_frames);
     return SVCMI_LAST_ERROR();
 }
 

@@ -8,7 +8,7 @@ DEFAULT_LIB = os.path.join(HERE, "libsvcmi.so")
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_MISH, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4, 5
 CONV_ACCUMULATE, CONV_MASK_IN, CONV_MASK_OUT, CONV_PARTIALS = 1, 2, 4, 8
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class SnakeConvDesc(Structure):
@@ -62,7 +62,7 @@ SIGNATURES = {
     "svcmi_logmel_finish_f32": (c_int, [_P, _P, _P, _I, _I, _I, _P]),
     "svcmi_crepe_frames_f32": (c_int, [_P, _L, _I, _I, _I, _P, _I, _P]),
     "svcmi_bn_maxpool2_f32": (c_int, [_P, _P, _P, _P, _L, _I, _I, _I, _P]),
-    "svcmi_viterbi_decode": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "svcmi_viterbi_decode": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "svcmi_row_sqnorm_f32": (c_int, [_P, _I, _L, _I, _P, _P]),
     "svcmi_knn_blend_f32": (c_int, [_P, _I, _P, _I, _P, _L, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "svcmi_snake_post_supported": (c_int, [_I, _I, _I]),

@@ -330,15 +330,16 @@ class Ops:
                    self._stream(), work={"bytes": 6.0 * B * T * Cc})
         return y
 
-    def viterbi_decode(self, prob, log_trans, batch_frames, minidx, maxidx):
-        """prob [frames, 360] (sigmoid outputs), log_trans [360, 360] float64 -> decoded bins int32 [frames]."""
+    def viterbi_decode(self, prob, log_trans, batch_frames, minidx, maxidx, band=0):
+        """prob [frames, 360] (sigmoid outputs), log_trans [360, 360] float64 -> decoded bins int32 [frames].
+        ``band`` > 0: entries with |i - j| > band are one constant (see ``transition_band``)."""
         self._chk(prob, log_trans)
         Fr = prob.shape[0]
         lp = torch.empty(Fr * 360, dtype=torch.float32, device=prob.device)
         ptr = torch.empty(Fr * 360, dtype=torch.int16, device=prob.device)
         path = torch.empty(Fr, dtype=torch.int32, device=prob.device)
         self._call("svcmi_viterbi_decode", _ptr(prob), _ptr(log_trans), _ptr(lp), _ptr(ptr), _ptr(path), Fr, batch_frames,
-                   minidx, maxidx, self._stream())
+                   minidx, maxidx, band, self._stream())
         return path
 
     # ------------------------------------------------------------------ feature retrieval

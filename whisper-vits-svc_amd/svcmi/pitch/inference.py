@@ -94,12 +94,21 @@ def _transition():
     return _TRANSITION
 
 
+def transition_band(transition):
+    """Half-width of a banded transition matrix (largest |i - j| with a non-zero entry), or 0 when the entries outside that
+    band are not all equal -- what ``svcmi_viterbi_decode`` needs to know to take its banded path."""
+    tr = np.asarray(transition)
+    ii, jj = np.nonzero(tr)
+    band = int(np.abs(ii - jj).max())
+    off = np.abs(np.subtract.outer(np.arange(tr.shape[0]), np.arange(tr.shape[1]))) > band
+    return band if (2 * band + 1 < tr.shape[0] and np.all(tr[off] == tr[0, -1])) else 0
+
+
 def bins_to_hz(bins, dither=None):
     """crepe/convert.py:13-34,58-64: bins -> cents (+ triangular dither) -> Hz."""
     bins = torch.as_tensor(bins).cpu().long()
-    if dither is None:
-        import scipy.stats
-        dither = scipy.stats.triang.rvs(c=0.5, loc=-CENTS_PER_BIN, scale=2 * CENTS_PER_BIN, size=tuple(bins.shape))
+    if dither is None:      # convert.py:58-64 draws scipy.stats.triang(c=0.5, loc=-C, scale=2C): the symmetric triangular law on [-C, C]
+        dither = np.random.triangular(-CENTS_PER_BIN, 0.0, CENTS_PER_BIN, size=tuple(bins.shape))
     cents = CENTS_PER_BIN * bins + 1997.3794084376191
     cents = cents + cents.new_tensor(np.asarray(dither))
     return 10 * 2 ** (cents / 1200)
@@ -118,8 +127,7 @@ def decode(prob, fmin=50.0, fmax=1000.0, decoder="viterbi", dither=None):
     else:
         raise ValueError(decoder)
     if dither is None:
-        import scipy.stats
-        dither = scipy.stats.triang.rvs(c=0.5, loc=-CENTS_PER_BIN, scale=2 * CENTS_PER_BIN, size=bins.shape)
+        dither = np.random.triangular(-CENTS_PER_BIN, 0.0, CENTS_PER_BIN, size=bins.shape)
     cents = CENTS_PER_BIN * torch.from_numpy(bins) + 1997.3794084376191
     cents = cents + cents.new_tensor(np.asarray(dither))
     return 10 * 2 ** (cents / 1200)
@@ -151,12 +159,15 @@ def compute_f0_sing(filename, device, model=None, noise=None, dither=None, decod
         audio = torch.from_numpy(load_audio(filename))
     else:
         audio = torch.as_tensor(filename, dtype=torch.float32)
-    nz = torch.randn_like(audio) if noise is None else torch.as_tensor(noise, dtype=torch.float32)
+    # the 1e-3 input noise (:77) is drawn / added on the model's device: two elementwise passes over the waveform on the host cost
+    # more than the whole network on a many-core box (torch CPU ops wake a thread pool per call)
+    audio = audio.to(model.device)
+    nz = torch.randn_like(audio) if noise is None else torch.as_tensor(noise, dtype=torch.float32).to(model.device)
     audio = audio + nz * 0.001
     prob = model.probabilities(audio, hop=320, batch_size=512)
     if decoder == "viterbi" and model.ops.on_gpu:      # the DP on the device (one block per 512-frame decoding batch)
-        lt = torch.from_numpy(np.log(_transition() + np.finfo(np.float32).tiny)).to(prob.device)
-        bins = model.ops.viterbi_decode(prob, lt, 512, _frequency_to_bins(50.0), _frequency_to_bins(1000.0, ceil=True))
+        lt, band = _viterbi_constants(prob.device)
+        bins = model.ops.viterbi_decode(prob, lt, 512, _frequency_to_bins(50.0), _frequency_to_bins(1000.0, ceil=True), band=band)
         pitch = bins_to_hz(bins, dither)[None].float()
     else:
         prob, out = prob.cpu(), []
@@ -164,8 +175,33 @@ def compute_f0_sing(filename, device, model=None, noise=None, dither=None, decod
             d = None if dither is None else np.asarray(dither)[i:i + 512]
             out.append(decode(prob[i:i + 512], 50.0, 1000.0, decoder, d))
         pitch = torch.cat(out)[None].float()
-    pitch = torch.from_numpy(np.repeat(pitch.numpy(), 2, -1))        # 320 -> 160 * 2 (:95)
-    return mean_filter(pitch, 5).squeeze(0).numpy()
+    pitch = np.repeat(pitch.numpy(), 2, -1)                           # 320 -> 160 * 2 (:95)
+    return _mean_filter_np(pitch[0], 5)
+
+
+_VITERBI_CONSTANTS = {}
+
+
+def _viterbi_constants(device):
+    """log(transition + tiny) on the device and the band of the matrix, made once per device."""
+    key = str(device)
+    if key not in _VITERBI_CONSTANTS:
+        tr = _transition()
+        _VITERBI_CONSTANTS[key] = (torch.from_numpy(np.log(tr + np.finfo(np.float32).tiny)).to(device), transition_band(tr))
+    return _VITERBI_CONSTANTS[key]
+
+
+def _mean_filter_np(x, win_length):
+    """``mean_filter`` for one fp32 track in numpy (the track is a few thousand values: torch's CPU convolution spends its time
+    waking a thread pool on a 128-core host)."""
+    x = np.asarray(x, dtype=np.float32)
+    mask = ~np.isnan(x)
+    ones = np.ones(win_length, dtype=np.float32)
+    s = np.convolve(np.where(mask, x, np.float32(0)), ones, mode="same")
+    c = np.maximum(np.convolve(mask.astype(np.float32), ones, mode="same"), np.float32(1))
+    out = (s / c).astype(np.float32)
+    out[out == 0] = np.nan
+    return out
 
 
 def save_csv_pitch(pitch, path):
