@@ -47,6 +47,19 @@ def test_argument_validation_needs_no_gpu(hip_so):
     d = _lib.ConvDesc()
     assert lib.svcmi_conv_gemm_f32(ctypes.byref(d), None) == -1
     assert lib.svcmi_source2wav_i16(None, None, 10, None) == -1
+    # grouped / retrieval / decoding entry points reject bad arguments before touching the device
+    descs = (_lib.ConvDesc * 3)()
+    assert lib.svcmi_conv_gemm_group_f32(descs, 0, None) == -1 and lib.svcmi_conv_gemm_group_f32(descs, 4, None) == -1
+    assert lib.svcmi_conv_gemm_group_f32(descs, 2, None) == -1                    # null operands inside the descriptors
+    assert lib.svcmi_snake_conv_group_f32((_lib.SnakeConvDesc * 3)(), 0, None, 1, 10, 20, 20, None) == -1
+    assert lib.svcmi_block_mean_f32(None, 3, None, 16, None) == -1
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.svcmi_knn_blend_f32(p, 16, p, 16, p, 16, p, p, 16, 1, 16, 16, 9, 0.5, None) == -2   # k > 8: SVCMI_EUNSUPPORTED
+    assert lib.svcmi_knn_blend_f32(p, 16, p, 16, p, 4, p, p, 16, 1, 4, 16, 5, 0.5, None) == -1   # k > n
+    assert lib.svcmi_viterbi_decode(p, p, p, p, p, 4, 4, 0, 360, 16, None) == -2                 # band > 15
+    assert lib.svcmi_viterbi_decode(p, p, p, p, p, 4, 4, 10, 5, 0, None) == -1                   # empty bin range
+    assert lib.svcmi_tune_set(b"no_such_knob", 1) == -1
 
 
 def test_product_refuses_to_run_without_gpu(hip_so):
