@@ -2,14 +2,9 @@
 g++ -DSVCMI_EMU, called through the C ABI, checked against torch / the oracle on small shapes.
 This is what `-m "not gpu"` can verify about the HIP kernels without a GPU: tiling, indexing,
 masking, epilogues.  The gpu-marked tests run the identical checks on the real library."""
-import math
-
 import pytest
 import torch
-import torch.nn.functional as F
 
-from oracle import svc_oracle as O
-from workload import weights as W
 from tests import kernel_cases as K
 from tests.emu import emu_ops
 

@@ -15,7 +15,7 @@ from collections import OrderedDict
 import torch
 
 from .. import weights as PW
-from ..ops import ACT_MISH, ACT_NONE, ACT_RELU, ACT_TANH, Ops
+from ..ops import ACT_MISH, ACT_RELU, ACT_TANH, Ops
 from . import consts as K
 from .spec import default_state_dict, param_shapes
 
