@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SVCMI_ABI_VERSION 14
+#define SVCMI_ABI_VERSION 15
 
 enum svcmi_status { SVCMI_OK = 0, SVCMI_EINVAL = -1, SVCMI_EUNSUPPORTED = -2, SVCMI_EALIGN = -3 };
 
@@ -48,6 +48,7 @@ enum svcmi_conv_flags {
     SVCMI_CONV_TILE_P16_64x80 = 0x600,
     SVCMI_CONV_TILE_P16_128x80 = 0x700,
     SVCMI_CONV_TILE_P16_64x160 = 0x800,
+    SVCMI_CONV_TILE_64x128 = 0x900, /* reduced-precision entry points only */
     SVCMI_CONV_TILE_MASK = 0xF00
 };
 
@@ -110,6 +111,27 @@ int svcmi_conv_gemm_f32(const svcmi_conv_desc* d, void* stream);
  * problems fill the chip several blocks deep without multi-stream concurrency.  No split-K, no SVCMI_CONV_PARTIALS, no
  * x_row_shift; tile override bits of descs[0] apply to all.  Outputs of different problems must not overlap. */
 int svcmi_conv_gemm_group_f32(const svcmi_conv_desc* descs, int32_t count, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Reduced-precision variants of the same convolution: 16-bit MULTIPLICANDS, fp32 accumulation, fp32 activations in
+ * HBM on both sides (x, res, y, bias, workspace exactly as above).  The reference drops to fp16 on an accelerator
+ * (whisper/inference.py:22-23,43-44: model.half(), mel.half()); here the choice is per call and opt-in:
+ *   SVCMI_PREC_BF16X3  x = hi + lo with hi = bf16(x), lo = bf16(x - hi) on both operands, acc += hi*hi + lo*hi + hi*lo:
+ *                      three bf16 MFMAs (16x the fp32 matrix rate each) for ~2^-17 relative error per product -- fp32-class
+ *                      results (waveform within the 1e-3 parity bar, tests/test_gpu_precision.py) at up to ~5x the fp32 rate;
+ *   SVCMI_PREC_BF16    operands rounded to bf16 (8-bit mantissa), one MFMA;
+ *   SVCMI_PREC_F16     operands rounded to fp16 (11-bit mantissa, range 65504), one MFMA -- what `.half()` does.
+ * Weights are converted ONCE by svcmi_pack_weights_lp from the fp32 operand [n][ldw] svcmi_conv_gemm_f32 takes to a 16-bit
+ * image: row n = ldw16 values (K order permuted inside every block of 32 to match the kernel's fragment reads; bf16x3: hi row
+ * followed by lo row, 2*ldw16 values per n); ldw16 % 32 == 0, ldw16 >= ldw, `out` 16-byte aligned and n*ldw16*2 (x2 for bf16x3)
+ * bytes.  svcmi_conv_gemm_lp / svcmi_conv_gemm_group_lp take the SAME descriptor with d->w = that image and d->ldw = ldw16;
+ * everything else (epilogue, masks, split-K, SVCMI_CONV_PARTIALS, grouping rules) is unchanged.  Activations are rounded in
+ * registers inside the kernel, so no other kernel of the path changes.  Not supported (SVCMI_EUNSUPPORTED): per-element
+ * gathers (c_in % 4 != 0 or unaligned x) and the in-launch split-K combine (`counters` is ignored). */
+enum svcmi_precision { SVCMI_PREC_F32 = 0, SVCMI_PREC_BF16X3 = 1, SVCMI_PREC_BF16 = 2, SVCMI_PREC_F16 = 3 };
+int svcmi_pack_weights_lp(const float* w, int32_t n, int32_t ldw, int32_t precision, void* out, int32_t ldw16, void* stream);
+int svcmi_conv_gemm_lp(const svcmi_conv_desc* d, int32_t precision, void* stream);
+int svcmi_conv_gemm_group_lp(const svcmi_conv_desc* descs, int32_t count, int32_t precision, void* stream);
 
 /* LayerNorm over the channel dim of time-major rows, optional pre-add:
  *   y[r,:] = (v - mean(v)) / sqrt(var(v) + eps) * gamma + beta,   v = x[r,:] + (res ? res[r,:] : 0)

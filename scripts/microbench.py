@@ -29,7 +29,7 @@ def timeit(fn, iters=30, warm=5):
     return e0.elapsed_time(e1) * 1e3 / iters      # us
 
 
-def gemm(ops, tag, T, cin, n, k=1, dil=1, res=False, tiles=(0, 1, 2, 3), splits=(1, 0), B=1):
+def gemm(ops, tag, T, cin, n, k=1, dil=1, res=False, tiles=(0, 1, 2, 3), splits=(1, 0), B=1, prec=None, partials=False):
     g = torch.Generator().manual_seed(0)
     x = torch.randn(B, T, cin, generator=g).cuda()
     w = PW.pack_conv(torch.randn(n, cin, k, generator=g) / math.sqrt(cin * k)).cuda()
@@ -40,8 +40,12 @@ def gemm(ops, tag, T, cin, n, k=1, dil=1, res=False, tiles=(0, 1, 2, 3), splits=
     for tile in tiles:
         for sk in splits:
             try:
-                us = timeit(lambda: ops.conv(x, w, bias, ksize=k, dilation=dil, pad=(k - 1) * dil // 2, res=r, out=out, tile=tile, split_k=sk, n_out=n))
-                print(f"gemm {tag:18s} T={T} cin={cin} n={n} k={k} d={dil} tile={tile} split={sk}: {us:8.1f} us  {fl / us / 1e6:7.1f} TF/s", flush=True)
+                with ops.use_precision(prec):
+                    if partials and sk >= 1:
+                        us = timeit(lambda: ops.conv(x, w, None, ksize=k, dilation=dil, pad=(k - 1) * dil // 2, tile=tile, split_k=sk, partials=True))
+                    else:
+                        us = timeit(lambda: ops.conv(x, w, bias, ksize=k, dilation=dil, pad=(k - 1) * dil // 2, res=r, out=out, tile=tile, split_k=sk, n_out=n))
+                print(f"gemm {tag:18s} {prec or 'f32':6s} B={B} T={T} cin={cin} n={n} k={k} d={dil} tile={tile} split={sk}{' partials' if partials else ''}: {us:8.1f} us  {fl / us / 1e6:7.1f} TF/s", flush=True)
             except Exception as e:      # noqa: BLE001
                 print(f"gemm {tag} tile={tile} split={sk}: {e}")
 
@@ -54,6 +58,25 @@ def main():
         gemm(ops, "whisper_o", 500, 1280, 1280, res=True, splits=(1, 0, 2, 4))
         gemm(ops, "whisper_mlp1", 500, 1280, 5120)
         gemm(ops, "whisper_mlp2", 500, 5120, 1280, res=True, splits=(1, 0, 4, 8))
+    if "lp" in what:          # reduced-precision operand modes on the Whisper window shapes (M = 500 / 750) and a batch-16 flow shape
+        for T in (500, 750):
+            gemm(ops, "whisper_qkv", T, 1280, 3840, tiles=(1,), splits=(1,))
+            gemm(ops, "whisper_mlp1", T, 1280, 5120, tiles=(6,), splits=(1,))
+            gemm(ops, "whisper_o", T, 1280, 1280, tiles=(6,), splits=(2,), partials=True)
+            gemm(ops, "whisper_mlp2", T, 5120, 1280, tiles=(6,), splits=(4,), partials=True)
+            for prec in ("bf16x3", "bf16", "f16"):
+                gemm(ops, "whisper_qkv", T, 1280, 3840, tiles=(1, 9, 3), splits=(1,), prec=prec)
+                gemm(ops, "whisper_mlp1", T, 1280, 5120, tiles=(1, 9, 3), splits=(1,), prec=prec)
+                gemm(ops, "whisper_o", T, 1280, 1280, tiles=(1, 9), splits=(1, 2, 3, 4), prec=prec, partials=True)
+                gemm(ops, "whisper_mlp2", T, 5120, 1280, tiles=(1, 9), splits=(2, 4, 8), prec=prec, partials=True)
+        for prec in (None, "bf16x3", "bf16"):
+            gemm(ops, "square4096", 4096, 4096, 4096, tiles=(9, 3) if prec else (3,), splits=(1,), prec=prec)
+            gemm(ops, "flow_in_B16", 1000, 192, 384, k=5, tiles=(0,), splits=(1,), B=16, prec=prec)
+            gemm(ops, "encp_pre_B16", 1000, 1280, 192, k=5, tiles=(0,), splits=(1,), B=16, prec=prec)
+            gemm(ops, "dec_pre_B16", 1000, 192, 320, k=7, tiles=(0,), splits=(1,), B=16, prec=prec)
+            gemm(ops, "stage0_C160_B16", 5000, 160, 160, k=7, dil=3, res=True, tiles=(0,), splits=(1,), B=16, prec=prec)
+            gemm(ops, "stage1_C80_B16", 20000, 80, 80, k=7, dil=3, res=True, tiles=(0,), splits=(1,), B=16, prec=prec)
+            gemm(ops, "stage2_C40_B4", 80000, 40, 40, k=7, dil=3, res=True, tiles=(0,), splits=(1,), B=4, prec=prec)
     if "gemmpmc" in what:     # few launches, for counter collection
         global timeit
         _t = timeit

@@ -131,6 +131,79 @@ static inline svcmi_f32x4 svcmi_mfma_16x16x4(float a, float b, svcmi_f32x4 c) {
     return c;
 }
 
+// 16-bit-operand MFMAs (bf16 / fp16 in, fp32 accumulate): operands as 4 packed dwords = 8 values per lane.
+typedef unsigned svcmi_u32x4 __attribute__((vector_size(16)));
+static inline svcmi_u32x4 svcmi_as_u32x4(svcmi_f32x4 v) { svcmi_u32x4 r; memcpy(&r, &v, 16); return r; }
+static inline float svcmi_bits_f32(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+static inline unsigned emu_bf16_rne(float f) {
+    unsigned u; memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;      // NaN stays NaN
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+static inline float emu_bf16_f32(unsigned h) { return svcmi_bits_f32((h & 0xffffu) << 16); }
+static inline unsigned emu_f16_rne(float f) {          // IEEE binary16, round to nearest even, overflow -> inf
+    unsigned u; memcpy(&u, &f, 4);
+    const unsigned sign = (u >> 16) & 0x8000u;
+    const unsigned a = u & 0x7fffffffu;
+    if (a > 0x7f800000u) return sign | 0x7e00u;                         // NaN
+    if (a >= 0x477ff000u) return sign | 0x7c00u;                        // >= 65520 rounds to inf
+    if (a < 0x33000001u) return sign;                                   // <= 2^-25 rounds to zero
+    int e = (int)(a >> 23) - 127;
+    unsigned m = (a & 0x7fffffu) | 0x800000u;                           // 24-bit significand
+    int shift = e < -14 ? 13 + (-14 - e) : 13;                          // subnormal results lose more bits
+    unsigned r = m >> shift, rem = m & ((1u << shift) - 1), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (r & 1))) ++r;
+    if (e < -14) return sign | r;                                       // subnormal (a carry into 0x400 is the smallest normal)
+    return sign | (((unsigned)(e + 15) << 10) + (r - 0x400u));         // a mantissa carry bumps the exponent
+}
+static inline float emu_f16_f32(unsigned h) {
+    const unsigned sign = (h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3ffu;
+    if (e == 31) return svcmi_bits_f32(sign | 0x7f800000u | (m << 13));
+    if (e == 0) return (sign ? -1.f : 1.f) * ldexpf((float)m, -24);
+    return svcmi_bits_f32(sign | ((e + 112) << 23) | (m << 13));
+}
+static inline unsigned svcmi_cvt_pk_bf16(float a, float b) { return emu_bf16_rne(a) | (emu_bf16_rne(b) << 16); }
+static inline unsigned svcmi_cvt_pk_f16(float a, float b) { return emu_f16_rne(a) | (emu_f16_rne(b) << 16); }
+template <bool F16>
+static inline float emu_h16(const svcmi_u32x4& v, int e) {
+    const unsigned h = (v[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+    return F16 ? emu_f16_f32(h) : emu_bf16_f32(h);
+}
+// v_mfma_f32_32x32x16_{bf16,f16}: lane l holds A[i=l&31][k=8*(l>>5)..+7], B[k=8*(l>>5)..+7][j=l&31]; D as 32x32x2.
+template <bool F16>
+static inline svcmi_f32x16 svcmi_mfma16_32x32x16(svcmi_u32x4 a, svcmi_u32x4 b, svcmi_f32x16 c) {
+    svcmi_u32x4 ab[2] = {a, b};
+    svcmi_u32x4 all[64][2];
+    emu::wave_exchange(ab, sizeof(ab), all);
+    int l = emu::cur_lane();
+    int j = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        for (int h = 0; h < 2; ++h)
+            for (int e = 0; e < 8; ++e) acc += emu_h16<F16>(all[i + 32 * h][0], e) * emu_h16<F16>(all[j + 32 * h][1], e);
+        c[r] = acc;
+    }
+    return c;
+}
+// v_mfma_f32_16x16x32_{bf16,f16}: lane l holds A[l&15][8*(l>>4)..+7], B[8*(l>>4)..+7][l&15]; D as 16x16x4.
+template <bool F16>
+static inline svcmi_f32x4 svcmi_mfma16_16x16x32(svcmi_u32x4 a, svcmi_u32x4 b, svcmi_f32x4 c) {
+    svcmi_u32x4 ab[2] = {a, b};
+    svcmi_u32x4 all[64][2];
+    emu::wave_exchange(ab, sizeof(ab), all);
+    int l = emu::cur_lane();
+    int j = l & 15;
+    for (int r = 0; r < 4; ++r) {
+        int i = 4 * (l >> 4) + r;
+        float acc = c[r];
+        for (int h = 0; h < 4; ++h)
+            for (int e = 0; e < 8; ++e) acc += emu_h16<F16>(all[i + 16 * h][0], e) * emu_h16<F16>(all[j + 16 * h][1], e);
+        c[r] = acc;
+    }
+    return c;
+}
+
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 

@@ -55,7 +55,7 @@ def check_vits_golden(ops, device, tag, hp, tol=TIGHT):
     return errs
 
 
-def check_generator_widths_against_oracle(ops, device, T=5, B=2, tol=TIGHT):
+def check_generator_widths_against_oracle(ops, device, T=5, B=2, tol=TIGHT, precision=None):
     """The base.yaml generator widths (320 -> 160, 80, 40, 20, 10 channels: 64x64 / 64x80 / 64x48 grouped GEMM tiles, the grouped
     fused VALU kernels at 20 / 10 channels, the streaming ups+noise kernels and the fused output layer) on a short ragged batch
     with the small prior encoder / flow of the tiny config, against the oracle."""
@@ -67,21 +67,38 @@ def check_generator_widths_against_oracle(ops, device, T=5, B=2, tol=TIGHT):
     if B > 1:
         lens[-1] = max(1, T - 2)
     src = m.pitch2source(d["pit"], noise=(d["rand_ini"], d["src_noise"]))
+    m.precision = precision
+    saved, launches = ops.lp_min_flops, ops.launches
+    if precision is not None:
+        ops.lp_min_flops = 0.0           # tiny shapes: force every eligible GEMM through the reduced-precision kernels
     wav = m.inference(d["ppg"], d["vec"], d["pit"], d["spk"], lens, src, noise=d["enc_noise"])
+    ops.lp_min_flops = saved
     with torch.no_grad():
         o_src = O.pitch2source(sd, hp, d["pit"], d["rand_ini"], d["src_noise"])
         o_wav = O.synth_inference(sd, hp, d["ppg"], d["vec"], d["pit"], d["spk"], lens, o_src, d["enc_noise"])
     errs = dict(source=maxerr(src, o_src), wave=maxerr(wav, o_wav))
+    if precision is not None:
+        w = m._weights()
+        assert getattr(w.pre_conv_w, "_svcmi_lp", None) and getattr(w.flow[0]["wn"][0]["in_w"], "_svcmi_lp", None) \
+            and getattr(w.stages[0]["blocks"][0]["c1"][0][0], "_svcmi_lp", None), "reduced-precision kernels did not run"
+        assert errs["wave"] > 0.0
     assert errs["source"] <= 5e-5 and errs["wave"] <= min(tol * 5, WAVE_TOL), errs
     return errs
 
 
-def check_whisper_golden(ops, device, tag, dims, tol=TIGHT):
+def check_whisper_golden(ops, device, tag, dims, tol=TIGHT, precision=None):
     from svcmi.whisper.inference import load_model
     g = golden(tag)
     ck = W.make_whisper_state(dims)
     wm = load_model(ck, device, ops=ops)
+    wm.encoder.precision = precision
+    saved = ops.lp_min_flops
+    if precision is not None:
+        ops.lp_min_flops = 0.0
     out = wm.encoder(_t(g["mel"]), _t(g["mel_noise"]), 0.1)
+    ops.lp_min_flops = saved
+    if precision is not None:
+        assert getattr(wm.weights.blocks[0]["qkv_w"], "_svcmi_lp", None), "reduced-precision kernels did not run"
     err = maxerr(out, _t(g["ppg"]))
     assert err <= tol * max(1.0, float(np.abs(g["ppg"]).max())), err
     return err

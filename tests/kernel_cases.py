@@ -54,6 +54,29 @@ CONV_CASES_SMALL = [
     dict(id="p16_n38_ragged_masks", B=2, T=150, cin=16, n=38, k=5, pad=2, lengths=[150, 111], mask_in=True, mask_out=True, tile=4),
     dict(id="p16_n70_128x80", B=1, T=200, cin=32, n=70, k=3, pad=1, act=ACT_GELU, tile=7),
 ]
+# reduced-precision operand modes (svcmi_conv_gemm_lp): every tile policy x gather mode, split-K, the K tail, masks
+CONV_CASES_LP_SMALL = [
+    dict(id="lp_bf16x3_64x64_chunk_k3", B=1, T=70, cin=64, n=70, k=3, pad=1, act=ACT_GELU, prec="bf16x3", tile=1),
+    dict(id="lp_bf16_64x64_vec_k5_d2_res", B=2, T=37, cin=8, n=10, k=5, dil=2, pad=4, act=ACT_RELU, res=True, prec="bf16"),
+    dict(id="lp_f16_64x128_chunk", B=1, T=90, cin=32, n=150, k=1, prec="f16", tile=9),
+    dict(id="lp_bf16x3_64x128_vec_masks", B=2, T=29, cin=12, n=136, k=5, pad=2, lengths=[29, 17], mask_in=True, mask_out=True, prec="bf16x3", tile=9),
+    dict(id="lp_bf16x3_128x128_ktail", B=1, T=150, cin=20, n=140, k=3, pad=1, prec="bf16x3", tile=3),
+    dict(id="lp_bf16x3_repeat2_fused", B=1, T=40, cin=32, n=24, k=5, pad=2, repeat=True, prec="bf16x3"),
+    dict(id="lp_bf16x3_splitk3_acc", B=2, T=40, cin=64, n=70, k=5, pad=2, res=True, alpha=1.0 / 3.0, accumulate=True, split_k=3, prec="bf16x3"),
+    dict(id="lp_f16_splitk_auto", B=1, T=33, cin=16, n=8, k=63, pad=31, split_k=0, prec="f16"),
+    dict(id="lp_bf16x3_p16_n40_k11_d5", B=1, T=300, cin=40, n=40, k=11, dil=5, pad=25, res=True, prec="bf16x3", tile=4),
+    dict(id="lp_bf16_p16_n80_k3_acc", B=2, T=130, cin=80, n=80, k=3, pad=1, res=True, alpha=1.0 / 3.0, accumulate=True, prec="bf16", tile=6),
+    dict(id="lp_f16_p16_n38_masks", B=2, T=150, cin=16, n=38, k=5, pad=2, lengths=[150, 111], mask_in=True, mask_out=True, prec="f16", tile=4),
+    dict(id="lp_bf16x3_stride2", B=1, T=81, cin=32, n=40, k=3, stride=2, pad=1, act=ACT_GELU, prec="bf16x3"),
+]
+CONV_CASES_LP_LARGE = [
+    dict(id="lp_whisper_qkv_bf16x3", B=1, T=750, cin=1280, n=3840, k=1, prec="bf16x3"),
+    dict(id="lp_whisper_mlp2_res_f16", B=1, T=500, cin=5120, n=1280, k=1, res=True, prec="f16", split_k=4),
+    dict(id="lp_encp_pre_repeat_bf16x3", B=1, T=1000, cin=1280, n=192, k=5, pad=2, repeat=True, prec="bf16x3", split_k=0),
+    dict(id="lp_amp_k11_d5_bf16", B=1, T=5000, cin=160, n=160, k=11, dil=5, pad=25, res=True, prec="bf16"),
+    dict(id="lp_auto_p16_big_bf16x3", B=2, T=20000, cin=80, n=80, k=7, pad=3, prec="bf16x3"),
+    dict(id="lp_b16_wn_in_bf16x3", B=16, T=1000, cin=192, n=384, k=5, pad=2, prec="bf16x3"),
+]
 CONV_CASES_LARGE = [
     dict(id="whisper_qkv", B=1, T=500, cin=1280, n=3840, k=1),
     dict(id="whisper_mlp2_res", B=1, T=500, cin=5120, n=1280, k=1, res=True),
@@ -79,7 +102,21 @@ def check_conv(ops, c, device):
     lengths = torch.tensor(c["lengths"], dtype=torch.int32) if "lengths" in c else None
     mask = (torch.arange(Tl)[None, :] < lengths[:, None]).float().unsqueeze(-1) if lengths is not None else None
     xin = xl * mask if c.get("mask_in") else xl
-    ref = F.conv1d(xin.transpose(1, 2), w, bias, stride=stride, dilation=dil, padding=pad).transpose(1, 2)
+    prec = c.get("prec")
+    conv = lambda a, ww, bb=None: F.conv1d(a.transpose(1, 2), ww, bb, stride=stride, dilation=dil, padding=pad).transpose(1, 2)
+    exact = conv(xin, w, bias)
+    if prec is None:
+        ref = exact
+    else:       # the same rounding the kernel applies to both operands, products and sums in fp32
+        rnd = (lambda t: t.half().float()) if prec == "f16" else (lambda t: t.bfloat16().float())
+        xh, wh = rnd(xin), rnd(w)
+        ref = conv(xh, wh, bias)
+        if prec == "bf16x3":
+            ref = ref + conv(rnd(xin - xh), wh) + conv(xh, rnd(w - wh))
+        # and the mode's own error against the fp32 result stays in its class
+        bound = {"bf16x3": 2e-5, "f16": 2e-3, "bf16": 1.5e-2}[prec]
+        err = (ref - exact).abs().max().item() / max(1.0, exact.abs().max().item())
+        assert err <= bound, f"{c['id']}: {prec} rounding error {err:.2e} > {bound:.0e}"
     t_out = ref.shape[1]
     ref = _ACT[act](ref)
     res = torch.randn(B, t_out, n, generator=g) if c.get("res") else None
@@ -97,11 +134,17 @@ def check_conv(ops, c, device):
     xd = dev(x)
     if cin == 1:
         xd = xd.reshape(B, t_phys)      # a plain signal, ldx = 1
-    y = ops.conv(xd, wp, dev(bias), ksize=k, stride=stride, dilation=dil, pad=pad, act=act, res=dev(res),
-                 alpha=c.get("alpha", 1.0), accumulate=c.get("accumulate", False), lengths=dev(lengths),
-                 mask_in=c.get("mask_in", False), mask_out=c.get("mask_out", False), out=out,
-                 x_row_shift=1 if rep else 0, c_in=cin, ldx=cin, n_out=n, tile=c.get("tile", 0), split_k=c.get("split_k", 1),
-                 t_in=Tl, x_bstride=t_phys * cin)
+    launches, saved_min = ops.launches, ops.lp_min_flops
+    ops.lp_min_flops = 0.0
+    with ops.use_precision(prec):
+        y = ops.conv(xd, wp, dev(bias), ksize=k, stride=stride, dilation=dil, pad=pad, act=act, res=dev(res),
+                     alpha=c.get("alpha", 1.0), accumulate=c.get("accumulate", False), lengths=dev(lengths),
+                     mask_in=c.get("mask_in", False), mask_out=c.get("mask_out", False), out=out,
+                     x_row_shift=1 if rep else 0, c_in=cin, ldx=cin, n_out=n, tile=c.get("tile", 0), split_k=c.get("split_k", 1),
+                     t_in=Tl, x_bstride=t_phys * cin)
+    ops.lp_min_flops = saved_min
+    if prec is not None:
+        assert getattr(wp, "_svcmi_lp", None), f"{c['id']}: the reduced-precision kernel did not run"
     assert y.shape == ref.shape
     _close(y, ref, 2e-5 if cin * k < 4096 else 1e-4, c["id"])
 
@@ -364,7 +407,7 @@ def check_snake_conv(ops, c_, device):
     assert float(got[..., c:].abs().max()) == 0.0 if ld > c else True
 
 
-def check_grouped_launches(ops, device, B=2, n=333, c=40, ld=40):
+def check_grouped_launches(ops, device, B=2, n=333, c=40, ld=40, prec=None):
     """Grouped GEMM / SnakeAlias launches (3 problems per grid) are bit-identical to the single launches, and
     block_mean = ((a + b) + c) / 3."""
     g = _g(77 + n + c)
@@ -380,13 +423,21 @@ def check_grouped_launches(ops, device, B=2, n=333, c=40, ld=40):
     ws = [PW.pack_conv(torch.randn(c, c, k, generator=g) / math.sqrt(c * k), ld, ld).to(device) for k in ks]
     bs = [torch.randn(ld, generator=g).to(device) for _ in ks]
     rs = [torch.randn(B, n, ld, generator=g).to(device) for _ in ks]
+    saved_min, ops.lp_min_flops = ops.lp_min_flops, 0.0
     for n_prob in (1, 2, 3):
-        want = [ops.conv(xs[j], ws[j], bs[j], ksize=ks[j], dilation=ds[j], pad=(ks[j] - 1) * ds[j] // 2, res=rs[j], split_k=1,
-                         tile=(6 if c == 80 else 4 if c == 40 else 1)) for j in range(n_prob)]
-        got = ops.conv_group([dict(x=xs[j], w=ws[j], bias=bs[j], ksize=ks[j], dilation=ds[j], pad=(ks[j] - 1) * ds[j] // 2, res=rs[j],
-                                   out=torch.full((B, n, ld), 7.0).to(device)) for j in range(n_prob)])
+        with ops.use_precision(prec):
+            want = [ops.conv(xs[j], ws[j], bs[j], ksize=ks[j], dilation=ds[j], pad=(ks[j] - 1) * ds[j] // 2, res=rs[j], split_k=1,
+                             tile=(6 if c == 80 else 4 if c == 40 else 1)) for j in range(n_prob)]
+            got = ops.conv_group([dict(x=xs[j], w=ws[j], bias=bs[j], ksize=ks[j], dilation=ds[j], pad=(ks[j] - 1) * ds[j] // 2, res=rs[j],
+                                       out=torch.full((B, n, ld), 7.0).to(device)) for j in range(n_prob)])
         for j in range(n_prob):
             assert torch.equal(want[j], got[j]), (n_prob, j, float((want[j] - got[j]).abs().max()))
+        if prec is not None:        # the grouped reduced-precision launch really ran, and stays in its error class
+            assert all(getattr(w_, "_svcmi_lp", None) for w_ in ws[:n_prob])
+            exact = ops.conv(xs[0], ws[0], bs[0], ksize=ks[0], dilation=ds[0], pad=(ks[0] - 1) * ds[0] // 2, res=rs[0], split_k=1)
+            err = float((exact - got[0]).abs().max()) / max(1.0, float(exact.abs().max()))
+            assert 0 < err <= {"bf16x3": 2e-5, "f16": 2e-3, "bf16": 1.5e-2}[prec], err
+    ops.lp_min_flops = saved_min
     m = ops.block_mean(want)
     assert torch.equal(m.cpu(), ((want[0].cpu() + want[1].cpu()) + want[2].cpu()) / 3.0)
 

@@ -40,3 +40,15 @@ def test_svc_infer_with_knn_retrieval(ops):
 
 def test_generator_base_widths_match_oracle(ops):
     print(E.check_generator_widths_against_oracle(ops, "cpu", T=3, B=2))
+
+
+def test_generator_base_widths_bf16x3_within_parity_bar(ops):
+    """The reduced-precision GEMM path through the whole facade (single, PARTIALS and grouped launches): split-bf16 keeps the
+    waveform inside the 1e-3 bar."""
+    print(E.check_generator_widths_against_oracle(ops, "cpu", T=3, B=2, tol=2e-4, precision="bf16x3"))
+
+
+def test_whisper_tiny_f16_operands(ops):
+    """fp16 operands (what the reference's `.half()` accelerator path uses, whisper/inference.py:22-23) on the tiny encoder:
+    error in the fp16 class, far from fp32's 1e-6 but bounded."""
+    print(E.check_whisper_golden(ops, "cpu", "whisper_tiny", C.WHISPER_TINY_TEST, tol=2e-2, precision="f16"))

@@ -204,6 +204,31 @@ def test_whisper_10s_against_oracle(ops):
     assert out.shape == (1, 500, 1280) and err <= 1e-3
 
 
+def test_pred_ppg_two_windows_against_oracle(ops):
+    """Row a2 (whisper/inference.py:32-62): a 18.2 s clip = one full 15 s window (n = 1500 mel frames, Tw = 750, all kept)
+    + a ragged remainder window (odd mel length, kept = samples // 320 < Tw) through ``pred_ppg_from_mel`` with explicit
+    noise, against ``oracle.pred_ppg_from_mel``: values, window seam and total length."""
+    from svcmi.whisper.inference import load_model, pred_ppg_from_mel, window_plan
+    ck = W.make_whisper_state(C.WHISPER_LARGE_V2)
+    wm = load_model(ck, "cuda", ops=ops)
+    n_samples = 15 * 16000 + 51733
+    plan = window_plan(n_samples)
+    assert [(e - s_) for (s_, e, _) in plan] == [240000, 51733] and [k for (_, _, k) in plan] == [750, 161]
+    g = torch.Generator().manual_seed(23)
+    mels = [(torch.randn(80, (e - s_) // 160, generator=g) * 0.5).clamp(-1, 1.5) for (s_, e, _) in plan]      # audio.py:87: n // 160 frames
+    noises = [torch.randn(m_.shape, generator=g) for m_ in mels]
+    keep = [k for (_, _, k) in plan]
+    assert mels[1].shape[1] == 323 and (mels[1].shape[1] + 1) // 2 == 162 > keep[1]                            # the trim really drops a frame
+    got = pred_ppg_from_mel(wm, mels, keep, mel_noises=[z.cuda() for z in noises])
+    with torch.no_grad():
+        ref = O.pred_ppg_from_mel(ck["model_state_dict"], C.WHISPER_LARGE_V2, mels, noises, keep)
+    assert got.shape == ref.shape == (750 + 161, 1280)
+    scale = float(ref.abs().max())
+    err_w1, err_w2 = E.maxerr(got[:750], ref[:750]), E.maxerr(got[750:], ref[750:])
+    print(f"pred_ppg 2 windows: err window 1 (Tw=750) {err_w1:.2e}, window 2 (Tw=162, kept 161) {err_w2:.2e}, |ppg|max {scale:.2f}")
+    assert max(err_w1, err_w2) <= 1e-4 * max(1.0, scale)
+
+
 def test_cli_main_wav_to_wav(ops, tmp_path, monkeypatch):
     """The reference's CLI flow (svc_inference.py:137-203) in one process: wav -> PPG / vec / F0 files -> svc_out.wav,
     with seeded checkpoints in the reference's formats; checks the file formats and that the result equals running the

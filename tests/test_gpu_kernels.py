@@ -21,6 +21,16 @@ def test_conv_gemm(ops, case):
     K.check_conv(ops, case, device="cuda")
 
 
+@pytest.mark.parametrize("case", K.CONV_CASES_LP_SMALL + K.CONV_CASES_LP_LARGE, ids=lambda c: c["id"])
+def test_conv_gemm_reduced_precision(ops, case):
+    K.check_conv(ops, case, device="cuda")
+
+
+@pytest.mark.parametrize("n,c,B,prec", [(333, 40, 2, "bf16x3"), (20000, 80, 1, "bf16x3"), (5000, 160, 1, "bf16"), (80000, 40, 1, "f16")])
+def test_grouped_launches_reduced_precision(ops, n, c, B, prec):
+    K.check_grouped_launches(ops, "cuda", B=B, n=n, c=c, ld=c, prec=prec)
+
+
 @pytest.mark.parametrize("c", [32, 192, 1280])
 def test_layernorm(ops, c):
     K.check_layernorm(ops, c, device="cuda")

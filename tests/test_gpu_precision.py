@@ -1,0 +1,159 @@
+"""Reduced-precision GEMM operand modes (svcmi_conv_gemm_lp: bf16x3 / bf16 / f16) against the fp32 CPU oracle.
+
+The reference itself runs its accelerator path in fp16 (whisper/inference.py:22-23,43-44 `.half()`); fp32 is this
+library's parity default and the 16-bit modes are opt-in.  What is asserted, on the shapes BASELINE.json names:
+  * bf16x3 (split-bf16, three MFMAs, fp32 accumulate) meets the north_star bar -- <= 1e-3 max-abs on the waveform --
+    on configs[1] (B=1, 10 s, Whisper-large-v2 dims + base.yaml decoder, end to end), on configs[2] (B=16 x 10 s,
+    flow + decoder from pre-extracted PPG/F0) and on a 15 s Whisper window (Tw = 750);
+  * plain bf16 / f16 errors are MEASURED, printed and bounded (they exceed 1e-3, as SURVEY.md section 0 predicted:
+    random-init weights amplify an 8/11-bit operand rounding through 24 + 6 + 16 + 90 layers).
+Error bounds of the plain modes are ~3x what was measured on MI355X (profiles/r02_precision.json holds the numbers).
+"""
+import json
+import os
+
+import pytest
+import torch
+
+from oracle import svc_oracle as O
+from tests import engine_cases as E
+from workload import config as C
+from workload import inputs as I
+from workload import weights as W
+
+pytestmark = pytest.mark.gpu
+
+MODES = ("bf16x3", "bf16", "f16")
+# max-abs bounds: waveform in [-1, 1] (rms ~0.1 with these weights); PPG relative to its max |value|
+WAVE_BOUND = {"bf16x3": E.WAVE_TOL, "bf16": 0.6, "f16": 0.3}
+PPG_REL_BOUND = {"bf16x3": 1e-4, "bf16": 0.08, "f16": 0.02}
+REPORT = {}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from svcmi import Ops
+    o = Ops()
+    assert o.build == "hip:gfx950" and o.on_gpu
+    return o
+
+
+@pytest.fixture(scope="module", autouse=True)
+def write_report():
+    yield
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if REPORT and os.path.isdir(out):
+        with open(os.path.join(out, "precision_report.json"), "w") as f:
+            json.dump(REPORT, f, indent=1, sort_keys=True)
+
+
+@pytest.fixture(scope="module")
+def whisper(ops):
+    from svcmi.whisper.inference import load_model
+    ck = W.make_whisper_state(C.WHISPER_LARGE_V2)
+    return ck, load_model(ck, "cuda", ops=ops)
+
+
+@pytest.fixture(scope="module")
+def clip10(ops, whisper):
+    """configs[1] inputs and the oracle's intermediate / final results for them (one CPU run shared by all modes)."""
+    ck, _ = whisper
+    hp = C.base_hp()
+    m, sd = E.make_model(hp, ops, "cuda")
+    d = I.synth_clip(T=1000, hp=hp, seed=0, B=1, ppg=False)
+    with torch.no_grad():
+        ppg50 = O.audio_encoder(ck["model_state_dict"], d["mel"] + 0.1 * d["mel_noise"], 20, 24)[:, :500]
+        src = O.pitch2source(sd, hp, d["pit"], d["rand_ini"], d["src_noise"])
+        wav = O.synth_inference(sd, hp, ppg50.repeat_interleave(2, dim=1), d["vec"], d["pit"], d["spk"], d["lengths"], src, d["enc_noise"])
+    return dict(hp=hp, m=m, sd=sd, d=d, ppg50=ppg50, src=src, wav=wav)
+
+
+def _count_lp(ops, fn):
+    """Run fn and return (result, number of reduced-precision GEMM launches it made)."""
+    ops.timeline = []
+    out = fn()
+    torch.cuda.synchronize()
+    tl, ops.timeline = ops.timeline, None
+    return out, sum(1 for (name, _, _, _) in tl if name.endswith("_lp") and "pack" not in name)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_configs1_end_to_end(ops, whisper, clip10, mode):
+    """mel -> Whisper-24L -> PPG -> prior/flow/generator, every GEMM of both networks in `mode`, vs the fp32 oracle."""
+    _, wm = whisper
+    c, d, m = clip10, clip10["d"], clip10["m"]
+    wm.encoder.precision = m.precision = mode
+    try:
+        def run():
+            ppg50 = wm.encoder(d["mel"], d["mel_noise"], 0.1)[:, :500]
+            src = m.pitch2source(d["pit"], noise=(d["rand_ini"], d["src_noise"]))
+            wav = m.inference_ppg50(ppg50, d["vec"].cuda(), d["pit"].cuda(), d["spk"].cuda(), d["lengths"].to("cuda", torch.int32), src,
+                                    noise=d["enc_noise"].cuda())
+            return ppg50, wav
+        (ppg50, wav), n_lp = _count_lp(ops, run)
+    finally:
+        wm.encoder.precision = m.precision = None
+    e_ppg = E.maxerr(ppg50, c["ppg50"]) / float(c["ppg50"].abs().max())
+    e_wav = E.maxerr(wav, c["wav"])
+    rms = float(c["wav"].pow(2).mean().sqrt())
+    REPORT[f"configs1_{mode}"] = dict(ppg_rel_err=e_ppg, wave_max_abs_err=e_wav, wave_rms=rms, lp_launches=n_lp)
+    print(f"configs[1] {mode}: ppg rel err {e_ppg:.2e}, waveform max-abs err {e_wav:.2e} (rms {rms:.3f}), {n_lp} lp launches")
+    assert n_lp >= 24 * 4 + 40, n_lp                      # the Whisper linears and the VITS GEMMs really ran in `mode`
+    assert bool(torch.isfinite(wav).all())
+    assert e_ppg <= PPG_REL_BOUND[mode] and e_wav <= WAVE_BOUND[mode]
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_configs2_batch16_flow_decoder(ops, clip10, mode):
+    """configs[2]: 16 x 10 s clips, flow + decoder only (pre-extracted PPG / F0).  Item 0 is the configs[1] clip (its PPG
+    = the oracle's Whisper output) and is compared with the oracle waveform; all 16 items are compared with the fp32
+    engine, which test_gpu_engine.py pins to the oracle (solo == batch, 10 s clip vs oracle)."""
+    c, m, hp = clip10, clip10["m"], clip10["hp"]
+    B = 16
+    items = [c["d"]] + [I.synth_clip(T=1000, hp=hp, seed=s, B=1, ppg=False) for s in range(1, B)]
+    g = torch.Generator().manual_seed(5)
+    ppgs = [c["ppg50"]] + [torch.randn(1, 500, hp.vits.ppg_dim, generator=g) * float(c["ppg50"].std()) for _ in range(1, B)]
+    d = {k: torch.cat([it[k] for it in items], 0) for k in ("vec", "pit", "spk", "enc_noise", "rand_ini", "src_noise", "lengths")}
+    ppg50 = torch.cat(ppgs, 0).cuda()
+    src = m.pitch2source(d["pit"], noise=(d["rand_ini"], d["src_noise"]))
+    args = (ppg50, d["vec"].cuda(), d["pit"].cuda(), d["spk"].cuda(), d["lengths"].to("cuda", torch.int32), src)
+    ref32 = m.inference_ppg50(*args, noise=d["enc_noise"].cuda()).clone()
+    m.precision = mode
+    try:
+        wav, n_lp = _count_lp(ops, lambda: m.inference_ppg50(*args, noise=d["enc_noise"].cuda()))
+    finally:
+        m.precision = None
+    e_item0 = E.maxerr(wav[:1], c["wav"])
+    e_all = E.maxerr(wav, ref32)
+    REPORT[f"configs2_{mode}"] = dict(item0_vs_oracle=e_item0, all_vs_fp32_engine=e_all, lp_launches=n_lp)
+    print(f"configs[2] {mode}: item 0 vs oracle {e_item0:.2e}, 16 items vs fp32 engine {e_all:.2e}, {n_lp} lp launches")
+    assert n_lp >= 40 and wav.shape == (B, 1, 320000) and bool(torch.isfinite(wav).all())
+    assert E.maxerr(ref32[:1], c["wav"]) <= E.WAVE_TOL
+    assert e_item0 <= WAVE_BOUND[mode] and e_all <= 2 * WAVE_BOUND[mode]
+
+
+def test_whisper_15s_window_modes(ops, whisper):
+    """The 15 s window every clip > 15 s uses (n = 1500 mel frames, Tw = 750: 12 M-tiles) in fp32 and in each mode."""
+    ck, wm = whisper
+    g = torch.Generator().manual_seed(15)
+    mel = (torch.randn(1, 80, 1500, generator=g) * 0.5).clamp(-1, 1.5)
+    nz = torch.randn(1, 80, 1500, generator=g)
+    with torch.no_grad():
+        ref = O.audio_encoder(ck["model_state_dict"], mel + 0.1 * nz, 20, 24)
+    scale = float(ref.abs().max())
+    out = wm.encoder(mel, nz, 0.1)
+    assert out.shape == (1, 750, 1280)
+    e32 = E.maxerr(out, ref) / scale
+    REPORT["whisper15s_f32"] = dict(ppg_rel_err=e32)
+    print(f"whisper 15 s fp32: rel err {e32:.2e}")
+    assert e32 <= 1e-4
+    for mode in MODES:
+        wm.encoder.precision = mode
+        try:
+            out, n_lp = _count_lp(ops, lambda: wm.encoder(mel, nz, 0.1))
+        finally:
+            wm.encoder.precision = None
+        e = E.maxerr(out, ref) / scale
+        REPORT[f"whisper15s_{mode}"] = dict(ppg_rel_err=e, lp_launches=n_lp)
+        print(f"whisper 15 s {mode}: rel err {e:.2e}, {n_lp} lp launches")
+        assert n_lp >= 24 * 4 and e <= PPG_REL_BOUND[mode]

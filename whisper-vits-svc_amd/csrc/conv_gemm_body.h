@@ -1,0 +1,689 @@
+// conv_gemm_body.h -- implicit-GEMM 1-D convolution / linear layer on the gfx950 matrix cores: the kernel body shared by
+// conv_gemm.hip (fp32 operands, v_mfma_f32_32x32x2_f32 / 16x16x4_f32) and conv_gemm_lp.hip (16-bit operands, see "Reduced
+// precision" below).
+//
+// One kernel family serves every Conv1d / Linear / (polyphase) ConvTranspose1d of the path (svcmi.h).
+// Time-major activations make the im2col matrix free: row t of the A operand is the contiguous
+// span x[t*stride - pad ...][0:c_in] for dilation 1, and a gather of `ksize` row segments otherwise.
+//
+// Tiling (wave64, 256 threads = 2x2 waves):  block tile (64*WM) x (64*WN), wave tile (32*WM) x (32*WN)
+// as WM x WN accumulators of v_mfma_f32_32x32x2_f32 (16 VGPR each).  K is walked in steps of 32:
+// both operands are K-contiguous in HBM and go straight to LDS with 16-byte LDS-DMA
+// (buffer_load_dwordx4 ... lds: no VGPR round trip, nothing to wait for until the tile is consumed), double
+// buffered so the next tile's DMA flies under the current tile's MFMAs.  The LDS image is [row][32]
+// with the eight 16-byte chunks of a row XOR-swizzled by ((row >> 1) & 7) -- applied on the SOURCE offset of the
+// DMA and again on the fragment read -- so the 16-lane groups of ds_read_b128 hit 16 distinct 4-bank slots.
+// K-order trick: a lane's ds_read_b128 returns 4 consecutive k; lanes 0-31 take k = 8s+0..3 and
+// lanes 32-63 take k = 8s+4..7, so MFMA #j of sub-step s multiplies k-pairs (8s+j, 8s+4+j) -- a
+// permutation of the K summation shared by A and B, i.e. the same dot product.
+//
+// Addressing: each operand is a raw buffer (x of this batch item, bounded at the first masked row; the weight
+// matrix) and a lane's source is a 32-bit byte offset = row part (hoisted out of the K loop) + K part (wave
+// uniform in CHUNK mode) -- one v_add per 1-KiB DMA piece per K-step.  Zero fill (padding taps, masked rows,
+// ragged tile edges, the K tail) is the hardware's buffer range check: rows before the tensor give a negative
+// (huge unsigned) offset, rows past its end run over num_records, and everything else that must read as zero
+// adds a 2^30 sentinel; an out-of-range DMA lane writes zeros to LDS.  The staging code has no branches and no
+// selects on loaded data, and its issue slots are spread over the sub-steps of the previous tile's MFMAs.
+// Three instantiations of the A-gather keep the loop free of per-element integer division:
+//   CHUNK : c_in % 32 == 0 -- a K-step lies inside one tap (scalar tap/channel bookkeeping);
+//   VEC   : c_in % 4 == 0  -- one magic-number division per thread per K-step;
+//   SCALAR: anything else (the 1-channel source convolutions) -- 4-byte DMA.
+// (CHUNK_RS is CHUNK with the np.repeat(x, 2, 0) row shift fused into the gather; it recomputes rows per piece.)
+//
+// Blocks are enumerated M-tile fastest inside contiguous per-XCD ranges (block b runs on XCD b % 8), so all the
+// M tiles that consume one weight tile share an L2 instead of pulling it into all eight.
+//
+// Split-K (deterministic): when the tile grid cannot fill the 256 CUs (M = 500 Whisper rows against
+// N = 1280, or the N = 192 prior-encoder convs with K = 6400) the grid also enumerates S slices of the
+// K range; slices write raw partial tiles to a caller-provided workspace and a second small kernel adds
+// them in fixed order and applies the epilogue.  No atomics anywhere: results are run-to-run identical.
+//
+// Reduced precision (PREC != 0, svcmi_conv_gemm_lp): activations stay fp32 in HBM and travel to LDS exactly as above; only the
+// weights change format.  They are packed once (svcmi_pack_weights_lp) to a 16-bit image [n_out][ldw16] -- bf16, bf16 hi + lo
+// (bf16x3) or fp16 -- whose K order inside every block of 32 is permuted so that 16-byte chunk q (8 values) holds
+// k = 4q..4q+3 and 16+4q..16+4q+3: a lane's MFMA fragment (8 consecutive-in-LDS weights = ONE ds_read_b128) then pairs with
+// the fp32 A chunks q and q+4 (two ds_read_b128, both conflict-free under the fp32 swizzle), which are rounded to 16 bit
+// in registers (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32) right before the MFMA:
+//   bf16x3: x = hi + lo with hi = bf16(x), lo = bf16(x - hi) on BOTH operands and acc += hi*hi + lo*hi + hi*lo (fp32
+//           accumulate; the dropped lo*lo term is 2^-18 relative) -- three v_mfma_f32_32x32x16_bf16 at 16x the fp32 rate;
+//   bf16 / f16: one MFMA on the rounded operands.
+// The B tile is [rows][32 k] x 2 bytes = 64-byte rows, four 16-byte chunks XOR-swizzled by fB(row) = {0,2,3,1}[(row>>2)&3]
+// (conflict-free for the 16-lane groups of ds_read_b128 under both fragment patterns), 16 rows per 1-KiB DMA piece.
+// Tile geometry, A gather, split-K, grouping and the epilogue are the fp32 kernel's; 32x32x2 becomes 32x32x16 (2 sub-steps
+// per K-step of 32), 16x16x4 becomes 16x16x32 (1 sub-step).
+#pragma once
+#include <type_traits>
+
+#include "svcmi_rt.h"
+#include "../../include/svcmi.h"
+
+namespace {
+
+constexpr int BK = 32;
+enum { MODE_CHUNK = 0, MODE_VEC = 1, MODE_SCALAR = 2, MODE_CHUNK_RS = 3 };   // _RS: CHUNK with x_row_shift != 0
+
+enum { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_BF16 = 2, PREC_F16 = 3 };   // == enum svcmi_precision
+
+struct ConvArgs {
+    const float* x; const float* w; const float* bias; const float* res; float* y; const int32_t* lengths;
+    float* ws;                   // split-K partials [batch][split][t_out][n_out]
+    int* cnt;                    // one arrival counter per (batch, n-tile, m-tile), all zero between launches; NULL = two-kernel reduce
+    long long x_bs, y_bs, r_bs;
+    int t_in, t_out, c_in, ldx, n_out, ldw, ldy, ldr;
+    int ksize, stride, dil, pad, rshift, act, flags;
+    const unsigned short* w16;   // reduced precision: 16-bit weight image, row n = [hi: ldw16 values][lo: ldw16 values, bf16x3 only]
+    int ldw16;
+    int ktot;                    // ksize * c_in
+    int split;                   // K slices (1 = none)
+    int mt, nt;                  // tile grid (time x channels)
+    unsigned magic;              // ceil(2^32 / c_in) for the VEC / SCALAR gathers (0 when c_in == 1)
+    float alpha;
+};
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    switch (act) {
+        case SVCMI_ACT_RELU: return v > 0.f ? v : 0.f;
+        case SVCMI_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+        case SVCMI_ACT_MISH: {   // x * tanh(softplus(x)), softplus with torch's threshold 20
+            float sp = v > 20.f ? v : log1pf(expf(v));
+            return v * tanhf(sp);
+        }
+        case SVCMI_ACT_TANH: return tanhf(v);
+        case SVCMI_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+        default: return v;
+    }
+}
+
+__device__ __forceinline__ float epilogue(const ConvArgs& p, float v, float bias, const float* res_row, float* dst,
+                                          int n, bool masked) {
+    v = act_apply(v + bias, p.act);
+    if (res_row) v += res_row[n];
+    v *= p.alpha;
+    if (p.flags & SVCMI_CONV_ACCUMULATE) v += *dst;
+    return masked ? 0.f : v;
+}
+
+__device__ __forceinline__ int div_magic(int q, unsigned magic) {   // q / c_in, exact while q * c_in < 2^32
+    return magic ? (int)__umulhi((unsigned)q, magic) : q;
+}
+
+// LDS swizzle: the 16-byte chunk c of tile row r is stored at position c ^ swz(r).  A 16-lane ds_read_b128 group
+// reads one chunk column from 16 rows {4 consecutive, 4 consecutive, 8 consecutive}; a 256-byte bank row holds 2
+// tile rows x 8 positions, so the group is conflict-free iff rows of equal parity get distinct positions:
+// swz(r) = (r >> 1) & 7 does that for every group (r & 7 left 2-way conflicts: PMC SQ_LDS_BANK_CONFLICT ~ 50 %).
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+// 16-bit B tile (64-byte rows, 4 chunks): chunk q of row r is stored at position q ^ swz16(r), swz16 = {0,2,3,1}[(r>>2)&3].
+// A ds_read_b128 lane group covers 16 rows; rows of equal r&3 share a 64-byte quarter of the bank row and must land on
+// distinct positions: {0,12,20,24} / {4,8,16,28} (32x32x16: one chunk per group) and {0,12 | 4,8 with the next chunk}
+// (16x16x32: lanes 16-31 read chunk q+1) all do.
+__device__ __forceinline__ int swz16(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
+
+constexpr unsigned OOB = 0x40000000u;   // added to an offset that must read as zero; buffers are < 2^29 bytes
+
+// Two micro-kernel policies share everything but the fragment / MFMA / accumulator code:
+//   P16 = false: waves 2 x 2, wave tile (32*WM) x (32*WN), v_mfma_f32_32x32x2_f32   -> block (64*WM) x (64*WN);
+//   P16 = true : waves 4 x 1, wave tile (16*WM) x (16*WN), v_mfma_f32_16x16x4_f32   -> block (64*WM) x (16*WN):
+//                right-sized N for the 40 / 80 / 160-channel generator stages (a 64-multiple pads them by 60 / 60 / 20 %),
+//                and since fp32 MFMA time is proportional to the padded tile, that padding is pure loss.
+// `grid_blocks` / `block_id`: the launch geometry of THIS problem (a grouped launch runs several problems back to back in one grid).
+template <int WM, int WN, int MODE, bool P16, int NSTO = 0, int PREC = PREC_F32>
+__device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid_blocks, const int block_id) {
+    constexpr bool LP = PREC != PREC_F32;             // 16-bit weight image(s), fp32 activations rounded in registers
+    constexpr int NB = PREC == PREC_BF16X3 ? 2 : 1;   // B images per stage (hi, lo)
+    constexpr int BM = 64 * WM, BN = P16 ? 16 * WN : 64 * WN;
+    constexpr int BROW = LP ? BK / 2 : BK;            // floats per B row in LDS (LP: 32 x 2 bytes)
+    constexpr int BNL = LP ? (BN + 63) / 64 * 64 : (BN + 31) / 32 * 32;   // B rows held in LDS (whole 4-wave DMA rounds)
+    constexpr int A_PER = BM / 32, B_PER = LP ? BNL / 64 : BNL / 32;      // 1-KiB LDS-DMA pieces (8 x 128 B or 16 x 64 B rows) per wave per K-step (per image)
+    constexpr int BTILE = BNL * BROW;                 // floats per B image per stage
+    constexpr int CLD = BN;                           // epilogue staging tile [BM][BN] reuses the operand buffers
+    // LDS ring of NST operand tiles (48 / 72 / 64 KiB per block): tile it+NST-1 is in flight while tile
+    // `it` is consumed, so a K-step never waits a full HBM/L2 round trip -- what short K ranges (split-K slices,
+    // the k=1 projections of the prior encoder / flow, k=3 convolutions) would otherwise pay on every step.
+    constexpr int NST = NSTO ? NSTO : (LP ? 3 : (P16 ? ((BM + BNL) > 192 ? 2 : 3) : ((WM * WN == 1) ? 3 : (WM * WN == 2 ? 3 : 2))));
+    constexpr int RING = NST * (BM * BK + NB * BTILE);
+    static_assert(LP || BM * CLD <= RING, "C tile must fit in the operand buffers");
+    __shared__ __attribute__((aligned(16))) float smem[(RING > BM * CLD ? RING : BM * CLD) + 4];   // + the split-K ticket word
+    float* const As0 = smem;                          // As[slot] = As0 + slot*BM*BK, rows of 32 floats, chunk-swizzled
+    float* const Bs0 = smem + NST * BM * BK;          // Bs[slot][image] = Bs0 + (slot*NB + image)*BTILE
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = SVCMI_UNIFORM((int)(tid >> 6));
+    const int wm = P16 ? wave : (wave >> 1), wn = P16 ? 0 : (wave & 1);
+    // XCD-aware bijective enumeration: XCD g owns a contiguous range of the (z, n-tile, m-tile) order, m fastest
+    int bx, by, bz;
+    {
+        const int total = grid_blocks, id = block_id;
+        const int q8 = total >> 3, r8 = total & 7, xcd = id & 7, slot = id >> 3;
+        const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+        bx = L % p.mt;
+        const int rest = L / p.mt;
+        by = rest % p.nt;
+        bz = rest / p.nt;
+    }
+    const int b = bz / p.split, slice = bz - b * p.split;
+    const int m0 = bx * BM, n0 = by * BN;
+    const int len = p.lengths ? p.lengths[b] : 0x7fffffff;
+    const int t_lim = (p.flags & SVCMI_CONV_MASK_IN) ? (len < p.t_in ? len : p.t_in) : p.t_in;
+    // operand buffers: x of this batch item up to the first row that must read as zero; the whole weight matrix
+    const int x_rows = (t_lim + (1 << p.rshift) - 1) >> p.rshift;
+    const svcmi_rsrc xr = svcmi_make_rsrc(p.x + (long long)b * p.x_bs, (unsigned)x_rows * (unsigned)p.ldx * 4u);
+    const svcmi_rsrc wr = LP ? svcmi_make_rsrc(p.w16, (unsigned)p.n_out * (unsigned)(NB * p.ldw16) * 2u)
+                             : svcmi_make_rsrc(p.w, (unsigned)p.n_out * (unsigned)p.ldw * 4u);
+
+    const int nk_all = (p.ktot + BK - 1) / BK;
+    const int it_beg = (int)((long long)nk_all * slice / p.split);
+    const int it_end = (int)((long long)nk_all * (slice + 1) / p.split);
+
+    // LDS image: row r holds its 32 k-values as 8 chunks of 16 B, chunk c stored at position c ^ swz(r).
+    // A 1-KiB piece = 8 consecutive rows; the DMA writes lane l at byte 16*l of the piece, i.e. row l>>3,
+    // position l&7, so lane l must FETCH logical chunk (l&7) ^ swz(row) of that row (swizzle on the source).
+    const int prow = lane >> 3;                        // row within a piece
+    const int lkq = ((lane & 7) ^ swz(prow + 8 * wave)) * 4;   // this lane's k offset within the K-step (pieces start at multiples of 8 rows: swz(row) only needs row mod 16)
+    // K-invariant per-piece state: piece i of this wave covers rows (wave + 4*i)*8 .. +8
+    int a_tb[A_PER];                  // first input row of the piece's output row: t*stride - pad
+    unsigned a_row[A_PER];            // its byte offset (x_row_shift == 0), or the OOB sentinel past t_out
+    unsigned b_row[B_PER];
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+        const int t = m0 + (wave + 4 * i) * 8 + prow;
+        a_tb[i] = t * p.stride - p.pad;
+        a_row[i] = t < p.t_out ? (unsigned)a_tb[i] * (unsigned)p.ldx * 4u : OOB;
+        if (t >= p.t_out) a_tb[i] = -0x40000000;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+        // LP: a piece is 16 rows of 64 bytes, lane l -> row l>>2, position l&3
+        const int n = n0 + (wave + 4 * i) * (LP ? 16 : 8) + (LP ? (lane >> 2) : prow);
+        b_row[i] = n < p.n_out ? (LP ? (unsigned)(n * NB * p.ldw16) * 2u : (unsigned)(n * p.ldw) * 4u) : OOB;
+    }
+    const int lkq16 = ((lane & 3) ^ swz16(lane >> 2)) * 16;    // LP: this lane's byte offset within the 64-byte K-step of a B row
+    // CHUNK mode: wave-uniform (tap, first channel) of the K-step, advanced incrementally
+    int tap_u = 0, ci_u = 0;
+    if (MODE == MODE_CHUNK || MODE == MODE_CHUNK_RS) {
+        const int k0 = it_beg * BK;
+        tap_u = k0 / p.c_in;
+        ci_u = k0 - tap_u * p.c_in;
+    }
+    const svcmi_ldsaddr lds_a = svcmi_lds_advance(svcmi_lds_addr(As0), wave * 8 * BK);
+    const svcmi_ldsaddr lds_b = svcmi_lds_advance(svcmi_lds_addr(Bs0), wave * 8 * BK);
+    static_assert(!P16 || (MODE == MODE_CHUNK || MODE == MODE_VEC), "16x16x4 policy: vector gathers only");
+
+    using acc_t = typename std::conditional<P16, svcmi_f32x4, svcmi_f32x16>::type;
+    constexpr int ACC_N = P16 ? 4 : 16;
+    acc_t acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < ACC_N; ++r) acc[i][j][r] = 0.f;
+
+    // Per-K-step source offsets of tile `it`, then the DMA pieces (none lands in registers, none is waited for here).
+    unsigned a_koff = 0, b_koff = 0;     // K part of this lane's byte offset (or OOB), valid between prep and issue
+    int tap_v = 0, ci_v = 0;             // x_row_shift path: this K-step's (tap, channel)
+    auto stage_prep = [&](int it) {
+        const int kk = it * BK + lkq;
+        if (LP) b_koff = (it * BK * 2 + lkq16) < p.ldw16 * 2 ? (unsigned)(it * BK * 2 + lkq16) : OOB;
+        else b_koff = kk < p.ldw ? (unsigned)kk * 4u : OOB;
+        if (MODE == MODE_CHUNK || MODE == MODE_CHUNK_RS) {
+            tap_v = tap_u; ci_v = ci_u + lkq;
+            a_koff = (unsigned)(tap_u * p.dil * p.ldx + ci_u + lkq) * 4u;
+            ci_u += BK;
+            if (ci_u >= p.c_in) { ci_u -= p.c_in; ++tap_u; }
+        } else if (MODE == MODE_VEC) {
+            tap_v = div_magic(kk, p.magic); ci_v = kk - tap_v * p.c_in;
+            a_koff = kk < p.ktot ? (unsigned)(tap_v * p.dil * p.ldx + ci_v) * 4u : OOB;
+        }
+    };
+    auto stage_a = [&](int it, int buf, int i) {          // piece i of the A tile
+        const svcmi_ldsaddr dst = svcmi_lds_advance(lds_a, buf * BM * BK + 4 * i * 8 * BK);
+        if (MODE == MODE_SCALAR) {
+            // 4-byte DMA: a wave-instruction fills 2 rows (64 floats); the piece needs 4 of them.
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const int rr = 2 * h + (lane >> 5);                  // row within the piece
+                const int pc = (lane & 31) >> 2, e = lane & 3;       // physical chunk, element
+                const int q = it * BK + ((pc ^ swz(rr + 8 * wave)) << 2) + e;   // logical k of this LDS word
+                const int t = m0 + (wave + 4 * i) * 8 + rr;
+                const int k = div_magic(q, p.magic), ci = q - k * p.c_in;
+                const int tin = t * p.stride - p.pad + k * p.dil;
+                const bool ok = t < p.t_out && q < p.ktot && (unsigned)tin < (unsigned)t_lim;
+                svcmi_bdma4(ok ? (unsigned)((tin >> p.rshift) * p.ldx + ci) * 4u : OOB, svcmi_lds_advance(dst, 2 * h * BK), xr);
+            }
+        } else if (MODE == MODE_CHUNK_RS) {               // fused np.repeat(x, 2, 0): rows are tin >> 1
+            const int tin = a_tb[i] + tap_v * p.dil;
+            const bool ok = (unsigned)tin < (unsigned)t_lim;
+            svcmi_bdma16(ok ? (unsigned)((tin >> p.rshift) * p.ldx + ci_v) * 4u : OOB, dst, xr);
+        } else {
+            svcmi_bdma16(a_row[i] + a_koff, dst, xr);
+        }
+    };
+    auto stage_b = [&](int buf, int i) {                  // piece i of the B tile(s): i < B_PER hi (or fp32), then the lo image
+        if (i < B_PER) svcmi_bdma16(b_row[i] + b_koff, svcmi_lds_advance(lds_b, buf * NB * BTILE + 4 * i * 8 * BK), wr);
+        else svcmi_bdma16(b_row[i - B_PER] + b_koff + (unsigned)p.ldw16 * 2u, svcmi_lds_advance(lds_b, (buf * NB + 1) * BTILE + 4 * (i - B_PER) * 8 * BK), wr);
+    };
+
+    // fragment addresses.  32x32x2: row (lane&31) of the wave tile, logical chunk 2s + (lane>>5), 4 sub-steps of 8 k;
+    // 16x16x4: row (lane&15), chunk 4s + (lane>>4), 2 sub-steps of 16 k (MFMA #c contracts k = 16s + c + {0,4,8,12}).
+    // Either way the chunk sits at position chunk ^ swz(row), and both access patterns are bank-conflict free.
+    constexpr int FR = P16 ? 16 : 32;                  // rows per MFMA tile
+    const int frow = lane & (FR - 1), fhi = P16 ? (lane >> 4) : (lane >> 5);
+    const int a_off = (wm * FR * WM + frow) * BK, b_off = (wn * FR * WN + frow) * BROW;
+    // Fragment reads of sub-step s into (a4, b4).  `tie` is a register the MFMAs issued next consume.
+    auto load_frags = [&](const float* Ab, const float* Bb, int s, svcmi_f32x4 (&a4)[WM], svcmi_f32x4 (&b4)[WN], svcmi_f32x4& tie) {
+        const int pos = ((((P16 ? 4 : 2) * s + fhi) ^ swz(frow)) << 2);
+#pragma unroll
+        for (int i = 0; i < WM; ++i) svcmi_lds_read16(a4[i], Ab + i * FR * BK + pos, tie);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) svcmi_lds_read16(b4[j], Bb + j * FR * BK + pos, tie);
+    };
+    auto mma = [&](acc_t& c, float a, float b) {
+        if constexpr (P16) c = svcmi_mfma_16x16x4(a, b, c);
+        else c = svcmi_mfma_32x32x2(a, b, c);
+    };
+    auto frags_arrive = [&](svcmi_f32x4 (&a4)[WM], svcmi_f32x4 (&b4)[WN]) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) svcmi_lds_arrive(a4[i]);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) svcmi_lds_arrive(b4[j]);
+    };
+    // Reduced precision.  Sub-step s of a K-step contracts the 16 (32x32x16: s = 0, 1) or all 32 (16x16x32) k of the step: the
+    // lane reads 16-byte chunk q = 2s + (lane>>5) resp. lane>>4 of its 16-bit B row(s) and the fp32 A chunks q and q + 4.
+    auto load_frags_lp = [&](const float* Ab, const float* Bb, int s, svcmi_f32x4 (&a8)[WM][2], svcmi_f32x4 (&b8)[NB][WN], svcmi_f32x4& tie) {
+        const int q = (P16 ? 0 : 2 * s) + fhi;
+        const int pa = (q ^ swz(frow)) << 2, pb = (q ^ swz16(frow)) << 2;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            svcmi_lds_read16(a8[i][0], Ab + i * FR * BK + pa, tie);
+            svcmi_lds_read16(a8[i][1], Ab + i * FR * BK + (pa ^ 16), tie);
+        }
+#pragma unroll
+        for (int h = 0; h < NB; ++h)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) svcmi_lds_read16(b8[h][j], Bb + h * BTILE + j * FR * BROW + pb, tie);
+    };
+    auto frags_arrive_lp = [&](svcmi_f32x4 (&a8)[WM][2], svcmi_f32x4 (&b8)[NB][WN]) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) { svcmi_lds_arrive(a8[i][0]); svcmi_lds_arrive(a8[i][1]); }
+#pragma unroll
+        for (int h = 0; h < NB; ++h)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) svcmi_lds_arrive(b8[h][j]);
+    };
+    // fp32 fragment (chunks q | q+4) -> packed 16-bit operand(s): hi = round(x), lo = round(x - hi) (bf16x3 only)
+    auto round_frag = [&](const svcmi_f32x4 (&r)[2], svcmi_u32x4& hi, svcmi_u32x4& lo) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float x0 = r[e >> 1][2 * (e & 1)], x1 = r[e >> 1][2 * (e & 1) + 1];
+            if constexpr (PREC == PREC_F16) {
+                hi[e] = svcmi_cvt_pk_f16(x0, x1);
+            } else {
+                const unsigned h = svcmi_cvt_pk_bf16(x0, x1);
+                hi[e] = h;
+                if constexpr (NB == 2)
+                    lo[e] = svcmi_cvt_pk_bf16(x0 - svcmi_bits_f32(h << 16), x1 - svcmi_bits_f32(h & 0xffff0000u));
+            }
+        }
+    };
+    auto mma16 = [&](acc_t& c, svcmi_u32x4 a, svcmi_u32x4 b) {
+        if constexpr (P16) c = svcmi_mfma16_16x16x32<PREC == PREC_F16>(a, b, c);
+        else c = svcmi_mfma16_32x32x16<PREC == PREC_F16>(a, b, c);
+    };
+
+    // sub-steps per tile: fp32 4 x 8 k (32x32x2) or 2 x 16 k (16x16x4); 16-bit 2 x 16 k (32x32x16) or 1 x 32 k (16x16x32)
+    constexpr int NSUB = LP ? (P16 ? 1 : 2) : (P16 ? BK / 16 : BK / 8);
+    constexpr int PIECES = A_PER + NB * B_PER;            // pieces per tile per wave ...
+    constexpr int DMAS = (MODE == MODE_SCALAR ? 4 * A_PER : A_PER) + NB * B_PER;   // ... and the DMA instructions they take
+    // prologue: tiles it_beg .. it_beg+NST-2 into slots 0 .. NST-2
+#pragma unroll
+    for (int s0 = 0; s0 < NST - 1; ++s0) {
+        if (it_beg + s0 < it_end) {
+            stage_prep(it_beg + s0);
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i) stage_a(it_beg + s0, s0, i);
+#pragma unroll
+            for (int i = 0; i < NB * B_PER; ++i) stage_b(s0, i);
+        }
+    }
+    // One K-step.  ISSUE (compile time) = tile it+NST-1 exists: its DMA pieces are issued here, spread over the
+    // sub-steps so that their issue slots sit between this tile's MFMAs.  `inflight` = tiles issued after `it`
+    // that may still be in flight when tile `it` is needed (vmcnt counts this wave's DMAs in issue order).
+    auto k_step = [&](int it, int slot, int inflight, auto issue_tag) {
+        constexpr bool ISSUE = decltype(issue_tag)::value;
+        if (ISSUE || inflight == NST - 2) svcmi_dma_wait_n<(NST - 2) * DMAS>();
+        else if (inflight == 0) svcmi_dma_wait_n<0>();
+        else if (inflight == 1) svcmi_dma_wait_n<DMAS>();
+        else svcmi_dma_wait_n<2 * DMAS>();
+        __syncthreads();     // tile `it` has landed for every wave; all reads of the slot refilled below are done
+        int nslot = slot + NST - 1;
+        if (nslot >= NST) nslot -= NST;
+        if (ISSUE) stage_prep(it + NST - 1);
+        const float* Ab = As0 + slot * BM * BK + a_off;
+        const float* Bb = Bs0 + slot * NB * BTILE + b_off;
+        svcmi_f32x4 tie0 = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (LP) {
+            svcmi_f32x4 a8[2][WM][2], b8[2][NB][WN];
+            load_frags_lp(Ab, Bb, 0, a8[0], b8[0], tie0);
+            frags_arrive_lp(a8[0], b8[0]);
+#pragma unroll
+            for (int s = 0; s < NSUB; ++s) {
+                if (s + 1 < NSUB) load_frags_lp(Ab, Bb, s + 1, a8[(s + 1) & 1], b8[(s + 1) & 1], a8[s & 1][0][0]);
+                if (ISSUE) {
+#pragma unroll
+                    for (int q = s * PIECES / NSUB; q < (s + 1) * PIECES / NSUB; ++q) {
+                        if (q < A_PER) stage_a(it + NST - 1, nslot, q);
+                        else stage_b(nslot, q - A_PER);
+                    }
+                }
+                svcmi_u32x4 ahi[WM], alo[WM];
+#pragma unroll
+                for (int i = 0; i < WM; ++i) round_frag(a8[s & 1][i], ahi[i], alo[i]);
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) mma16(acc[i][j], ahi[i], svcmi_as_u32x4(b8[s & 1][0][j]));
+                if constexpr (NB == 2) {
+#pragma unroll
+                    for (int i = 0; i < WM; ++i)
+#pragma unroll
+                        for (int j = 0; j < WN; ++j) mma16(acc[i][j], alo[i], svcmi_as_u32x4(b8[s & 1][0][j]));
+#pragma unroll
+                    for (int i = 0; i < WM; ++i)
+#pragma unroll
+                        for (int j = 0; j < WN; ++j) mma16(acc[i][j], ahi[i], svcmi_as_u32x4(b8[s & 1][1][j]));
+                }
+                if (s + 1 < NSUB) {
+#pragma unroll
+                    for (int i = 0; i < WM; ++i)
+#pragma unroll
+                        for (int j = 0; j < WN; ++j) svcmi_pin(acc[i][j]);
+                    frags_arrive_lp(a8[(s + 1) & 1], b8[(s + 1) & 1]);
+                }
+            }
+            return;
+        }
+        svcmi_f32x4 a4[2][WM], b4[2][WN];
+        load_frags(Ab, Bb, 0, a4[0], b4[0], tie0);
+        frags_arrive(a4[0], b4[0]);
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) {
+            svcmi_f32x4(&af)[WM] = a4[s & 1];
+            svcmi_f32x4(&bf)[WN] = b4[s & 1];
+            // next sub-step's fragments are requested before this sub-step's MFMAs are issued ...
+            if (s + 1 < NSUB) load_frags(Ab, Bb, s + 1, a4[(s + 1) & 1], b4[(s + 1) & 1], af[0]);
+            if (ISSUE) {
+#pragma unroll
+                for (int q = s * PIECES / NSUB; q < (s + 1) * PIECES / NSUB; ++q) {
+                    if (q < A_PER) stage_a(it + NST - 1, nslot, q);
+                    else stage_b(nslot, q - A_PER);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) mma(acc[i][j], af[i][0], bf[j][0]);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) mma(acc[i][j], af[i][1], bf[j][1]);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) mma(acc[i][j], af[i][2], bf[j][2]);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) mma(acc[i][j], af[i][3], bf[j][3]);
+            // ... and waited for after them (the pins keep this sub-step's MFMAs above the wait)
+            if (s + 1 < NSUB) {
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) svcmi_pin(acc[i][j]);
+                frags_arrive(a4[(s + 1) & 1], b4[(s + 1) & 1]);
+            }
+        }
+    };
+    {
+        int it = it_beg, slot = 0;
+        for (; it + NST - 1 < it_end; ++it) {             // steady state: NST-2 later tiles in flight
+            k_step(it, slot, NST - 2, std::true_type());
+            if (++slot == NST) slot = 0;
+        }
+        for (; it < it_end; ++it) {                       // drain
+            const int rem = it_end - 1 - it;
+            k_step(it, slot, rem < NST - 2 ? rem : NST - 2, std::false_type());
+            if (++slot == NST) slot = 0;
+        }
+    }
+    __syncthreads();         // last tile fully consumed before the buffers are reused below
+
+    // Epilogue through LDS: the accumulators (D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) are
+    // laid out as a [BM][BN] tile so that the (rolled, single-copy) epilogue loop walks n fastest and
+    // every store instruction writes 256 contiguous bytes.  The loop's last barrier already retired all
+    // operand reads, so the buffers can be reused.
+    float* Cs = smem;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < ACC_N; ++r) {
+                // D layouts: 32x32 -> col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5);  16x16 -> col = lane&15, row = 4*(lane>>4) + r
+                const int ml = P16 ? (wm * 16 * WM + i * 16 + 4 * (lane >> 4) + r)
+                                   : (wm * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
+                const int nl = P16 ? (j * 16 + (lane & 15)) : (wn * 32 * WN + j * 32 + (lane & 31));
+                Cs[ml * CLD + nl] = acc[i][j][r];
+            }
+    __syncthreads();
+    const int nvalid = (p.n_out - n0) < BN ? (p.n_out - n0) : BN;
+    const int mvalid = (p.t_out - m0) < BM ? (p.t_out - m0) : BM;
+    if (p.split > 1 || (p.flags & SVCMI_CONV_PARTIALS)) {   // raw partial tile into this slice's slab
+        float* wsb = p.ws + ((long long)b * p.split + slice) * p.t_out * p.n_out;
+        if (!p.cnt) {        // no ticket counters: splitk_reduce_kernel sums the slabs in a second launch
+            for (int e = tid; e < BM * BN; e += 256) {
+                const int ml = e / BN, nl = e - ml * BN;
+                if (ml < mvalid && nl < nvalid) wsb[(long long)(m0 + ml) * p.n_out + n0 + nl] = Cs[ml * CLD + nl];
+            }
+            return;
+        }
+        // In-launch combine (cdna_hip_programming.md section 5, "in-launch split-K reduction", write-through form): the
+        // slab goes out with 16-byte sc1 (write-through) stores, which need no release fence -- a per-block
+        // `buffer_wbl2` made this 2.6x slower than the two-kernel path -- then every wave drains its stores and ONE
+        // relaxed agent-scope ticket is drawn.  The block that draws the last ticket of its tile acquires once and
+        // sums all slabs IN SLICE ORDER (its own included, from memory): the result does not depend on who is last.
+        {
+            const svcmi_rsrc sr = svcmi_make_rsrc(wsb, (unsigned)p.t_out * (unsigned)p.n_out * 4u);   // n_out % 4 == 0 here
+            for (int e = tid; e < BM * BN / 4; e += 256) {
+                const int ml = e / (BN / 4), nl = (e - ml * (BN / 4)) * 4;
+                if (ml < mvalid && nl < nvalid)
+                    svcmi_store16_sc1(*reinterpret_cast<const svcmi_f32x4*>(Cs + ml * CLD + nl), sr,
+                                      (unsigned)((m0 + ml) * p.n_out + n0 + nl) * 4u);
+            }
+        }
+        svcmi_dma_wait();                                   // every wave: its slab stores have left
+        __syncthreads();
+        int* const flag = reinterpret_cast<int*>(smem + BM * CLD);      // spare word behind the C tile (one LDS object only)
+        const int tile_id = (b * p.nt + by) * p.mt + bx;
+        if (tid == 0) *flag = svcmi_ticket(p.cnt + tile_id);
+        __syncthreads();
+        if (*flag != p.split - 1) return;
+        if (tid == 0) {
+            SVCMI_ACQUIRE_AGENT();
+            p.cnt[tile_id] = 0;                             // leave the counter ready for the next launch
+        }
+        __syncthreads();
+        float* yb2 = p.y + (long long)b * p.y_bs;
+        const float* rb2 = p.res ? p.res + (long long)b * p.r_bs : nullptr;
+        const float* ws0 = p.ws + (long long)b * p.split * p.t_out * p.n_out;
+        const long long sstride = (long long)p.t_out * p.n_out;
+        for (int e = tid; e < BM * BN; e += 256) {
+            const int ml = e / BN, nl = e - ml * BN;
+            if (ml >= mvalid || nl >= nvalid) continue;
+            const int t = m0 + ml, n = n0 + nl;
+            const float* src = ws0 + (long long)t * p.n_out + n;
+            float v = 0.f;
+            for (int sl = 0; sl < p.split; ++sl) v += src[sl * sstride];
+            float* dst = yb2 + (long long)t * p.ldy + n;
+            *dst = epilogue(p, v, p.bias ? p.bias[n] : 0.f, rb2 ? rb2 + (long long)t * p.ldr : nullptr, dst, n,
+                            (p.flags & SVCMI_CONV_MASK_OUT) && t >= len);
+        }
+        return;
+    }
+    float* yb = p.y + (long long)b * p.y_bs;
+    const float* rbp = p.res ? p.res + (long long)b * p.r_bs : nullptr;
+    const bool mask_out = (p.flags & SVCMI_CONV_MASK_OUT) != 0;
+    for (int e = tid; e < BM * BN; e += 256) {
+        const int ml = e / BN, nl = e - ml * BN;
+        if (ml >= mvalid || nl >= nvalid) continue;
+        const int t = m0 + ml, n = n0 + nl;
+        float* dst = yb + (long long)t * p.ldy + n;
+        *dst = epilogue(p, Cs[ml * CLD + nl], p.bias ? p.bias[n] : 0.f, rbp ? rbp + (long long)t * p.ldr : nullptr, dst, n,
+                        mask_out && t >= len);
+    }
+}
+
+template <int WM, int WN, int MODE, bool P16, int PREC = PREC_F32>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
+    conv_gemm_body<WM, WN, MODE, P16, 0, PREC>(p, (int)gridDim.x, (int)blockIdx.x);
+}
+
+// Grouped launch: up to GROUP_MAX problems of identical tile policy / gather mode in ONE grid, blocks of problem 0 first.  The
+// generator runs the three AMP blocks of a stage (same shapes, 3 / 7 / 11 taps) this way: one launch carries 3x the blocks
+// of a single convolution, so the 20000 x 80 and 80000 x 40 problems fill the 256 CUs several blocks deep without relying
+// on multi-stream concurrency, and the long-K problem goes first so the short ones fill the tail.
+constexpr int GROUP_MAX = 3;
+struct GroupArgs {
+    ConvArgs p[GROUP_MAX];
+    int first[GROUP_MAX + 1];      // first[i] = first block of problem i; first[count..] = grid size
+};
+
+// NSTO: ring depth override -- the grouped problems have 4 .. 55 K-steps and thousands of blocks, where a 2-deep ring
+// (one more resident block per CU) can beat the 3-deep one tuned for the long-K Whisper GEMMs.
+template <int WM, int WN, int MODE, bool P16, int NSTO, int PREC = PREC_F32>
+__global__ __launch_bounds__(256) void conv_gemm_group_kernel(GroupArgs g) {
+    const int id = (int)blockIdx.x;
+    const int gi = id >= g.first[2] ? 2 : (id >= g.first[1] ? 1 : 0);      // block-uniform: the arguments stay scalar loads
+    conv_gemm_body<WM, WN, MODE, P16, NSTO, PREC>(g.p[gi], g.first[gi + 1] - g.first[gi], id - g.first[gi]);
+}
+
+// y = epilogue(sum over slices, fixed order).  One thread per 4 consecutive n (n_out % 4 handled by a scalar tail).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs p, int batch) {
+    const long long total = (long long)batch * p.t_out * p.n_out;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int n = (int)(e % p.n_out);
+        const long long bt = e / p.n_out;
+        const int t = (int)(bt % p.t_out), b = (int)(bt / p.t_out);
+        const float* src = p.ws + ((long long)b * p.split * p.t_out + t) * p.n_out + n;
+        float v = 0.f;
+        for (int s = 0; s < p.split; ++s) v += src[(long long)s * p.t_out * p.n_out];
+        const int len = p.lengths ? p.lengths[b] : 0x7fffffff;
+        float* dst = p.y + (long long)b * p.y_bs + (long long)t * p.ldy + n;
+        const float* rr = p.res ? p.res + (long long)b * p.r_bs + (long long)t * p.ldr : nullptr;
+        *dst = epilogue(p, v, p.bias ? p.bias[n] : 0.f, rr, dst, n, (p.flags & SVCMI_CONV_MASK_OUT) && t >= len);
+    }
+}
+
+template <int WM, int WN, bool P16, int PREC = PREC_F32>
+int launch(const ConvArgs& a_in, int batch, int mode, void* stream) {
+    constexpr int BM = 64 * WM, BN = P16 ? 16 * WN : 64 * WN;
+    ConvArgs a = a_in;
+    a.mt = (a.t_out + BM - 1) / BM;
+    a.nt = (a.n_out + BN - 1) / BN;
+    const long long blocks = (long long)a.mt * a.nt * batch * a.split;
+    if (blocks > 0x7fffffffLL) return SVCMI_EUNSUPPORTED;
+    dim3 grid((unsigned)blocks);
+    if (mode == MODE_CHUNK) SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_CHUNK, P16, PREC>), grid, dim3(256), 0, stream, a);
+    else if (mode == MODE_VEC) SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_VEC, P16, PREC>), grid, dim3(256), 0, stream, a);
+    else if constexpr (!P16) {
+        if (mode == MODE_CHUNK_RS) SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_CHUNK_RS, false, PREC>), grid, dim3(256), 0, stream, a);
+        else if constexpr (PREC == PREC_F32) SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_SCALAR, false>), grid, dim3(256), 0, stream, a);
+        else return SVCMI_EUNSUPPORTED;     // per-element gathers (c_in % 4 != 0) stay on the fp32 kernel
+    } else {
+        return SVCMI_EUNSUPPORTED;
+    }
+    int rc = SVCMI_LAST_ERROR();
+    if (rc == 0 && a.split > 1 && !a.cnt && !(a.flags & SVCMI_CONV_PARTIALS)) {
+        const long long total = (long long)batch * a.t_out * a.n_out;
+        long long nb = (total + 255) / 256;
+        if (nb > 2048) nb = 2048;
+        SVCMI_LAUNCH(splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream, a, batch);
+        rc = SVCMI_LAST_ERROR();
+    }
+    return rc;
+}
+
+static int g_group_nst = 0;        // tuning knob (svcmi_tune_set("group_nst", 0 | 2 | 3)): ring depth of the grouped launches, 0 = default
+
+template <int WM, int WN, bool P16, int PREC = PREC_F32>
+int launch_group(GroupArgs& g, int count, int batch, int mode, void* stream) {
+    constexpr int BM = 64 * WM, BN = P16 ? 16 * WN : 64 * WN;
+    long long blocks = 0;
+    for (int i = 0; i < GROUP_MAX; ++i) {
+        g.first[i] = (int)blocks;
+        if (i < count) {
+            ConvArgs& a = g.p[i];
+            a.mt = (a.t_out + BM - 1) / BM;
+            a.nt = (a.n_out + BN - 1) / BN;
+            blocks += (long long)a.mt * a.nt * batch;
+            if (blocks > 0x7fffffffLL) return SVCMI_EUNSUPPORTED;
+        }
+    }
+    g.first[GROUP_MAX] = (int)blocks;
+    dim3 grid((unsigned)blocks);
+    // measured (scripts/microbench.py group): the 16x16x4 tiles gain 7 % (80 channels) / 11 % (40) from the 2-deep ring (3 resp.
+    // 4 resident blocks per CU), the 64 x 64 tile does not
+    const int nst = g_group_nst ? g_group_nst : (P16 ? 2 : 3);
+    if (mode != MODE_CHUNK && mode != MODE_VEC) return SVCMI_EUNSUPPORTED;
+    if constexpr (PREC != PREC_F32) {       // one ring depth per policy (the knob is an fp32 tuning aid)
+        constexpr int NSTL = P16 ? 2 : 3;
+        if (mode == MODE_CHUNK) SVCMI_LAUNCH((conv_gemm_group_kernel<WM, WN, MODE_CHUNK, P16, NSTL, PREC>), grid, dim3(256), 0, stream, g);
+        else SVCMI_LAUNCH((conv_gemm_group_kernel<WM, WN, MODE_VEC, P16, NSTL, PREC>), grid, dim3(256), 0, stream, g);
+    } else if (nst == 2) {
+        if (mode == MODE_CHUNK) SVCMI_LAUNCH((conv_gemm_group_kernel<WM, WN, MODE_CHUNK, P16, 2>), grid, dim3(256), 0, stream, g);
+        else SVCMI_LAUNCH((conv_gemm_group_kernel<WM, WN, MODE_VEC, P16, 2>), grid, dim3(256), 0, stream, g);
+    } else {
+        if (mode == MODE_CHUNK) SVCMI_LAUNCH((conv_gemm_group_kernel<WM, WN, MODE_CHUNK, P16, 3>), grid, dim3(256), 0, stream, g);
+        else SVCMI_LAUNCH((conv_gemm_group_kernel<WM, WN, MODE_VEC, P16, 3>), grid, dim3(256), 0, stream, g);
+    }
+    return SVCMI_LAST_ERROR();
+}
+
+// Validation + argument block + gather mode of one convolution (shared by the single and the grouped entry points).
+// lp: d->w is the 16-bit image of svcmi_pack_weights_lp and d->ldw its leading dimension in 16-bit values.
+int prepare(const svcmi_conv_desc* d, ConvArgs& a, int& mode, int prec = PREC_F32) {
+    const bool lp = prec != PREC_F32;
+    if (!d || !d->x || !d->w || !d->y) return SVCMI_EINVAL;
+    /* 32-bit buffer offsets with a 2^30 out-of-range sentinel: each operand buffer stays below 2^29 bytes */
+    if ((long long)d->t_in * d->ldx >= (1LL << 27) || (long long)d->n_out * d->ldw * (prec == PREC_BF16X3 ? 2 : 1) >= (1LL << (lp ? 28 : 27))) return SVCMI_EUNSUPPORTED;
+    if (((long long)d->ksize * d->dilation + d->pad) * d->ldx >= (1LL << 27)) return SVCMI_EUNSUPPORTED;
+    if (d->batch <= 0 || d->t_in <= 0 || d->t_out <= 0 || d->c_in <= 0 || d->n_out <= 0 || d->ksize <= 0) return SVCMI_EINVAL;
+    if (d->stride <= 0 || d->dilation <= 0 || d->x_row_shift < 0 || d->x_row_shift > 1) return SVCMI_EINVAL;
+    if (d->ldw % (lp ? 32 : 4) != 0 || d->ldw < d->ksize * d->c_in) return SVCMI_EINVAL;
+    if (d->ldy < d->n_out || (d->res && d->ldr < d->n_out) || d->ldx < d->c_in) return SVCMI_EINVAL;
+    if ((d->flags & (SVCMI_CONV_MASK_IN | SVCMI_CONV_MASK_OUT)) && !d->lengths) return SVCMI_EINVAL;
+    if (d->act < SVCMI_ACT_NONE || d->act > SVCMI_ACT_SIGMOID) return SVCMI_EINVAL;
+    if (d->split_k < 0 || (d->split_k > 1 && !d->workspace)) return SVCMI_EINVAL;
+    if (((uintptr_t)d->w & 15) != 0) return SVCMI_EALIGN;
+    // magic-number division q / c_in is exact while q * c_in < 2^32 (q < ksize*c_in)
+    if ((long long)d->ksize * d->c_in * d->c_in >= 0x100000000LL || (long long)d->ksize * d->c_in >= 0x7fffffffLL) return SVCMI_EUNSUPPORTED;
+
+    a.w16 = lp ? reinterpret_cast<const unsigned short*>(d->w) : nullptr;
+    a.ldw16 = lp ? d->ldw : 0;
+    a.x = d->x; a.w = d->w; a.bias = d->bias; a.res = d->res; a.y = d->y; a.lengths = d->lengths;
+    a.ws = d->workspace;
+    a.cnt = nullptr;
+    a.x_bs = d->x_bstride; a.y_bs = d->y_bstride; a.r_bs = d->res_bstride;
+    a.t_in = d->t_in; a.t_out = d->t_out; a.c_in = d->c_in; a.ldx = d->ldx; a.n_out = d->n_out;
+    a.ldw = d->ldw; a.ldy = d->ldy; a.ldr = d->ldr;
+    a.ksize = d->ksize; a.stride = d->stride; a.dil = d->dilation; a.pad = d->pad; a.rshift = d->x_row_shift;
+    a.act = d->act; a.flags = d->flags; a.alpha = d->alpha;
+    a.ktot = d->ksize * d->c_in;
+    a.magic = d->c_in == 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d->c_in - 1) / (unsigned)d->c_in);
+    const bool vec = (d->c_in % 4 == 0) && (d->ldx % 4 == 0) && (d->x_bstride % 4 == 0) && (((uintptr_t)d->x & 15) == 0);
+    mode = !vec ? MODE_SCALAR : (d->c_in % BK == 0 ? MODE_CHUNK : MODE_VEC);
+    if (d->x_row_shift) mode = mode == MODE_CHUNK ? MODE_CHUNK_RS : MODE_SCALAR;   // the fused row repeat: CHUNK_RS or per-element
+    return SVCMI_OK;
+}
+
+}  // namespace

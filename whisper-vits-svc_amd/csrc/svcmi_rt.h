@@ -41,6 +41,34 @@ __device__ __forceinline__ svcmi_f32x4 svcmi_mfma_16x16x4(float a, float b, svcm
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// 16-bit-operand matrix instructions (bf16 / fp16 in, fp32 accumulate; 16x the fp32 MFMA rate).  Operands travel as four
+// packed dwords = 8 values; lane l supplies A[i = l&31][k = 8*(l>>5) .. +7] and B[k = 8*(l>>5) .. +7][j = l&31]
+// (32x32x16) resp. A[l&15][8*(l>>4) .. +7], B[8*(l>>4) .. +7][l&15] (16x16x32); C/D layouts as the fp32 forms above.
+typedef unsigned svcmi_u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 svcmi_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 svcmi_bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 svcmi_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 svcmi_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ svcmi_u32x4 svcmi_as_u32x4(svcmi_f32x4 v) { return __builtin_bit_cast(svcmi_u32x4, v); }
+__device__ __forceinline__ float svcmi_bits_f32(unsigned u) { return __builtin_bit_cast(float, u); }
+// (lo, hi) halves = round-to-nearest-even of (a, b): v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32
+__device__ __forceinline__ unsigned svcmi_cvt_pk_bf16(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(svcmi_f32x2{a, b}, svcmi_bf16x2));
+}
+__device__ __forceinline__ unsigned svcmi_cvt_pk_f16(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(svcmi_f32x2{a, b}, svcmi_f16x2));
+}
+template <bool F16>
+__device__ __forceinline__ svcmi_f32x16 svcmi_mfma16_32x32x16(svcmi_u32x4 a, svcmi_u32x4 b, svcmi_f32x16 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(svcmi_f16x8, a), __builtin_bit_cast(svcmi_f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(svcmi_bf16x8, a), __builtin_bit_cast(svcmi_bf16x8, b), c, 0, 0, 0);
+}
+template <bool F16>
+__device__ __forceinline__ svcmi_f32x4 svcmi_mfma16_16x16x32(svcmi_u32x4 a, svcmi_u32x4 b, svcmi_f32x4 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(svcmi_f16x8, a), __builtin_bit_cast(svcmi_f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(svcmi_bf16x8, a), __builtin_bit_cast(svcmi_bf16x8, b), c, 0, 0, 0);
+}
+
 // Asynchronous global -> LDS copy (LDS-DMA) through a buffer descriptor: `buffer_load_dword[x4] voff, rsrc, 0 offen lds`.
 // Lane l fetches 16 (4) bytes at rsrc.base + voff[l]; they land at lds_wave_base + 16*l (4*l) bytes, where
 // `lds_wave_base` is wave-uniform (it travels in M0).  The hardware range-checks voff against rsrc.num_records

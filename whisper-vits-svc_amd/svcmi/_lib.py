@@ -8,7 +8,10 @@ DEFAULT_LIB = os.path.join(HERE, "libsvcmi.so")
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_MISH, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4, 5
 CONV_ACCUMULATE, CONV_MASK_IN, CONV_MASK_OUT, CONV_PARTIALS = 1, 2, 4, 8
-ABI_VERSION = 14
+ABI_VERSION = 15
+PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16 = 0, 1, 2, 3
+PRECISIONS = {None: 0, "f32": 0, "fp32": 0, "bf16x3": 1, "bf16": 2, "f16": 3, "fp16": 3}
+CONV_TILE_64x128 = 9
 
 
 class SnakeConvDesc(Structure):
@@ -36,6 +39,9 @@ SIGNATURES = {
     "svcmi_abi_version": (c_int, []),
     "svcmi_build_info": (c_char_p, []),
     "svcmi_conv_gemm_f32": (c_int, [POINTER(ConvDesc), _P]),
+    "svcmi_pack_weights_lp": (c_int, [_P, _I, _I, _I, _P, _I, _P]),
+    "svcmi_conv_gemm_lp": (c_int, [POINTER(ConvDesc), _I, _P]),
+    "svcmi_conv_gemm_group_lp": (c_int, [_P, _I, _I, _P]),
     "svcmi_layernorm_f32": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
     "svcmi_channel_norm_gelu_f32": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "svcmi_splitk_layernorm_f32": (c_int, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),

@@ -4,13 +4,14 @@ PyTorch is used for device memory and streams only.  Activations are time-major 
 ``[B, T, C]`` (contiguous, ``C % 4 == 0``); see DESIGN.md for the layout rationale.  Every method
 launches one kernel on the current stream and returns its output tensor.
 """
+import contextlib
 import ctypes
 
 import torch
 
 from . import _lib
 from ._lib import (ACT_GELU, ACT_MISH, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, CONV_ACCUMULATE, CONV_MASK_IN,  # noqa: F401
-                   CONV_MASK_OUT, CONV_PARTIALS, ConvDesc, SnakeConvDesc, SvcmiError)
+                   CONV_MASK_OUT, CONV_PARTIALS, PREC_BF16X3, PREC_F32, PRECISIONS, ConvDesc, SnakeConvDesc, SvcmiError)
 
 
 def _ptr(t):
@@ -36,6 +37,11 @@ class Ops:
         # 10 s step 15.8 ms (write-through slabs) / 16.1 ms (release fence per block) vs 12.6 ms -> off by default.
         self.inlaunch_reduce = False
         self.timeline = None     # set to a list to record (kernel, work, start_event, end_event) per launch
+        # GEMM operand precision (include/svcmi.h: enum svcmi_precision).  fp32 is the parity default; "bf16x3" / "bf16" /
+        # "f16" route every eligible convolution through svcmi_conv_gemm_lp with a 16-bit weight image packed on first use
+        # (cached on the fp32 weight tensor).  Convolutions below `lp_min_flops` stay fp32: nothing to gain there.
+        self.precision = PREC_F32
+        self.lp_min_flops = 2.0e7
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
@@ -61,6 +67,48 @@ class Ops:
         self.launches += 1
         if rc != 0:
             raise SvcmiError(f"{name} failed with code {rc}")
+
+    # ------------------------------------------------------------------ reduced precision
+    def set_precision(self, precision):
+        if precision not in PRECISIONS and precision not in PRECISIONS.values():
+            raise SvcmiError(f"unknown precision {precision!r}; one of {sorted(k for k in PRECISIONS if k)}")
+        self.precision = PRECISIONS.get(precision, precision)
+
+    @contextlib.contextmanager
+    def use_precision(self, precision):
+        """``with ops.use_precision("bf16x3"): ...`` -- None leaves the current setting untouched."""
+        old = self.precision
+        if precision is not None:
+            self.set_precision(precision)
+        try:
+            yield self
+        finally:
+            self.precision = old
+
+    def lp_weight(self, w, prec):
+        """16-bit image of the packed fp32 operand ``w`` [n, ldw] (svcmi_pack_weights_lp), made once per (tensor, precision)."""
+        cache = w.__dict__.setdefault("_svcmi_lp", {})
+        img = cache.get(prec)
+        if img is None:
+            n, ldw = w.shape
+            ldw16 = (ldw + 31) // 32 * 32
+            img = torch.empty(n, (2 if prec == PREC_BF16X3 else 1) * ldw16, dtype=torch.int16, device=w.device)
+            self._call("svcmi_pack_weights_lp", _ptr(w), n, ldw, prec, _ptr(img), ldw16, self._stream())
+            cache[prec] = img
+        return img
+
+    def _lp_eligible(self, d, w, work):
+        """The reduced-precision kernels take 16-byte gathers only (c_in, ldx, batch stride % 4, aligned x)."""
+        return (self.precision != PREC_F32 and work["flops"] >= self.lp_min_flops and w.dim() == 2 and w.is_contiguous()
+                and d.c_in % 4 == 0 and d.ldx % 4 == 0 and d.x_bstride % 4 == 0 and (d.x or 0) % 16 == 0
+                and (not d.x_row_shift or d.c_in % 32 == 0) and (d.flags >> 8) in (0, 1, 3, 4, 6, 9))
+
+    def _to_lp(self, d, w, work):
+        prec = self.precision
+        img = self.lp_weight(w, prec)
+        d.w, d.ldw = img.data_ptr(), img.shape[1] // (2 if prec == PREC_BF16X3 else 1)
+        work["bytes"] += d.n_out * d.ksize * d.c_in * (4.0 if prec == PREC_BF16X3 else 2.0) - 4.0 * d.n_out * d.ksize * d.c_in
+        return prec
 
     def empty(self, *shape, like=None, dtype=torch.float32):
         return torch.empty(*shape, dtype=dtype, device=like.device if like is not None else ("cuda" if self.on_gpu else "cpu"))
@@ -118,7 +166,11 @@ class Ops:
         """y[b,t,n] = epilogue(sum_k sum_ci x[b, t*stride + k*dilation - pad, ci] * w[n, k*c_in + ci]).
         ``x`` is [B, T, C]; ``w`` is [N, ldw] packed (weights.pack_conv).  Keywords: see ``_conv_desc``."""
         d, out, ws, B, t_out, N, work = self._conv_desc(x, w, bias, **kw)
-        self._call("svcmi_conv_gemm_f32", ctypes.byref(d), self._stream(), work=work)
+        if self._lp_eligible(d, w, work):
+            prec = self._to_lp(d, w, work)
+            self._call("svcmi_conv_gemm_lp", ctypes.byref(d), prec, self._stream(), work=work)
+        else:
+            self._call("svcmi_conv_gemm_f32", ctypes.byref(d), self._stream(), work=work)
         if kw.get("partials"):      # [B, split, t_out, N] view of this stream's workspace; valid until the next split-K launch on it
             return ws[0][:B * d.split_k * t_out * N].view(B, d.split_k, t_out, N)
         return out
@@ -127,14 +179,26 @@ class Ops:
         """Up to 3 convolutions of one geometry in one launch (svcmi_conv_gemm_group_f32).  ``problems``: dicts of ``conv``
         arguments (x, w, bias + keywords; ``out`` required to differ).  Returns the outputs."""
         descs = (ConvDesc * len(problems))()
-        outs, work = [], {"flops": 0.0, "bytes": 0.0}
+        outs, works, ws = [], [], []
         for i, pr in enumerate(problems):
             pr = dict(pr)
-            d, out, _, _, _, _, wk = self._conv_desc(pr.pop("x"), pr.pop("w"), pr.pop("bias", None), split_k=1, **pr)
+            w = pr.pop("w")
+            d, out, _, _, _, _, wk = self._conv_desc(pr.pop("x"), w, pr.pop("bias", None), split_k=1, **pr)
             descs[i] = d
             outs.append(out)
-            work = {k: work[k] + wk[k] for k in work}
-        self._call("svcmi_conv_gemm_group_f32", descs, len(problems), self._stream(), work=work)
+            works.append(wk)
+            ws.append(w)
+        total = {"flops": sum(wk["flops"] for wk in works), "bytes": 0.0}
+        lp = all(self._lp_eligible(descs[i], ws[i], total) for i in range(len(problems))) and (descs[0].flags >> 8) in (0, 1, 4, 6)
+        prec = PREC_F32
+        if lp:
+            for i in range(len(problems)):
+                prec = self._to_lp(descs[i], ws[i], works[i])
+        total["bytes"] = sum(wk["bytes"] for wk in works)
+        if lp:
+            self._call("svcmi_conv_gemm_group_lp", descs, len(problems), prec, self._stream(), work=total)
+        else:
+            self._call("svcmi_conv_gemm_group_f32", descs, len(problems), self._stream(), work=total)
         return outs
 
     # ------------------------------------------------------------------ norm / attention

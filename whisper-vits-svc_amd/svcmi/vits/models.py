@@ -31,6 +31,9 @@ class SynthesizerInfer:
         self.parallel_blocks = False     # fallback for stages the grouped scheme does not fit: AMP blocks on forked HIP streams
         self.grouped_blocks = True       # the AMP blocks of a stage advance in lock-step through grouped launches
         self._stop_after = None          # tuning aid (scripts/stage_times.py), never set in production
+        # GEMM operand precision of prior encoder / flow / generator: None = fp32 (parity default), "bf16x3" / "bf16" /
+        # "f16" (Ops.use_precision).  Element-wise kernels, softmax, LayerNorm, SnakeAlias and accumulation stay fp32.
+        self.precision = None
         self._streams, self._streams_dev = None, None
 
     # ------------------------------------------------------------------ nn.Module-like surface
@@ -128,9 +131,10 @@ class SynthesizerInfer:
         if noise is None:
             noise = torch.randn(B, w.I, T, device=dev)
         noise = noise.to(dev, torch.float32).contiguous()
-        z_p = self._prior_encoder(w, ops, ppg, vec, pit, lengths, noise)
-        z = self._flow_reverse(w, ops, z_p.clone() if return_parts else z_p, spk, lengths)
-        o = self._generator(w, ops, z, spk, source)
+        with ops.use_precision(self.precision):
+            z_p = self._prior_encoder(w, ops, ppg, vec, pit, lengths, noise)
+            z = self._flow_reverse(w, ops, z_p.clone() if return_parts else z_p, spk, lengths)
+            o = self._generator(w, ops, z, spk, source)
         if return_parts:
             return o, {"z_p": ops.nlc_to_ncl(z_p), "z": ops.nlc_to_ncl(z)}
         return o
@@ -147,13 +151,14 @@ class SynthesizerInfer:
         B, T = pit.shape
         if noise is None:
             noise = torch.randn(B, w.I, T, device=pit.device)
-        z_p = self._prior_encoder(w, ops, ppg50, vec, pit, lengths, noise, ppg_row_shift=1)
-        if self._stop_after == "prior":      # scripts/stage_times.py: truncated pipelines for in-situ stage timing
-            return z_p
-        z = self._flow_reverse(w, ops, z_p, spk, lengths)
-        if self._stop_after == "flow":
-            return z
-        return self._generator(w, ops, z, spk, source.view(B, T * w.hop))
+        with ops.use_precision(self.precision):
+            z_p = self._prior_encoder(w, ops, ppg50, vec, pit, lengths, noise, ppg_row_shift=1)
+            if self._stop_after == "prior":      # scripts/stage_times.py: truncated pipelines for in-situ stage timing
+                return z_p
+            z = self._flow_reverse(w, ops, z_p, spk, lengths)
+            if self._stop_after == "flow":
+                return z
+            return self._generator(w, ops, z, spk, source.view(B, T * w.hop))
 
     # ------------------------------------------------------------------ stages (time-major)
     def _prior_encoder(self, w, ops, ppg, vec, pit, lengths, noise, ppg_row_shift=0):

@@ -24,10 +24,24 @@ class AudioEncoder:
         # 64x64 (N = 5120 -> 8 x 64 = 512 blocks; N = 1280 with 2-4 K slices); the QKV projection stays on 64x64.
         self.split_o, self.split_mlp = 2, 4
         self.tile_o = self.tile_mlp = 6          # SVCMI_CONV_TILE_P16_64x80 >> 8
+        # GEMM operand precision of this encoder: None = fp32 (parity default); "bf16x3" / "bf16" / "f16" (the reference's
+        # own accelerator path is fp16: whisper/inference.py:22-23,43-44) route the linear layers through
+        # svcmi_conv_gemm_lp.  LayerNorm, softmax, GELU, residual stream and accumulation stay fp32 in every mode.
+        self.precision = None
+        self.lp_split_o, self.lp_split_mlp = 2, 4
+        self.lp_tile_qkv = self.lp_tile_o = self.lp_tile_mlp1 = self.lp_tile_mlp2 = 0      # 0 = library heuristic
 
     @torch.no_grad()
     def __call__(self, mel, noise=None, noise_scale=0.1):
+        with self.ops.use_precision(self.precision):
+            return self._forward(mel, noise, noise_scale)
+
+    def _forward(self, mel, noise, noise_scale):
         w, ops = self.w, self.ops
+        lp = ops.precision != 0
+        split_o, split_mlp = (self.lp_split_o, self.lp_split_mlp) if lp else (self.split_o, self.split_mlp)
+        tile_qkv, tile_o, tile_m1, tile_m2 = (self.lp_tile_qkv, self.lp_tile_o, self.lp_tile_mlp1, self.lp_tile_mlp2) if lp else \
+            (0, self.tile_o, self.tile_mlp, self.tile_mlp)
         dev = w.lnp_g.device
         mel = mel.to(dev, torch.float32).contiguous()
         if noise is not None:
@@ -46,12 +60,12 @@ class AudioEncoder:
         nb = len(w.blocks)
         h = ops.layernorm(x, w.blocks[0]["ln1_g"], w.blocks[0]["ln1_b"]) if nb else None
         for i, blk in enumerate(w.blocks):
-            qkv = ops.conv(h, blk["qkv_w"], blk["qkv_b"])
+            qkv = ops.conv(h, blk["qkv_w"], blk["qkv_b"], tile=tile_qkv)
             a = ops.attention(qkv, w.heads, scale)
-            p = ops.conv(a, blk["o_w"], None, partials=True, split_k=max(1, min(self.split_o, blk["o_w"].shape[1] // 128)), tile=self.tile_o)
+            p = ops.conv(a, blk["o_w"], None, partials=True, split_k=max(1, min(split_o, blk["o_w"].shape[1] // 128)), tile=tile_o)
             h = ops.splitk_layernorm(p, blk["o_b"], x, blk["ln2_g"], blk["ln2_b"], out=h)
-            m = ops.conv(h, blk["m1_w"], blk["m1_b"], act=ACT_GELU, tile=self.tile_mlp, split_k=1)
-            p = ops.conv(m, blk["m2_w"], None, partials=True, split_k=max(1, min(self.split_mlp, blk["m2_w"].shape[1] // 128)), tile=self.tile_mlp)
+            m = ops.conv(h, blk["m1_w"], blk["m1_b"], act=ACT_GELU, tile=tile_m1, split_k=1)
+            p = ops.conv(m, blk["m2_w"], None, partials=True, split_k=max(1, min(split_mlp, blk["m2_w"].shape[1] // 128)), tile=tile_m2)
             g, b = (w.blocks[i + 1]["ln1_g"], w.blocks[i + 1]["ln1_b"]) if i + 1 < nb else (w.lnp_g, w.lnp_b)
             h = ops.splitk_layernorm(p, blk["m2_b"], x, g, b, out=h)
         return h if nb else ops.layernorm(x, w.lnp_g, w.lnp_b)
