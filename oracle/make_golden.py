@@ -231,6 +231,100 @@ def crepe_fixture(tag, capacity, n, seed):
                         f0_viterbi=f0v.numpy(), weights_checksum=checksum({k: v.float() for k, v in sd.items()}))
 
 
+def config0_fixture(tag="config0_035"):
+    """BASELINE.json configs[0]: the reference's own bundled sample (configs/singers_sample/22-wave-girl/035.wav, 63 902
+    samples @16 kHz = 3.99 s) and speaker (configs/singers/singer0001.npy) through the reference's OWN functions in the order
+    svc_inference.py:137-203 runs them: whisper/inference.py pred_ppg (large-v2 dims, 24 blocks) -> hubert/inference.py
+    pred_vec -> np.repeat x2 -> svc_infer.  Weights are the seeded random-init ones (no checkpoints offline); librosa is
+    absent, so `librosa.load` is replaced by the int16 / 32768 conversion it performs on a 16 kHz file and the Slaney
+    filterbank by the restated one (as in logmel_fixture); the F0 track is a synthetic integer-Hz contour passed the way
+    `--pit` passes a CSV (CREPE's Viterbi decoding needs librosa.sequence).  The wav and the speaker file are copied next
+    to the fixture so the GPU box can read them."""
+    import shutil
+    import scipy.io.wavfile
+    from . import audio_oracle as A
+    from . import hubert_oracle as H
+    print(f"[{tag}]")
+    R._prepare()
+    wav_src = os.path.join(R.REF, "configs", "singers_sample", "22-wave-girl", "035.wav")
+    spk_src = os.path.join(R.REF, "configs", "singers", "singer0001.npy")
+    shutil.copyfile(wav_src, os.path.join(OUT, "035.wav"))
+    shutil.copyfile(spk_src, os.path.join(OUT, "singer0001.npy"))
+    os.chmod(os.path.join(OUT, "035.wav"), 0o644)
+    os.chmod(os.path.join(OUT, "singer0001.npy"), 0o644)
+    sr, pcm = scipy.io.wavfile.read(wav_src)
+    assert sr == 16000 and pcm.dtype == np.int16 and pcm.shape == (63902,)
+    audio = pcm.astype(np.float32) / 32768.0
+    import librosa
+    librosa.load = lambda f, sr=16000: (audio.copy(), sr)
+    hp = C.base_hp()
+    # ---- PPG: the reference's pred_ppg
+    import whisper.audio as ref_audio
+    import whisper.inference as ref_winf
+    fb = A.slaney_mel_filterbank()
+    ref_audio.librosa_mel_fn = lambda **kw: fb
+    ref_audio.mel_filters.cache_clear()
+    ck = W.make_whisper_state(C.WHISPER_LARGE_V2)
+    wm = R.ref_whisper_encoder(ck)
+    g = torch.Generator().manual_seed(35)
+    n_mel = audio.shape[0] // 160
+    mel_noise = torch.randn(80, n_mel, generator=g)
+    with tempfile.TemporaryDirectory() as tmp:
+        with torch.no_grad(), R.injected_noise([mel_noise]):
+            ref_winf.pred_ppg(wm, wav_src, os.path.join(tmp, "ppg.npy"), "cpu")
+        ppg = np.load(os.path.join(tmp, "ppg.npy"))
+        # ---- vec: the reference's pred_vec
+        import hubert.inference as ref_hinf
+        from hubert.hubert_model import HubertSoft
+        hsd = W.make_hubert_state()
+        hub = HubertSoft()
+        hub.load_state_dict(hsd, strict=True)
+        hub.eval()
+        ref_hinf.pred_vec(hub, wav_src, os.path.join(tmp, "vec.npy"), "cpu")
+        vec = np.load(os.path.join(tmp, "vec.npy"))
+    assert ppg.shape == (audio.shape[0] // 320, 1280) and vec.shape[1] == 256, (ppg.shape, vec.shape)
+    with torch.no_grad():
+        mel = ref_audio.log_mel_spectrogram(audio)
+        o_mel = A.log_mel_spectrogram(torch.from_numpy(audio))
+        o_ppg = O.pred_ppg_from_mel(ck["model_state_dict"], C.WHISPER_LARGE_V2, [o_mel], [mel_noise], [audio.shape[0] // 320])
+        o_vec = H.units(hsd, torch.from_numpy(audio)[None, None], 12)[0]
+    _agree("logmel", o_mel, mel, 1e-6)
+    _agree("ppg", o_ppg, torch.from_numpy(ppg))
+    _agree("vec", o_vec, torch.from_numpy(vec))
+    # ---- svc_inference.py:172-203, then the reference's own svc_infer
+    drv = _import_ref_driver()
+    from feature_retrieval import DummyRetrieval
+    spk = torch.FloatTensor(np.load(spk_src))
+    ppg2 = torch.FloatTensor(np.repeat(ppg, 2, 0))
+    vec2 = torch.FloatTensor(np.repeat(vec, 2, 0))
+    T = min(ppg2.shape[0], vec2.shape[0])
+    pit = torch.FloatTensor([int(v) for v in I.synth_f0(T, seed=35).tolist()])
+    sd = W.make_vits_state(hp, seed=1234)
+    ref = R.ref_synthesizer(hp, sd)
+    L = T * hp.data.hop_length
+    rand_ini = torch.rand(1, 11, generator=g)
+    src_noise = torch.randn(1, L, 11, generator=g)
+    plan = O.chunk_schedule(T, hp.data.hop_length)
+    assert len(plan) == 1
+    enc_noises = [torch.randn(1, hp.vits.inter_channels, T, generator=g)]
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            with R.injected_noise([src_noise] + enc_noises, [rand_ini]):
+                wav = drv.svc_infer(ref, DummyRetrieval(), spk, pit, ppg2, vec2, hp, "cpu")
+        finally:
+            os.chdir(cwd)
+    with torch.no_grad():
+        o_wav, _ = O.svc_infer(sd, hp, spk, pit, ppg2, vec2, rand_ini, src_noise, enc_noises)
+    _agree("svc_infer wave", torch.from_numpy(o_wav), torch.from_numpy(wav))
+    assert wav.shape[0] == L - 1
+    print(f"  T={T} frames, {wav.shape[0]} samples, rms {float(np.sqrt((wav ** 2).mean())):.3f}")
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), T=T, noise_seed=35, logmel=mel.numpy(), ppg=ppg, vec=vec, pit=pit.numpy(),
+                        wave=wav, whisper_checksum=checksum(ck["model_state_dict"]), hubert_checksum=checksum(hsd),
+                        vits_checksum=checksum(sd), audio_checksum=checksum([torch.from_numpy(audio)]))
+
+
 def main():
     assert R.available(), "needs /root/reference"
     os.makedirs(OUT, exist_ok=True)
@@ -243,8 +337,13 @@ def main():
     logmel_fixture("logmel_2p5s", n=40000, seed=21)
     hubert_fixture("hubert_soft_1s", n=16000, seed=3)
     crepe_fixture("crepe_full_1s", "full", n=16000, seed=5)
+    config0_fixture()
     print("golden fixtures written to", OUT)
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "config0":
+        assert R.available(), "needs /root/reference"
+        config0_fixture()
+    else:
+        main()

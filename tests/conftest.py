@@ -20,9 +20,17 @@ def pytest_configure(config):
 def pytest_collection_modifyitems(config, items):
     have_ref = os.path.isdir("/root/reference/vits")
     skip_ref = pytest.mark.skip(reason="/root/reference not present")
+    try:
+        import torch
+        have_gpu = torch.cuda.is_available()
+    except Exception:       # noqa: BLE001
+        have_gpu = False
+    skip_gpu = pytest.mark.skip(reason="no GPU visible (run on the MI355X box: pytest -m gpu)")
     for item in items:
         if "needs_reference" in item.keywords and not have_ref:
             item.add_marker(skip_ref)
+        if "gpu" in item.keywords and not have_gpu:
+            item.add_marker(skip_gpu)
 
 
 @pytest.fixture(scope="session")

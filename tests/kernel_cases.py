@@ -53,6 +53,9 @@ CONV_CASES_SMALL = [
     dict(id="p16_n160_chunk_k7_d3_splitk", B=1, T=200, cin=160, n=160, k=7, dil=3, pad=9, res=True, split_k=2, tile=8),
     dict(id="p16_n38_ragged_masks", B=2, T=150, cin=16, n=38, k=5, pad=2, lengths=[150, 111], mask_in=True, mask_out=True, tile=4),
     dict(id="p16_n70_128x80", B=1, T=200, cin=32, n=70, k=3, pad=1, act=ACT_GELU, tile=7),
+    # outlier-scale inputs: the exact-erf GELU / Mish far in both tails (|v| up to ~100)
+    dict(id="gelu_large_arguments", B=1, T=70, cin=64, n=70, k=3, pad=1, act=ACT_GELU, xscale=30.0),
+    dict(id="mish_large_arguments", B=1, T=70, cin=32, n=40, k=7, pad=3, act=ACT_MISH, xscale=30.0),
 ]
 # reduced-precision operand modes (svcmi_conv_gemm_lp): every tile policy x gather mode, split-K, the K tail, masks
 CONV_CASES_LP_SMALL = [
@@ -94,7 +97,7 @@ def check_conv(ops, c, device):
     g = _g(hash(c["id"]) % 10000)
     rep = c.get("repeat", False)
     t_phys = T // 2 if rep else T
-    x = torch.randn(B, t_phys, cin, generator=g)
+    x = torch.randn(B, t_phys, cin, generator=g) * c.get("xscale", 1.0)
     w = torch.randn(n, cin, k, generator=g) / math.sqrt(cin * k)
     bias = torch.randn(n, generator=g) if c.get("bias", True) else None
     xl = x.repeat_interleave(2, dim=1) if rep else x                      # logical input
@@ -315,11 +318,13 @@ def check_attention(ops, c, device):
     _close(got, want, 2e-5, c["id"])
 
 
-def check_snake(ops, n, c, device):
+def check_snake(ops, n, c, device, amp=1.5, alpha_mean=0.0):
+    """``amp`` / ``alpha_mean`` >> the defaults: outlier-scale activations and SnakeBeta frequencies (sin^2 arguments of
+    hundreds to thousands of radians -- the Cody-Waite range reduction, not the polynomial core, csrc/snake_math.h)."""
     g = _g(n * 100 + c)
     B = 2
-    x = torch.randn(B, n, c, generator=g) * 1.5
-    al, be = torch.randn(c, generator=g) * 0.3, torch.randn(c, generator=g) * 0.3
+    x = torch.randn(B, n, c, generator=g) * amp
+    al, be = torch.randn(c, generator=g) * 0.3 + alpha_mean, torch.randn(c, generator=g) * 0.3
     filt = W.kaiser_sinc_filter().view(-1)
     want = O.snake_alias(x.transpose(1, 2), al, be, filt).transpose(1, 2)
     got = ops.snake_alias(x.to(device), al.to(device), be.to(device), filt.to(device))

@@ -52,3 +52,9 @@ def test_whisper_tiny_f16_operands(ops):
     """fp16 operands (what the reference's `.half()` accelerator path uses, whisper/inference.py:22-23) on the tiny encoder:
     error in the fp16 class, far from fp32's 1e-6 but bounded."""
     print(E.check_whisper_golden(ops, "cpu", "whisper_tiny", C.WHISPER_TINY_TEST, tol=2e-2, precision="f16"))
+
+
+def test_outlier_stress_weights_whisper_and_generator(ops):
+    """parity must not rest on N(0, sigma) weights only."""
+    print(E.check_whisper_stress(ops, "cpu", C.WHISPER_TINY_TEST, n=120))
+    print(E.check_generator_widths_against_oracle(ops, "cpu", T=3, B=1, stress=True))

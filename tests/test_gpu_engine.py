@@ -204,6 +204,31 @@ def test_whisper_10s_against_oracle(ops):
     assert out.shape == (1, 500, 1280) and err <= 1e-3
 
 
+def test_config0_bundled_wav_and_speaker_through_the_engine(ops):
+    """BASELINE.json configs[0]: the reference's own 035.wav + singer0001.npy, wav in -> wav out, vs the reference's outputs."""
+    print(E.check_config0_wav_to_wav(ops, "cuda"))
+
+
+def test_outlier_stress_weights_against_oracle(ops):
+    """Outlier-stress weight sets (massive residual channels, LayerNorm gains up to 30, saturated GELU, SnakeBeta frequencies
+    up to e^2.5 on x50 channels) at full size: Whisper-large-v2 dims on a 10 s window and the base.yaml synthesizer on a
+    3 s clip, vs the oracle."""
+    print("whisper stress:", E.check_whisper_stress(ops, "cuda", C.WHISPER_LARGE_V2, n=1000))
+    hp = C.base_hp()
+    m, sd = E.make_model(hp, ops, "cuda", stress=True)
+    d = I.synth_clip(T=300, hp=hp, seed=12, B=1)
+    src = m.pitch2source(d["pit"], noise=(d["rand_ini"], d["src_noise"]))
+    wav = m.inference(d["ppg"], d["vec"], d["pit"], d["spk"], d["lengths"], src, noise=d["enc_noise"])
+    with torch.no_grad():
+        o_src = O.pitch2source(sd, hp, d["pit"], d["rand_ini"], d["src_noise"])
+        o_wav = O.synth_inference(sd, hp, d["ppg"], d["vec"], d["pit"], d["spk"], d["lengths"], o_src, d["enc_noise"])
+    err = E.maxerr(wav, o_wav)
+    fl = E.stress_floor(sd, hp, d, d["lengths"], o_src, o_wav, wav)
+    print(f"synth stress: waveform err {err:.2e} (vs fp64 oracle {fl['wave_vs_fp64']:.2e}; fp32 oracle vs fp64 {fl['oracle_fp32_vs_fp64']:.2e}), "
+          f"rms {float(o_wav.pow(2).mean().sqrt()):.3f}")
+    assert err <= E.WAVE_TOL and fl["wave_vs_fp64"] <= E.WAVE_TOL
+
+
 def test_pred_ppg_two_windows_against_oracle(ops):
     """Row a2 (whisper/inference.py:32-62): a 18.2 s clip = one full 15 s window (n = 1500 mel frames, Tw = 750, all kept)
     + a ragged remainder window (odd mel length, kept = samples // 320 < Tw) through ``pred_ppg_from_mel`` with explicit

@@ -53,6 +53,11 @@ SNAKE_CONV_LARGE = [
 ]
 
 
+@pytest.mark.parametrize("n,c,amp,alpha", [(61, 12, 40.0, 2.5), (130, 20, 300.0, 3.0)])
+def test_snake_alias_outlier_scale(ops, n, c, amp, alpha):
+    K.check_snake(ops, n, c, device="cuda", amp=amp, alpha_mean=alpha)
+
+
 @pytest.mark.parametrize("case", K.SNAKE_CONV_CASES + SNAKE_CONV_LARGE, ids=lambda c: c["id"])
 def test_snake_conv_fused(ops, case):
     K.check_snake_conv(ops, case, device="cuda")

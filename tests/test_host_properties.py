@@ -71,3 +71,32 @@ def test_lpt_sharding_invariants(lengths, world):
     if lengths:
         loads = [sum(lengths[i] for i in s) for s in shards]
         assert max(loads) - min(loads) <= max(lengths)
+
+
+@settings(max_examples=100, deadline=None)
+@given(st.lists(st.floats(0.0, 1200.0, allow_nan=False, width=32), min_size=1, max_size=40))
+def test_batch_path_quantises_f0_like_the_csv_round_trip(tmp_path_factory, f0):
+    """svc_inference_batch must hand the synthesizer the same F0 as svc_inference (which round-trips the pitch
+    CSV, pitch/inference.py:102-119): int() truncation per frame."""
+    path = tmp_path_factory.mktemp("csv") / "q.csv"
+    PI.save_csv_pitch(f0, str(path))
+    assert PI.quantize_pitch_like_csv(f0) == PI.load_csv_pitch(str(path))
+
+
+def test_batch_path_rejects_nan_f0_like_the_reference():
+    import pytest
+    with pytest.raises(ValueError):
+        PI.quantize_pitch_like_csv([220.0, float("nan")])          # int(nan): the reference's save_csv_pitch fails the same way
+
+
+@settings(max_examples=100, deadline=None)
+@given(st.lists(st.one_of(st.floats(50.0, 1000.0, width=32), st.just(float("nan")), st.just(0.0)), min_size=1, max_size=30),
+       st.sampled_from([3, 5, 9]))
+def test_mean_filter_keeps_length_and_matches_the_oracle(x, win):
+    """clips shorter than the window must keep their length (crepe/filter.py:10-57 pads, it does not grow)."""
+    import torch
+    from oracle import crepe_oracle as CO
+    got = PI._mean_filter_np(np.asarray(x, dtype=np.float32), win)
+    want = CO.mean_filter(torch.tensor(x, dtype=torch.float32)[None], win)[0].numpy()
+    assert got.shape == want.shape == (len(x),)
+    assert np.allclose(got, want, rtol=1e-6, atol=0, equal_nan=True)

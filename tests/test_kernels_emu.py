@@ -39,6 +39,11 @@ def test_snake_alias(ops, n, c):
     K.check_snake(ops, n, c, device="cpu")
 
 
+@pytest.mark.parametrize("n,c,amp,alpha", [(61, 12, 40.0, 2.5), (130, 20, 300.0, 3.0)])
+def test_snake_alias_outlier_scale(ops, n, c, amp, alpha):
+    K.check_snake(ops, n, c, device="cpu", amp=amp, alpha_mean=alpha)
+
+
 @pytest.mark.parametrize("case", K.SNAKE_CONV_CASES, ids=lambda c: c["id"])
 def test_snake_conv_fused(ops, case):
     K.check_snake_conv(ops, case, device="cpu")

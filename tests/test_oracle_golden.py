@@ -171,3 +171,57 @@ def test_viterbi_restatement_on_a_known_case():
     tr = np.array([[0.9, 0.05, 0.05], [0.05, 0.9, 0.05], [0.05, 0.05, 0.9]])
     assert CO.viterbi_path(prob, tr).tolist() == [0, 0, 0]
     assert CO.viterbi_path(prob, np.full((3, 3), 1 / 3)).tolist() == [0, 1, 0]
+
+
+@pytest.mark.needs_reference
+def test_crepe_mean_filter_oracle_matches_the_reference_filter():
+    """the tail of compute_f0_sing (np.repeat x2 + crepe.filter.mean(5), pitch/inference.py:95-97) was only
+    compared oracle-to-engine.  Here the oracle's mean_filter and the engine's numpy form run against the reference's own
+    crepe/filter.py:10-57 (imported from /root/reference) on tracks with NaNs, exact zeros and lengths below the window."""
+    import importlib.util
+    import numpy as np
+    from oracle import crepe_oracle as CO
+    from svcmi.pitch import inference as PI
+    spec = importlib.util.spec_from_file_location("ref_crepe_filter", "/root/reference/crepe/filter.py")
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    g = torch.Generator().manual_seed(5)
+    for T in (1, 2, 3, 4, 5, 6, 9, 64, 1001):
+        for win in (3, 5):
+            x = 50.0 + 900.0 * torch.rand(1, T, generator=g)
+            x[torch.rand(1, T, generator=g) < 0.2] = float("nan")
+            x[torch.rand(1, T, generator=g) < 0.1] = 0.0
+            x = torch.from_numpy(np.repeat(x.numpy(), 2, -1))              # pitch/inference.py:95
+            want = ref.mean(x.clone(), win)
+            assert torch.allclose(CO.mean_filter(x.clone(), win), want, rtol=0, atol=0, equal_nan=True)
+            got = PI._mean_filter_np(x[0].numpy(), win)
+            assert got.shape == (2 * T,) and np.allclose(got, want[0].numpy(), rtol=1e-6, atol=0, equal_nan=True)
+
+
+def test_config0_fixture_oracle_reproduces_the_reference(golden_dir):
+    """BASELINE.json configs[0] (plumbing on the CPU): the bundled 035.wav + singer0001.npy.  The stored PPG / vec / waveform are
+    what the REFERENCE's pred_ppg, pred_vec and svc_infer produced (make_golden.config0_fixture); the oracle must reproduce
+    the log-mel from the wav file and the waveform from the stored features with the same injected noise."""
+    import scipy.io.wavfile
+    from oracle import audio_oracle as A
+    from tests.engine_cases import config0_noise
+    g = _load(golden_dir, "config0_035")
+    hp = C.base_hp()
+    sr, pcm = scipy.io.wavfile.read(os.path.join(golden_dir, "035.wav"))
+    assert sr == 16000 and pcm.shape == (63902,)
+    audio = torch.from_numpy(pcm.astype(np.float32) / 32768.0)
+    assert checksum([audio]) == pytest.approx(float(g["audio_checksum"]), rel=1e-12)
+    assert (A.log_mel_spectrogram(audio) - _t(g["logmel"])).abs().max() <= 1e-6
+    T = int(g["T"])
+    assert g["ppg"].shape == (63902 // 320, 1280) and 2 * g["ppg"].shape[0] == T == 398      # SURVEY.md 8d config 1
+    spk = torch.FloatTensor(np.load(os.path.join(golden_dir, "singer0001.npy")))
+    assert spk.shape == (256,) and abs(float(spk.norm()) - 0.82) < 0.05
+    sd = W.make_vits_state(hp, seed=1234)
+    assert checksum(sd) == pytest.approx(float(g["vits_checksum"]), rel=1e-9)
+    _, rand_ini, src_noise, enc_noises = config0_noise(g, T, hp)
+    ppg2 = torch.FloatTensor(np.repeat(g["ppg"], 2, 0))
+    vec2 = torch.FloatTensor(np.repeat(g["vec"], 2, 0))
+    with torch.no_grad():
+        wav, _ = O.svc_infer(sd, hp, spk, _t(g["pit"]), ppg2, vec2, rand_ini, src_noise, enc_noises)
+    assert wav.shape == g["wave"].shape == (T * 320 - 1,)
+    assert np.abs(wav - g["wave"]).max() <= TOL

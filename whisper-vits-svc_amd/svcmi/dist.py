@@ -38,9 +38,12 @@ def broadcast_state_dict(sd, src=0, device="cpu", group=None):
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return {k: v.to(device) for k, v in sd.items()}
     rank = dist.get_rank(group)
-    meta = [[(k, tuple(v.shape)) for k, v in sd.items()]] if rank == src else [None]
+    # integer / bool buffers (e.g. BatchNorm's num_batches_tracked) are tiny and must not be rounded through fp32: they
+    # travel with the layout message
+    meta = [([(k, tuple(v.shape)) for k, v in sd.items() if v.is_floating_point()],
+             {k: v.cpu() for k, v in sd.items() if not v.is_floating_point()})] if rank == src else [None]
     dist.broadcast_object_list(meta, src=src, group=group)
-    layout = meta[0]
+    layout, other = meta[0]
     total = sum(int(torch.Size(s).numel()) for _, s in layout)
     if rank == src:
         arena = torch.cat([sd[k].detach().reshape(-1).to(device=device, dtype=torch.float32) for k, _ in layout])
@@ -52,6 +55,7 @@ def broadcast_state_dict(sd, src=0, device="cpu", group=None):
         n = int(torch.Size(s).numel())
         out[k] = arena[off:off + n].view(s)
         off += n
+    out.update({k: v.to(device) for k, v in other.items()})
     return out
 
 

@@ -22,6 +22,8 @@ from .ops import Ops
 from .svc_inference import IRetrieval
 
 MAX_SCORE_FLOATS = 1 << 28        # 1 GiB of fp32 scores per search tile
+MAX_NEAREST = 8                   # candidates svcmi_knn_blend_f32 keeps per frame
+MAX_GEMM_FLOATS = (1 << 27) - 1   # one svcmi_conv_gemm_f32 operand addresses < 2^27 floats
 
 
 class KnnFeatureIndex:
@@ -30,6 +32,8 @@ class KnnFeatureIndex:
     def __init__(self, bank, ratio, n_nearest_vectors, device="cuda", ops=None):
         if 1 > n_nearest_vectors:
             raise ValueError("n-retrieval-vectors must be gte 1")
+        if n_nearest_vectors > MAX_NEAREST:
+            raise ValueError(f"n-retrieval-vectors must be lte {MAX_NEAREST} (svcmi_knn_blend_f32 keeps {MAX_NEAREST} candidates per frame)")
         if not 0 <= ratio <= 1:
             raise ValueError(f"{ratio=} must be in rage (0, 1)")
         bank = torch.as_tensor(bank, dtype=torch.float32)
@@ -65,7 +69,7 @@ class KnnFeatureIndex:
         out = torch.empty_like(x)
         n = self.bank.shape[0]
         ldd = (n + 3) // 4 * 4
-        rows = max(1, min(t, MAX_SCORE_FLOATS // ldd))
+        rows = max(1, min(t, MAX_SCORE_FLOATS // ldd, MAX_GEMM_FLOATS // d))      # score tile and the GEMM's x operand both bounded
         dots = torch.empty(rows, ldd, dtype=torch.float32, device=x.device)
         for s in range(0, t, rows):
             e = min(t, s + rows)
@@ -78,7 +82,15 @@ class KnnFeatureIndex:
 
 def load_retrieve_index(filepath, ratio, n_nearest_vectors, device="cuda", ops=None):
     """index.py:163-166 for ``.npy`` feature banks."""
-    return KnnFeatureIndex(np.load(str(filepath)), ratio, n_nearest_vectors, device=device, ops=ops)
+    filepath = str(filepath)
+    if not os.path.exists(filepath):
+        faiss_file = filepath[:-4] if filepath.endswith(".index.npy") else filepath
+        if faiss_file.endswith(".index") and os.path.exists(faiss_file):
+            raise FileNotFoundError(
+                f"{faiss_file} is a faiss index, which this stack cannot read (faiss is not installed): rebuild the bank from the "
+                f"speaker's feature files with svcmi.feature_retrieval.build_index_bank(<data_svc/whisper|hubert/spk>, '{filepath}')")
+        raise FileNotFoundError(f"retrieval feature bank {filepath} not found (see build_index_bank)")
+    return KnnFeatureIndex(np.load(filepath), ratio, n_nearest_vectors, device=device, ops=ops)
 
 
 def build_index_bank(feature_dir, out_path=None):

@@ -197,8 +197,11 @@ def _mean_filter_np(x, win_length):
     x = np.asarray(x, dtype=np.float32)
     mask = ~np.isnan(x)
     ones = np.ones(win_length, dtype=np.float32)
-    s = np.convolve(np.where(mask, x, np.float32(0)), ones, mode="same")
-    c = np.maximum(np.convolve(mask.astype(np.float32), ones, mode="same"), np.float32(1))
+    # 'full' + slice keeps len(x) outputs also when len(x) < win_length (mode="same" returns max(len(x), win_length) values;
+    # the reference's F.conv1d(padding=win_length // 2) keeps the length, crepe/filter.py:10-37)
+    lo = win_length // 2
+    s = np.convolve(np.where(mask, x, np.float32(0)), ones, mode="full")[lo:lo + x.shape[0]]
+    c = np.maximum(np.convolve(mask.astype(np.float32), ones, mode="full")[lo:lo + x.shape[0]], np.float32(1))
     out = (s / c).astype(np.float32)
     out[out == 0] = np.nan
     return out
@@ -213,6 +216,13 @@ def save_csv_pitch(pitch, path):
             seconds = (t - minute * 60000) // 1000
             millisecond = t % 1000
             print(f"{minute}m {seconds}s {millisecond:3d},{int(pitch[i])}", file=f)
+
+
+def quantize_pitch_like_csv(pitch):
+    """What a ``save_csv_pitch`` -> ``load_csv_pitch`` round trip does to an F0 track, without the file: ``int(p)`` truncation
+    per frame (and the reference's ``ValueError`` on NaN, pitch/inference.py:110).  The synthesizer only ever sees F0 that went
+    through the CSV (svc_inference.py:150-154,183), so every in-process path must apply this."""
+    return [int(p) for p in pitch]
 
 
 def load_csv_pitch(path):

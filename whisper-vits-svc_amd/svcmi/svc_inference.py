@@ -194,7 +194,8 @@ def build_parser():
     p.add_argument("--retrieval-index-prefix", default="",
                    help="retrieval index file prefix. Will load file %%prefix%%hubert.index.npy/%%prefix%%whisper.index.npy")
     p.add_argument("--retrieval-ratio", type=float, default=.5, help="ratio of feature retrieval effect. Must be in range 0..1")
-    p.add_argument("--n-retrieval-vectors", type=int, default=3, help="get n nearest vectors from retrieval index (1..8)")
+    p.add_argument("--n-retrieval-vectors", type=int, default=3, choices=range(1, 9), metavar="[1-8]",
+                   help="get n nearest vectors from retrieval index (1..8)")
     p.add_argument("--hubert-index-path", required=False, help="path to a hubert feature bank (.npy [n, 256])")
     p.add_argument("--whisper-index-path", required=False, help="path to a whisper feature bank (.npy [n, 1280])")
     p.add_argument("--whisper", type=str, default=os.path.join("whisper_pretrain", "large-v2.pt"))

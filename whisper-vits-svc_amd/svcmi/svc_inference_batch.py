@@ -51,7 +51,12 @@ class Converter:
         self.crepe = pitch_inf.load_crepe(bc(_load_on_rank0(args.crepe, rank)), device)
         ck = _load_on_rank0(args.model, rank)
         self.model = SynthesizerInfer(self.hp.data.filter_length // 2 + 1, self.hp.data.segment_size // self.hp.data.hop_length, self.hp)
-        sd = bc({k: v for k, v in ck["model_g"].items() if k in self.model.state_dict()} if rank == 0 else None)
+        want = self.model.state_dict()
+        if rank == 0:                       # svc_inference.py:61-74: report what the checkpoint lacks instead of silently keeping the init values
+            for k in want:
+                if k not in ck["model_g"]:
+                    print("%s is not in the checkpoint" % k)
+        sd = bc({k: v for k, v in ck["model_g"].items() if k in want} if rank == 0 else None)
         self.model.load_state_dict({k: v.cpu() for k, v in sd.items()}, strict=False)
         self.model.eval()
         self.model.to(device)
@@ -70,7 +75,8 @@ class Converter:
         pit = pitch_inf.compute_f0_sing(wav_path, self.device, model=self.crepe)
         ppg = torch.FloatTensor(np.repeat(np.load(ppg_p), 2, 0))
         vec = torch.FloatTensor(np.repeat(np.load(vec_p), 2, 0))
-        pit = torch.FloatTensor(shift_pitch(np.asarray(pit), self.args.shift))
+        # the reference hands F0 to the synthesizer through the pitch CSV (svc_inference.py:150-154,183): int() per frame
+        pit = torch.FloatTensor(shift_pitch(pitch_inf.quantize_pitch_like_csv(pit), self.args.shift))
         os.remove(ppg_p)
         os.remove(vec_p)
         return svc_infer(self.model, DummyRetrieval(), self.spk, pit, ppg, vec, self.hp, self.device, write_pit_wav=False)

@@ -189,6 +189,66 @@ def make_whisper_state(dims=None, seed=4321, n_layers_present=None):
     return {"dims": dims, "model_state_dict": {k: v.float().contiguous() for k, v in sd.items()}}
 
 
+def stress_whisper_state(ck, seed=97):
+    """Outlier-stress variant of a Whisper checkpoint (a modified copy): trained Whisper-large encoders carry a handful of
+    residual-stream channels two orders of magnitude above the rest, LayerNorm gains far from 1 and saturated GELU inputs,
+    which N(0, sigma) weights never produce.  Deterministic post-hoc edits, so the plain fixtures keep their RNG stream:
+      * 4 residual channels driven to |x| ~ 50-100 from block 1 on (mlp.2 rows x50 and a +-20 bias),
+      * 6 LayerNorm gains per block raised to 10..30 (attn_ln and mlp_ln),
+      * 8 mlp.0 biases per block at +-15 (erf-GELU far in both tails),
+      * one head's query/key rows x3 in every third block (peaked softmax)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {k: v.clone() for k, v in ck["model_state_dict"].items()}
+    S = ck["dims"]["n_audio_state"]
+    dh = S // ck["dims"]["n_audio_head"]
+    big = torch.randperm(S, generator=g)[:4]
+    nb = len([k for k in sd if k.endswith(".mlp_ln.weight")])
+    for i in range(nb):
+        b = f"encoder.blocks.{i}"
+        if i == 1:
+            sd[f"{b}.mlp.2.weight"][big] *= 50.0
+            sd[f"{b}.mlp.2.bias"][big] += torch.tensor([20.0, -20.0, 20.0, -20.0])
+        for ln in ("attn_ln", "mlp_ln"):
+            idx = torch.randperm(S, generator=g)[:6]
+            sd[f"{b}.{ln}.weight"][idx] = 10.0 + 20.0 * torch.rand(6, generator=g)
+        idx = torch.randperm(4 * S, generator=g)[:8]
+        sd[f"{b}.mlp.0.bias"][idx] = 15.0 * torch.sign(torch.randn(8, generator=g))
+        if i % 3 == 0:
+            h = int(torch.randint(0, S // dh, (1,), generator=g))
+            sd[f"{b}.attn.query.weight"][h * dh:(h + 1) * dh] *= 3.0
+            sd[f"{b}.attn.key.weight"][h * dh:(h + 1) * dh] *= 3.0
+    idx = torch.randperm(S, generator=g)[:6]
+    sd["encoder.ln_post.weight"][idx] = 10.0 + 20.0 * torch.rand(6, generator=g)
+    return {"dims": dict(ck["dims"]), "model_state_dict": sd}
+
+
+def stress_vits_state(sd, hp=None, seed=98):
+    """Outlier-stress variant of a SynthesizerInfer state dict (a modified copy): a few generator channels x50 at conv_pre
+    (|x| >> 1 into the first SnakeBeta stages), SnakeBeta frequencies e^alpha up to e and amplitudes 1/e^beta up to 1.6 on a
+    fifth of the channels, and prior-encoder LayerNorm gains up to 30 (|z_p| reaches hundreds).  The set is tuned to stay
+    WELL-CONDITIONED: x50 channels combined with frequencies e^2.5 and amplitudes e^2 make the fp32 and fp64 oracles themselves
+    disagree by 5e-2 on the waveform (each SnakeBeta then has slope ~100 and 90 of them are chained), which would test chaos,
+    not kernels; sin^2 at arguments of thousands of radians is covered at kernel level instead (kernel_cases.check_snake)."""
+    hp = hp or C.base_hp()
+    g = torch.Generator().manual_seed(seed)
+    sd = {k: v.clone() for k, v in sd.items()}
+    C0 = hp.gen.upsample_initial_channel
+    idx = torch.randperm(C0, generator=g)[:3]
+    sd["dec.conv_pre.weight"][idx] *= 50.0
+    for k in sd:
+        if k.endswith(".act.alpha") or k.endswith(".act.beta"):
+            n = sd[k].shape[0]
+            m = max(1, n // 5)
+            sel = torch.randperm(n, generator=g)[:m]
+            sd[k][sel] = (1.0 if k.endswith("alpha") else -0.5) * torch.rand(m, generator=g)
+        # (not the last norm_layers_2: it feeds `proj`, whose log-sigma half is exponentiated -- gains of 30 there make
+        # |z_p| ~ 1e7 and the comparison a test of exp() conditioning)
+        if ".norm_layers_" in k and k.endswith(".gamma") and k != f"enc_p.enc.norm_layers_2.{C.ENC_LAYERS - 1}.gamma":
+            sel = torch.randperm(sd[k].shape[0], generator=g)[:4]
+            sd[k][sel] = 10.0 + 20.0 * torch.rand(4, generator=g)
+    return sd
+
+
 def make_hubert_state(dims=None, seed=2468):
     """``HubertSoft().state_dict()`` key layout (hubert/hubert_model.py; 166 tensors at the reference dims), seeded.
     ``masked_spec_embed`` / ``label_embedding`` are training-only and included so a strict load succeeds."""
