@@ -5,19 +5,28 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one batch of synthetic input resident in HBM:
-    mel [B,80,1000] --(+0.1*randn)--> Whisper-24L encoder --> PPG 50 fps --(x2 repeat fused)-->
-    prior encoder -> reverse flow -> NSF-BigVGAN (incl. pitch2source) --> 32 kHz waveform [B,1,320000] in HBM.
-The workload is BASELINE.json configs[1] (1 GPU, batch 1, 10 s clip, whisper-large-v2 dims + base.yaml decoder),
-fp32, random-init weights of that architecture (no checkpoints/network), the path's stochastic draws made on the
-device inside the step.  With N GPUs every rank runs the same per-GPU work on its own clip (weak scaling);
-weights are generated on rank 0 and broadcast once over RCCL; the hot loop has no collective.
+One "step" = one pass of the hot path over one batch of synthetic input resident in HBM.  The default (the judged line) is
+BASELINE.json configs[1]:
+    mel [1,80,1000] --(+0.1*randn)--> Whisper-24L encoder --> PPG 50 fps --(x2 repeat fused)-->
+    prior encoder -> reverse flow -> NSF-BigVGAN (incl. pitch2source) --> 32 kHz waveform [1,1,320000] in HBM,
+fp32, random-init weights of the named architecture (no checkpoints / network), the path's stochastic draws made on the
+device inside the step.  `--config` selects the other BASELINE.json configurations (same JSON schema, `config.workload` names it):
+    2  1 GPU: batch 16 x 10 s clips, flow + decoder only (pre-extracted PPG / F0), bf16 GEMM operands
+    3  512 x 10 s utterances sharded over the ranks (64 per GPU at 8), batches of 16, full pipeline incl. Whisper; a step is
+       one pass over this rank's shard, so the total work is fixed: "scaling": "strong"
+    4  30 s clips per rank through the reference schedule: two 15 s Whisper windows (Tw = 750 each, fp16 GEMM operands like
+       the reference's .half() accelerator path), T = 3000 frames -> synthesis chunks [0,2510) / [2490,3000) with the halo
+       trim of svc_inference.py:101-131
+With N GPUs every rank runs its own clips (weak scaling; config 3: strong); rank 0 makes and PACKS the weights once and all
+ranks receive the packed arena through one RCCL broadcast per model; the hot loop has no collective.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the fp32-MFMA conv/linear GEMM):
-algorithmic FLOPs of its launches / their HIP-event durations, measured on the launch stream in an instrumented
-pass of the same step.  `cpu_baseline` times the oracle (CPU port of the reference path) on one clip.
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel family (the implicit-GEMM conv/linear kernel):
+algorithmic FLOPs of its launches / their HIP-event durations, measured on the launch stream in an instrumented pass of the
+same step (`frac`), beside the same ratio from the newest committed rocprofv3 summary (`frac_rocprof`).  `cpu_baseline`
+times the oracle (CPU port of the reference path) on one clip of the workload on this host's cores.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -39,23 +48,32 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-class Workload:
-    """Device-resident synthetic inputs + the engine objects for one rank."""
+# ------------------------------------------------------------------------------------------------ workloads
+def synth_features(T, hp, seeds, device):
+    """mel / vec / F0 / speaker of len(seeds) clips of T frames, resident on ``device`` (the noise draws of the path are made
+    inside the step).  Same recipe as workload.inputs.synth_clip, without its 14 MB-per-clip source-noise tensors."""
+    from workload import inputs as I
+    mel, vec, pit, spk = [], [], [], []
+    for s in seeds:
+        g = torch.Generator().manual_seed(1000 + s)
+        mel.append((torch.randn(80, T, generator=g) * 0.5).clamp(-1.0, 1.5))
+        vec.append(torch.randn(T, hp.vits.vec_dim, generator=g))
+        pit.append(I.synth_f0(T, seed=3 + s, base=180.0 + 40 * (s % 4)))
+        spk.append(I.synth_spk(hp.vits.spk_dim, seed=7 + s % 56))
+    f = lambda ts: torch.stack(ts).to(device)
+    return f(mel), f(vec), f(pit), f(spk)
 
-    def __init__(self, ops, device, batch, seconds, wsd, vsd, hp, seed, precision=None):
+
+class Workload:
+    """configs[1] (and --batch / --seconds variants of it): device-resident synthetic inputs + the engine objects of one rank."""
+
+    name = "configs[1]"
+
+    def __init__(self, ops, device, whisper, model, hp, args, rank, world):
         from workload import inputs as I      # synthetic input recipe (SURVEY.md 8d config 2)
-        from svcmi import SynthesizerInfer
-        from svcmi.whisper.inference import load_model
-        self.ops, self.device, self.hp = ops, device, hp
-        self.B, self.T = batch, int(seconds * 100)
-        self.whisper = load_model(wsd, device, ops=ops)
-        self.model = SynthesizerInfer(hp.data.filter_length // 2 + 1, hp.data.segment_size // hp.data.hop_length, hp, ops=ops)
-        self.model.load_state_dict(vsd)
-        self.model.eval()
-        self.model.to(device)
-        self.model._weights()
-        self.whisper.encoder.precision = self.model.precision = precision     # None = fp32 (the judged line)
-        d = I.synth_clip(T=self.T, hp=hp, seed=seed, B=batch, ppg=False)
+        self.ops, self.device, self.hp, self.whisper, self.model = ops, device, hp, whisper, model
+        self.B, self.T = args.batch, int(args.seconds * 100)
+        d = I.synth_clip(T=self.T, hp=hp, seed=100 + rank, B=self.B, ppg=False)
         self.cpu_inputs = d
         self.mel = d["mel"].to(device)
         self.vec = d["vec"].to(device)
@@ -63,10 +81,14 @@ class Workload:
         self.spk = d["spk"].to(device)
         self.lengths = d["lengths"].to(device, torch.int32)
         self.keep = self.T // 2                                   # whisper/inference.py:40: len // 320 frames
+        self.audio_seconds_per_step = self.B * args.seconds
+        self.scaling = "weak"
+        self.workload = (f"configs[1]: batch={self.B} x {args.seconds:g}s clip per GPU, whisper-large-v2 dims (24 of 32 encoder blocks) "
+                         f"+ base.yaml prior/flow/NSF-BigVGAN")
 
     def step(self, noise=None):
         """The timed unit.  noise=None draws on the device (as the reference does per call)."""
-        m, B, T = self.model, self.B, self.T
+        m = self.model
         mel_noise = torch.randn_like(self.mel) if noise is None else noise["mel_noise"]
         ppg50 = self.whisper.encoder(self.mel, mel_noise, 0.1)[:, :self.keep]
         src = m.pitch2source(self.pit, noise=None if noise is None else (noise["rand_ini"], noise["src_noise"]))
@@ -74,20 +96,139 @@ class Workload:
                                  noise=None if noise is None else noise["enc_noise"])
 
 
-def build_graph(wl, warm=2):
-    """Capture one step into a HIP graph (torch.cuda.CUDAGraph captures the ctypes launches made on its
-    capture stream).  Returns (graph, output) or (None, None) if capture is not possible."""
+class FlowDecoderBatch(Workload):
+    """configs[2]: 16 x 10 s clips per step, flow + decoder only: PPG (50 fps, as Whisper leaves it) / HuBERT vec / F0 are
+    pre-extracted inputs resident in HBM; the step is pitch2source + prior encoder + reverse flow + generator."""
+
+    name = "configs[2]"
+
+    def __init__(self, ops, device, whisper, model, hp, args, rank, world):
+        self.ops, self.device, self.hp, self.whisper, self.model = ops, device, hp, None, model
+        self.B, self.T = args.batch, int(args.seconds * 100)
+        seeds = [100 + rank * self.B + b for b in range(self.B)]
+        _, self.vec, self.pit, self.spk = synth_features(self.T, hp, seeds, device)
+        g = torch.Generator().manual_seed(900 + rank)
+        self.ppg50 = torch.randn(self.B, self.T // 2, hp.vits.ppg_dim, generator=g).to(device)     # layer-normed Whisper output: O(1)
+        self.lengths = torch.full((self.B,), self.T, dtype=torch.int32, device=device)
+        self.audio_seconds_per_step = self.B * args.seconds
+        self.scaling = "weak"
+        self.cpu_inputs = None
+        self.workload = (f"configs[2]: batch={self.B} x {args.seconds:g}s clips per GPU, flow + decoder only (pre-extracted PPG / vec / F0 "
+                         f"in HBM): pitch2source + prior encoder + reverse flow + NSF-BigVGAN, base.yaml")
+
+    def step(self, noise=None):
+        m = self.model
+        src = m.pitch2source(self.pit)
+        return m.inference_ppg50(self.ppg50, self.vec, self.pit, self.spk, self.lengths, src)
+
+
+class ShardedUtterances(Workload):
+    """configs[3]: 512 x 10 s utterances, sharded over the ranks (svcmi.dist.plan_batches: 64 per GPU at 8), converted in
+    batches of 16 through the FULL pipeline (Whisper -> PPG -> prior / flow / generator).  One step = this rank's whole
+    shard; the features of the shard are resident in HBM, each batch is staged into the static input buffers of one captured
+    HIP graph (a device-to-device copy, counted in the step)."""
+
+    name = "configs[3]"
+
+    def __init__(self, ops, device, whisper, model, hp, args, rank, world):
+        from svcmi import dist as D
+        self.ops, self.device, self.hp, self.whisper, self.model = ops, device, hp, whisper, model
+        self.B, self.T = args.batch, int(args.seconds * 100)
+        self.batches = D.plan_batches(args.utterances, world, rank, self.B)
+        ids = [i for b in self.batches for i in b]
+        self.all = synth_features(self.T, hp, ids, device)                       # the whole shard: 64 clips = 0.3 GB at 8 GPUs
+        self.mel, self.vec, self.pit, self.spk = (t[:self.B].clone() for t in self.all)      # static graph inputs
+        self.lengths = torch.full((self.B,), self.T, dtype=torch.int32, device=device)
+        self.keep = self.T // 2
+        self.n_mine = len(ids)
+        self.audio_seconds_per_step = None                                       # strong scaling: the job is fixed
+        self.total_audio_seconds = args.utterances * args.seconds
+        self.scaling = "strong"
+        self.cpu_inputs = None
+        self.outputs = torch.empty(len(ids), 1, self.T * 320, device=device)     # the converted shard stays in HBM
+        self.workload = (f"configs[3]: {args.utterances} x {args.seconds:g}s utterances sharded over {world} GPU(s) ({len(ids)} on this rank), "
+                         f"batches of {self.B}, full pipeline incl. Whisper-24L")
+        self.graph_one_batch = None
+
+    def one_batch(self, noise=None):
+        return Workload.step(self, noise)
+
+    def step(self, noise=None):
+        done = 0
+        for b in self.batches:
+            n = len(b)
+            for dst, src in zip((self.mel, self.vec, self.pit, self.spk), self.all):
+                dst[:n].copy_(src[done:done + n])
+            out = self.graph_one_batch() if self.graph_one_batch is not None else self.one_batch()
+            self.outputs[done:done + n].copy_(out[:n])
+            done += n
+        return self.outputs
+
+
+class LongForm(Workload):
+    """configs[4]: one 30 s clip per rank and step through the reference's schedule -- pred_ppg's two 15 s windows
+    (whisper/inference.py:37-61; Tw = 750 each, run as ONE batch of 2: windows are independent), np.repeat x2 fused, then
+    svc_infer's chunks [0,2510) -> keep [0,-3200) and [2490,3000) -> keep [3200,-1) (svc_inference.py:101-131), output L - 1
+    samples in HBM."""
+
+    name = "configs[4]"
+
+    def __init__(self, ops, device, whisper, model, hp, args, rank, world):
+        from svcmi.svc_inference import chunk_schedule
+        from svcmi.whisper.inference import window_plan
+        self.ops, self.device, self.hp, self.whisper, self.model = ops, device, hp, whisper, model
+        secs = args.seconds
+        self.T = int(secs * 100)
+        n_samples = int(secs * 16000)
+        self.windows = window_plan(n_samples)
+        assert len({e - s for (s, e, _) in self.windows}) == 1, "equal windows expected (30 s = 2 x 15 s)"
+        n_mel = (self.windows[0][1] - self.windows[0][0]) // 160
+        self.keep = [k for (_, _, k) in self.windows]
+        mel, self.vec, self.pit, self.spk = synth_features(n_mel * len(self.windows), hp, [100 + rank], device)
+        self.mel = mel[0].view(80, len(self.windows), n_mel).permute(1, 0, 2).contiguous()          # [windows, 80, n_mel]
+        self.vec, self.pit = self.vec[:, :self.T], self.pit[:, :self.T]
+        self.plan = chunk_schedule(self.T, hp.data.hop_length)
+        self.B = 1
+        self.audio_seconds_per_step = secs
+        self.scaling = "weak"
+        self.cpu_inputs = None
+        self.workload = (f"configs[4]: one {secs:g}s clip per GPU and step, reference schedule: {len(self.windows)} Whisper windows of "
+                         f"Tw={n_mel // 2} (one batch), synthesis chunks {[(a, b) for (a, b, _, _) in self.plan]} with halo trim, whisper-large-v2 dims + base.yaml")
+
+    def step(self, noise=None):
+        m, hop = self.model, self.hp.data.hop_length
+        ppg = self.whisper.encoder(self.mel, torch.randn_like(self.mel), 0.1)                      # [windows, Tw, 1280]
+        ppg50 = torch.cat([ppg[i, :k] for i, k in enumerate(self.keep)], 0).unsqueeze(0)             # pred_ppg's concat (:48,60)
+        src = m.pitch2source(self.pit)                                                                # the whole clip (svc_inference.py:89)
+        pieces = []
+        for (cs, ce, cso, ceo) in self.plan:
+            n = ce - cs
+            lengths = torch.full((1,), n, dtype=torch.int32, device=self.device)
+            o = m.inference_ppg50(ppg50[:, cs // 2:(ce + 1) // 2], self.vec[:, cs:ce], self.pit[:, cs:ce], self.spk, lengths,
+                                  src[:, :, cs * hop:ce * hop].contiguous())
+            pieces.append(o[0, 0, cso:ceo])
+        return torch.cat(pieces)
+
+
+WORKLOADS = {1: Workload, 2: FlowDecoderBatch, 3: ShardedUtterances, 4: LongForm}
+# per-config defaults: (batch, seconds, whisper precision, synthesizer precision)
+DEFAULTS = {1: (1, 10.0, "f32", "f32"), 2: (16, 10.0, None, "bf16"), 3: (16, 10.0, "f32", "f32"), 4: (1, 30.0, "f16", "f32")}
+
+
+def build_graph(fn, warm=2):
+    """Capture ``fn`` into a HIP graph (torch.cuda.CUDAGraph captures the ctypes launches made on its capture stream).
+    Returns (graph, output) or (None, None) if capture is not possible."""
     try:
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(warm):
-                wl.step()
+                fn()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            out = wl.step()
+            out = fn()
         g.replay()
         torch.cuda.synchronize()
         return g, out
@@ -97,15 +238,15 @@ def build_graph(wl, warm=2):
         return None, None
 
 
-def roofline_pass(wl):
+def roofline_pass(wl, fn):
     """Instrumented pass: every launch bracketed by HIP events on the launch stream.  A spin kernel is queued
     first so the host runs ahead and the device executes the launches back-to-back (no host-induced gaps)."""
     ops = wl.ops
-    wl.step()
+    fn()
     torch.cuda.synchronize()
     ops.timeline = []
     torch.cuda._sleep(int(2.0e8))        # ~0.1 s of device spin
-    wl.step()
+    fn()
     torch.cuda.synchronize()
     tl, ops.timeline = ops.timeline, None
     agg = {}
@@ -122,7 +263,6 @@ def measured_traffic(kernel="conv_gemm_kernel"):
     """HBM bytes per launch of the dominant kernel from the newest committed PMC summary (profiles/r*_traffic.json,
     made by scripts/pmc_traffic.sh + scripts/traffic_summary.py: rocprofv3 cannot be driven from inside this
     process).  Returns (bytes_per_launch, source) or (None, None)."""
-    import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
     if not files:
         return None, None
@@ -133,27 +273,71 @@ def measured_traffic(kernel="conv_gemm_kernel"):
         return None, None
 
 
-def cpu_baseline(wl, wsd, vsd, hp, gpu_step):
-    """Oracle (CPU port of the reference path) on ONE clip of the same workload, on this host's cores; also the
-    parity check of the GPU path against it with identical noise."""
+def rocprof_gemm_ms_per_step(prefixes=("conv_gemm_kernel<", "conv_gemm_group_kernel<")):
+    """Summed `calls_per_step x avg_us` of the implicit-GEMM kernels in the newest committed rocprofv3 --kernel-trace --stats
+    summary of the judged configuration (profiles/r*_kernel_stats.csv, scripts/prof_summary.py).  Returns (ms, source)."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_stats.csv")))
+    if not files:
+        return None, None
+    ms = 0.0
+    try:
+        for line in open(files[-1]):
+            if line.startswith("\n") or line.startswith("# per"):
+                if ms:
+                    break
+                continue
+            if line.startswith(prefixes):
+                name, rest = line.rsplit(">", 1)
+                cols = rest.strip(",\n").split(",")            # calls, calls_per_step, total_us, avg_us, percent
+                ms += float(cols[1]) * float(cols[3]) / 1e3
+    except Exception:       # noqa: BLE001
+        return None, None
+    return (ms, os.path.relpath(files[-1], ROOT)) if ms else (None, None)
+
+
+def cpu_baseline(wl, wsd, vsd, hp):
+    """The oracle (CPU port of the reference path, reference operator sequence) on ONE clip of the configs[1] workload on this
+    host's cores.  torch's intra-op thread count is swept once on a 2 s clip of the synthesis path (10-160 channel ops
+    oversubscribe a 128-core host), then the full clip runs three times at the best count and the median is reported.  The
+    last run also serves as the parity check of the GPU path with identical noise."""
     from oracle import svc_oracle as O
+    from workload import inputs as I
     d = wl.cpu_inputs
     noise = {k: d[k][:1] for k in ("mel_noise", "rand_ini", "src_noise", "enc_noise")}
     dims = wsd["dims"]
-    t0 = time.perf_counter()
+    ncpu = os.cpu_count() or 1
+    saved_threads = torch.get_num_threads()
+    sweep = {}
+    ds = I.synth_clip(T=200, hp=hp, seed=7, B=1)
     with torch.no_grad():
-        ppg50 = O.audio_encoder(wsd["model_state_dict"], d["mel"][:1] + 0.1 * noise["mel_noise"], dims["n_audio_head"],
-                                O.whisper_kept_layers(dims))[:, :wl.keep]
-        t1 = time.perf_counter()
-        src = O.pitch2source(vsd, hp, d["pit"][:1], noise["rand_ini"], noise["src_noise"])
-        t2 = time.perf_counter()
-        ppg = ppg50.repeat_interleave(2, dim=1)          # np.repeat(ppg, 2, 0), svc_inference.py:175-177
-        wav = O.synth_inference(vsd, hp, ppg, d["vec"][:1], d["pit"][:1], d["spk"][:1], d["lengths"][:1], src, noise["enc_noise"])
-        t3 = time.perf_counter()
+        for nt in sorted({n for n in (8, 16, 32, 64, 128) if n <= ncpu} | {min(ncpu, 128)}):
+            torch.set_num_threads(nt)
+            t0 = time.perf_counter()
+            s_ = O.pitch2source(vsd, hp, ds["pit"], ds["rand_ini"], ds["src_noise"])
+            O.synth_inference(vsd, hp, ds["ppg"], ds["vec"], ds["pit"], ds["spk"], ds["lengths"], s_, ds["enc_noise"])
+            sweep[nt] = time.perf_counter() - t0
+        best = min(sweep, key=sweep.get)
+        torch.set_num_threads(best)
+        runs = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            ppg50 = O.audio_encoder(wsd["model_state_dict"], d["mel"][:1] + 0.1 * noise["mel_noise"], dims["n_audio_head"],
+                                    O.whisper_kept_layers(dims))[:, :wl.keep]
+            t1 = time.perf_counter()
+            src = O.pitch2source(vsd, hp, d["pit"][:1], noise["rand_ini"], noise["src_noise"])
+            t2 = time.perf_counter()
+            ppg = ppg50.repeat_interleave(2, dim=1)          # np.repeat(ppg, 2, 0), svc_inference.py:175-177
+            wav = O.synth_inference(vsd, hp, ppg, d["vec"][:1], d["pit"][:1], d["spk"][:1], d["lengths"][:1], src, noise["enc_noise"])
+            t3 = time.perf_counter()
+            runs.append((t3 - t0, t1 - t0, t2 - t1, t3 - t2))
+    torch.set_num_threads(saved_threads)
+    runs.sort()
+    tot, tw, tp, ti = runs[1]
     secs = wl.T / 100.0
-    info = {"value": round(secs / (t3 - t0), 3), "unit": "audio-seconds/sec", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": f"1 clip x {secs:g} s, oracle (torch CPU fp32): whisper {t1 - t0:.2f}s + pitch2source {t2 - t1:.2f}s + inference {t3 - t2:.2f}s"}
+    info = {"value": round(secs / tot, 3), "unit": "audio-seconds/sec", "cores": best, "kind": "port",
+            "sample": (f"1 clip x {secs:g} s, oracle (torch CPU fp32, reference operator sequence), median of 3 at {best} threads of {ncpu} logical CPUs: "
+                       f"whisper {tw:.2f}s + pitch2source {tp:.2f}s + inference {ti:.2f}s; runs {[round(r[0], 2) for r in runs]} s; "
+                       f"thread sweep on a 2 s synthesis clip {{{', '.join(f'{k}: {v:.2f}s' for k, v in sorted(sweep.items()))}}}")}
     # parity of the GPU path on the same clip and the same noise
     dev_noise = {k: v.to(wl.device) for k, v in noise.items()}
     saved = (wl.mel, wl.vec, wl.pit, wl.spk, wl.lengths, wl.B)
@@ -168,19 +352,30 @@ def cpu_baseline(wl, wsd, vsd, hp, gpu_step):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1, help="clips per step per GPU (configs[1] = 1)")
-    ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20; config 3: 2)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 3; config 3: 1)")
+    ap.add_argument("--config", type=int, default=1, choices=[1, 2, 3, 4], help="BASELINE.json configs[N] (1 = the judged line)")
+    ap.add_argument("--batch", type=int, default=None, help="clips per step (config 1: 1; configs 2 / 3: 16)")
+    ap.add_argument("--seconds", type=float, default=None, help="clip length (10 s; config 4: 30 s)")
+    ap.add_argument("--utterances", type=int, default=512, help="config 3: total utterances of the job")
     ap.add_argument("--eager", action="store_true", help="do not replay a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16", "f16"],
-                    help="GEMM operand precision (fp32 accumulate in every mode); f32 is the parity default and the judged line")
+    ap.add_argument("--precision", default=None, choices=["f32", "bf16x3", "bf16", "f16"],
+                    help="GEMM operand precision of BOTH networks (fp32 accumulate in every mode).  Default per config: 1 and 3 f32 "
+                         "(the parity default, the judged line), 2 bf16 (flow + decoder), 4 f16 Whisper + f32 synthesizer")
     args = ap.parse_args()
+    d_batch, d_secs, d_wprec, d_sprec = DEFAULTS[args.config]
+    args.batch = args.batch or d_batch
+    args.seconds = args.seconds or d_secs
+    args.steps = args.steps if args.steps is not None else (2 if args.config == 3 else 20)
+    args.warmup = args.warmup if args.warmup is not None else (1 if args.config == 3 else 3)
+    wprec, sprec = (args.precision, args.precision) if args.precision else (d_wprec, d_sprec)
+    norm = lambda p: None if p in (None, "f32") else p
 
     from workload import config as C, weights as W      # synthetic checkpoint factory + base.yaml values
-    from svcmi import Ops, dist as D
+    from svcmi import Ops, SynthesizerInfer, dist as D, weights as PW
+    from svcmi.whisper.inference import WhisperEncoderModel
     import torch.distributed as dist
 
     rank, local_rank, world = D.init_from_env()
@@ -190,26 +385,43 @@ def main():
     torch.cuda.set_device(device)
     ops = Ops()
     hp = C.base_hp()
+    need_whisper = args.config != 2
 
-    # weights: rank 0 makes the seeded checkpoints, everyone receives them through one RCCL broadcast
+    # weights: rank 0 makes the seeded checkpoints and PACKS them (weight-norm folded, GEMM layouts); every rank receives
+    # the packed arena through one RCCL broadcast per model and only takes views of it
     t0 = time.perf_counter()
+    wsd_cpu = vsd_cpu = vw = ww = None
     if rank == 0:
-        wck = W.make_whisper_state(C.WHISPER_LARGE_V2)
-        vsd = W.make_vits_state(hp, seed=1234)
-        wsd_cpu, vsd_cpu = wck, vsd
-    else:
-        wck = {"dims": dict(C.WHISPER_LARGE_V2), "model_state_dict": None}
-        vsd = None
+        vsd_cpu = W.make_vits_state(hp, seed=1234)
+        vw = PW.VitsWeights(vsd_cpu, hp, device)
+        if need_whisper:
+            wsd_cpu = W.make_whisper_state(C.WHISPER_LARGE_V2)
+            ww = PW.WhisperWeights(wsd_cpu, device)
+    t1 = time.perf_counter()
     if world > 1:
-        wck = {"dims": wck["dims"], "model_state_dict": D.broadcast_state_dict(wck["model_state_dict"], 0, device)}
-        vsd = D.broadcast_state_dict(vsd, 0, device)
+        vw = D.broadcast_packed(vw, 0, device)
+        if need_whisper:
+            ww = D.broadcast_packed(ww, 0, device)
         torch.cuda.synchronize()
-    log(f"[rank {rank}] weights ready in {time.perf_counter() - t0:.1f}s")
-    prec = None if args.precision == "f32" else args.precision
-    wl = Workload(ops, device, args.batch, args.seconds, wck, vsd, hp, seed=100 + rank, precision=prec)
+    log(f"[rank {rank}] weights ready in {time.perf_counter() - t0:.1f}s (pack {t1 - t0:.1f}s on rank 0, broadcast {time.perf_counter() - t1:.1f}s)")
+    model = SynthesizerInfer(hp.data.filter_length // 2 + 1, hp.data.segment_size // hp.data.hop_length, hp, ops=ops).load_packed(vw, device)
+    model.precision = norm(sprec)
+    whisper = None
+    if need_whisper:
+        whisper = WhisperEncoderModel(None, device, ops=ops, packed=ww)
+        whisper.encoder.precision = norm(wprec)
+    wl = WORKLOADS[args.config](ops, device, whisper, model, hp, args, rank, world)
 
-    graph, gout = (None, None) if args.eager else build_graph(wl)
-    run = (lambda: graph.replay()) if graph is not None else (lambda: wl.step())
+    graph = None
+    if not args.eager:
+        if args.config == 3:            # the per-batch pipeline is the graph; the shard loop around it stays on the host
+            g1, gout = build_graph(wl.one_batch)
+            if g1 is not None:
+                wl.graph_one_batch = lambda: (g1.replay(), gout)[1]
+                graph = g1
+        else:
+            graph, gout = build_graph(wl.step)
+    run = (lambda: graph.replay()) if (graph is not None and args.config != 3) else (lambda: wl.step())
     for _ in range(args.warmup):
         run()
     torch.cuda.synchronize()
@@ -229,48 +441,64 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1000.0 * elapsed / args.steps
-    audio_s = args.batch * args.seconds * world
+    audio_s = wl.total_audio_seconds if wl.scaling == "strong" else wl.audio_seconds_per_step * world
     value = audio_s / (ms_per_step / 1000.0)
+    prec_txt = ", ".join(f"{n} {'fp32' if norm(p) is None else p + ' GEMM operands / fp32 accumulate'}"
+                         for n, p in (("Whisper", wprec), ("synthesizer", sprec)) if not (n == "Whisper" and not need_whisper))
+    dtype = (norm(sprec) or "f32") if (not need_whisper or norm(wprec) == norm(sprec)) else f"{norm(wprec) or 'f32'} (Whisper) + {norm(sprec) or 'f32'} (synthesizer)"
 
     out = {
         "metric": "audio-seconds/sec end-to-end SVC @32kHz, 10s clips (Whisper-PPG -> flow -> NSF-BigVGAN)",
         "value": round(value, 2), "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.precision, "data": "synthetic (seeded mel/vec/F0/speaker, random-init weights of the named architecture)",
-        "config": {"workload": f"configs[1]: batch={args.batch} x {args.seconds:g}s clip per GPU, whisper-large-v2 dims "
-                               f"(24 of 32 encoder blocks) + base.yaml prior/flow/NSF-BigVGAN, {'fp32' if prec is None else prec + ' GEMM operands / fp32 accumulate'}",
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": wl.scaling, "vs_baseline": None,
+        "dtype": dtype, "data": "synthetic (seeded mel/vec/F0/speaker, random-init weights of the named architecture)",
+        "config": {"workload": f"{wl.workload}; {prec_txt}",
                    "launch": "hipGraph replay" if graph is not None else "eager",
                    "per_gpu_value": round(value / world, 2), "realtime_factor": round(value / world, 2)},
     }
     if rank == 0 and not args.no_roofline:
-        agg = roofline_pass(wl)
+        fn = wl.one_batch if args.config == 3 else wl.step
+        agg = roofline_pass(wl, fn)
         total_ms = sum(a["ms"] for a in agg.values())
-        # the dominant kernel family: the implicit-GEMM body, single + grouped launches (3 convolutions per grid); in a
-        # reduced-precision run its 16-bit instantiations (the few GEMMs that stay fp32 there are reported in kernel_time_ms)
-        fam = ("svcmi_conv_gemm_f32", "svcmi_conv_gemm_group_f32") if prec is None else ("svcmi_conv_gemm_lp", "svcmi_conv_gemm_group_lp")
-        gm = {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0}
-        for name in fam:
-            for k, v in agg.get(name, {}).items():
-                gm[k] += v
-        mults = {None: 1.0, "bf16x3": 3.0}.get(prec, 1.0)        # MFMA work actually issued per algorithmic FLOP
-        peak = FP32_MFMA_PEAK_TFLOPS if prec is None else BF16_MFMA_PEAK_TFLOPS
+        # the dominant kernel family: the implicit-GEMM body, single + grouped launches (3 convolutions per grid), fp32 and
+        # 16-bit-operand instantiations; `peak` is the fp32 matrix peak unless every GEMM FLOP of the step ran on 16-bit operands
+        fams = {"f32": ("svcmi_conv_gemm_f32", "svcmi_conv_gemm_group_f32"), "lp": ("svcmi_conv_gemm_lp", "svcmi_conv_gemm_group_lp")}
+        part = {}
+        for key, names in fams.items():
+            gm = {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0}
+            for name in names:
+                for k, v in agg.get(name, {}).items():
+                    gm[k] += v
+            part[key] = gm
+        dom = "lp" if part["lp"]["flops"] > part["f32"]["flops"] else "f32"
+        gm = part[dom]
+        lp_prec = norm(sprec) if not need_whisper else (norm(wprec) or norm(sprec))
+        mults = 3.0 if (dom == "lp" and lp_prec == "bf16x3") else 1.0        # MFMA work actually issued per algorithmic FLOP
+        peak = FP32_MFMA_PEAK_TFLOPS if dom == "f32" else BF16_MFMA_PEAK_TFLOPS
         ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
-        traffic, traffic_src = measured_traffic() if prec is None else (None, None)
-        out["roofline"] = {"kernel": "conv_gemm_kernel + conv_gemm_group_kernel (" + " / ".join(fam) + ")", "bound": "mfma", "achieved": round(ach, 2),
-                           "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                           "mfma_issue_frac": round(mults * ach / peak, 4),
+        traffic, traffic_src = measured_traffic() if (dom == "f32" and args.config == 1) else (None, None)
+        out["roofline"] = {"kernel": "conv_gemm_kernel + conv_gemm_group_kernel (" + " / ".join(fams[dom]) + ")", "bound": "mfma",
+                           "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                           "timing": "HIP events on the launch stream around every launch of one instrumented step (includes inter-launch gaps)",
                            "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
                            "traffic_source": traffic_src, "launches_per_step": gm["launches"],
                            "avg_launch_us": round(1000.0 * gm["ms"] / gm["launches"], 2),
                            "algorithmic_gflop_per_step": round(gm["flops"] / 1e9, 1),
                            "algorithmic_bytes_per_launch": int(gm["bytes"] / gm["launches"]),
                            "share_of_step_kernel_time": round(gm["ms"] / total_ms, 3)}
+        if mults != 1.0:
+            out["roofline"]["mfma_issue_frac"] = round(mults * ach / peak, 4)
+        if dom == "f32" and args.config == 1 and args.batch == 1 and args.seconds == 10.0:
+            rp_ms, rp_src = rocprof_gemm_ms_per_step()
+            if rp_ms:
+                out["roofline"]["frac_rocprof"] = round(gm["flops"] / (rp_ms * 1e-3) / 1e12 / peak, 4)
+                out["roofline"]["frac_rocprof_source"] = f"{rp_src}: sum(calls_per_step x avg_us) of conv_gemm_kernel* = {rp_ms:.3f} ms per step"
         out["kernel_time_ms"] = {k.replace("svcmi_", ""): round(v["ms"], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
         sn = agg.get("svcmi_snake_alias_f32")
         if sn:
             out["snake_alias_GBs"] = round(sn["bytes"] / (sn["ms"] * 1e-3) / 1e9, 1)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        info, err = cpu_baseline(wl, wsd_cpu, vsd_cpu, hp, run)
+    if rank == 0 and world == 1 and args.config == 1 and not args.no_cpu_baseline:
+        info, err = cpu_baseline(wl, wsd_cpu, vsd_cpu, hp)
         out["cpu_baseline"] = info
         out["parity_max_abs_vs_oracle"] = err
     if rank == 0:

@@ -157,6 +157,21 @@ def flow_reverse(sd, z, mask, spk):
 
 # ----------------------------------------------------------------------------- generator
 def snake_alias(x, alpha_log, beta_log, filt):
+    """vits_decoder/alias/act.py:124-129 with the reference's own operator sequence, so that the CPU baseline costs what
+    the reference costs: UpSample1d (resample.py:25-33: replicate-pad 5, depthwise conv_transpose1d stride 2, x2, crop
+    15 / 15) -> SnakeBeta (act.py:79-92, log-scale alpha / beta) -> LowPassFilter1d with stride 2 (filter.py:86-95:
+    replicate-pad 5 / 6, depthwise conv1d).  ``snake_alias_polyphase`` is the same function in the gather form of
+    SURVEY.md A.5 (the form the kernels implement); tests/test_oracle_golden.py checks the two against each other."""
+    Cc = x.shape[1]
+    f = filt.view(1, 1, -1).expand(Cc, -1, -1)
+    up = 2.0 * F.conv_transpose1d(F.pad(x, (5, 5), mode="replicate"), f, stride=2, groups=Cc)[..., 15:-15]
+    a = torch.exp(alpha_log).view(1, -1, 1)
+    b = torch.exp(beta_log).view(1, -1, 1)
+    s = up + (1.0 / (b + 1e-9)) * torch.pow(torch.sin(up * a), 2)
+    return F.conv1d(F.pad(s, (5, 6), mode="replicate"), f, stride=2, groups=Cc)
+
+
+def snake_alias_polyphase(x, alpha_log, beta_log, filt):
     """vits_decoder/alias/act.py:124-129 in the polyphase form of SURVEY.md A.5:
     2x Kaiser-sinc upsample (resample.py:25-33) -> SnakeBeta (act.py:79-92) -> 2x low-pass
     decimation (filter.py:86-95), replicate padding at the SEQUENCE ends."""

@@ -121,3 +121,77 @@ def test_folder_conversion_shards_files_over_ranks(tmp_path):
         for f in res[r]:
             sr, x = read(tmp_path / "_svc_out" / f)
             assert sr == 32000 and len(x) == sizes[f] and float(x[0]) == float(r)
+
+
+# ---------------------------------------------------------------------------------------------- packed arena + configs[3] plan
+def _packed_worker(rank, world, port, q):
+    """BASELINE.json configs[3] on a stub: rank 0 packs the (tiny) synthesizer weights, ONE broadcast ships the arena, every
+    rank rebuilds the weight object from views (no folding / packing on ranks != 0), then converts its shard of the 512
+    utterances in batches of 16 with a stand-in for the GPU pipeline."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    D.init_from_env(backend="gloo")
+    from svcmi import weights as PW
+    from workload import config as C, weights as W
+    hp = C.tiny_hp()
+    w = PW.VitsWeights(W.make_vits_state(hp, seed=1234), hp, "cpu") if rank == 0 else None
+    got = D.broadcast_packed(w, src=0, device="cpu")
+    assert type(got).__name__ == "VitsWeights" and got.hop == 320 and len(got.flow) == 4 and len(got.stages) == 5
+    tensors = []
+
+    def walk(o):
+        if isinstance(o, torch.Tensor):
+            tensors.append(o)
+        elif isinstance(o, dict):
+            [walk(v) for v in o.values()]
+        elif isinstance(o, (list, tuple)):
+            [walk(v) for v in o]
+        elif hasattr(o, "__dict__"):
+            [walk(v) for v in o.__dict__.values()]
+    walk(got)
+    assert all(t.data_ptr() % 16 == 0 for t in tensors)          # kernel operands need 16-byte alignment
+    digest = float(sum(t.double().abs().sum() + 0.5 * t.double().sum() for t in tensors))
+    batches = D.plan_batches(512, world, rank, 16)
+    done = [i for b in batches for i in b]                        # the stub "conversion": record which utterances ran here
+    q.put((rank, len(tensors), digest, [len(b) for b in batches], done))
+    torch.distributed.destroy_process_group()
+
+
+def test_packed_arena_broadcast_and_config3_plan_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_packed_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, n0, d0, b0, done0), (_, n1, d1, b1, done1) = res
+    assert n0 == n1 > 500 and d0 == d1                           # every rank holds bit-identical packed weights
+    assert b0 == b1 == [16] * 16                                  # 512 utterances -> 256 per rank -> 16 batches of 16
+    assert sorted(done0 + done1) == list(range(512))              # every utterance exactly once
+
+
+def test_config3_plan_matches_baseline_numbers():
+    for world in (1, 2, 4, 8):
+        plans = [D.plan_batches(512, world, r, 16) for r in range(world)]
+        assert sorted(i for p in plans for b in p for i in b) == list(range(512))
+        assert all(sum(len(b) for b in p) == 512 // world for p in plans)       # 64 per GPU at 8 (BASELINE.json configs[3])
+    assert [len(b) for b in D.plan_batches(40, 1, 0, 16)] == [16, 16, 8]          # a short tail batch
+
+
+def test_pack_arena_round_trip_single_process():
+    from svcmi import weights as PW
+    from workload import config as C, weights as W
+    ck = W.make_whisper_state(C.WHISPER_TINY_TEST)
+    w = PW.WhisperWeights(ck, "cpu")
+    skel, arena = D.pack_arena(w)
+    import pickle
+    w2 = D.unpack_arena(pickle.loads(pickle.dumps(skel)), arena)
+    assert w2.S == w.S and w2.heads == w.heads and len(w2.blocks) == len(w.blocks)
+    for a, b in zip(w.blocks, w2.blocks):
+        for k in a:
+            assert torch.equal(a[k], b[k]) and b[k].data_ptr() % 16 == 0
+    assert torch.equal(w.pos, w2.pos) and torch.equal(w.conv2_w, w2.conv2_w)
+    assert D.broadcast_packed(w) is w                             # world size 1: identity

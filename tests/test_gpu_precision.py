@@ -7,7 +7,7 @@ library's parity default and the 16-bit modes are opt-in.  What is asserted, on 
     flow + decoder from pre-extracted PPG/F0) and on a 15 s Whisper window (Tw = 750);
   * plain bf16 / f16 errors are MEASURED, printed and bounded (they exceed 1e-3, as SURVEY.md section 0 predicted:
     random-init weights amplify an 8/11-bit operand rounding through 24 + 6 + 16 + 90 layers).
-Error bounds of the plain modes are ~3x what was measured on MI355X (profiles/r02_precision.json holds the numbers).
+Error bounds of the plain modes are ~4x what was measured on MI355X (profiles/r02b_precision_report.json holds the numbers).
 """
 import json
 import os
@@ -25,8 +25,10 @@ pytestmark = pytest.mark.gpu
 
 MODES = ("bf16x3", "bf16", "f16")
 # max-abs bounds: waveform in [-1, 1] (rms ~0.1 with these weights); PPG relative to its max |value|
-WAVE_BOUND = {"bf16x3": E.WAVE_TOL, "bf16": 0.6, "f16": 0.3}
-PPG_REL_BOUND = {"bf16x3": 1e-4, "bf16": 0.08, "f16": 0.02}
+# measured on MI355X (profiles/r02b_precision_report.json): waveform bf16x3 1.3e-5 / 1.7e-5, f16 0.99e-3 / 1.0e-3, bf16 7.3e-3 / 7.9e-3
+# (configs[1] / configs[2]); PPG relative error bf16x3 9e-6, f16 6.9e-4, bf16 5.8e-3
+WAVE_BOUND = {"bf16x3": E.WAVE_TOL, "bf16": 3e-2, "f16": 4e-3}
+PPG_REL_BOUND = {"bf16x3": 1e-4, "bf16": 2e-2, "f16": 3e-3}
 REPORT = {}
 
 

@@ -59,6 +59,105 @@ def broadcast_state_dict(sd, src=0, device="cpu", group=None):
     return out
 
 
+class _Ref:
+    """Placeholder of one tensor inside a packed-weights skeleton: (offset, shape) into the flat fp32 arena."""
+    __slots__ = ("off", "shape")
+
+    def __init__(self, off, shape):
+        self.off, self.shape = off, shape
+
+
+ARENA_ALIGN = 64        # floats: every tensor of the arena starts 256-byte aligned (the kernels need 16 bytes)
+
+
+def _skeleton(obj, tensors, total):
+    """Copy of a container tree (dicts, lists, tuples, plain objects) with every fp32 tensor replaced by a _Ref; the tensors
+    are appended to ``tensors`` in traversal order.  Non-fp32 tensors and Python scalars travel inside the skeleton."""
+    import copy
+    if isinstance(obj, torch.Tensor):
+        if obj.dtype != torch.float32:
+            return obj.detach().cpu()
+        off = (total[0] + ARENA_ALIGN - 1) // ARENA_ALIGN * ARENA_ALIGN
+        total[0] = off + obj.numel()
+        tensors.append((off, obj))
+        return _Ref(off, tuple(obj.shape))
+    if isinstance(obj, dict):
+        out = obj.__class__.__new__(obj.__class__)
+        dict.update(out, {k: _skeleton(v, tensors, total) for k, v in obj.items()})
+        return out
+    if isinstance(obj, (list, tuple)):
+        return obj.__class__(_skeleton(v, tensors, total) for v in obj)
+    if hasattr(obj, "__dict__") and not callable(obj):
+        out = copy.copy(obj)
+        out.__dict__ = {k: _skeleton(v, tensors, total) for k, v in obj.__dict__.items()}
+        return out
+    return obj
+
+
+def _materialise(obj, arena):
+    if isinstance(obj, _Ref):
+        n = int(torch.Size(obj.shape).numel())
+        return arena[obj.off:obj.off + n].view(obj.shape)
+    if isinstance(obj, torch.Tensor):
+        return obj.to(arena.device)
+    if isinstance(obj, dict):
+        for k in list(obj.keys()):
+            dict.__setitem__(obj, k, _materialise(dict.__getitem__(obj, k), arena))
+        return obj
+    if isinstance(obj, (list, tuple)):
+        return obj.__class__(_materialise(v, arena) for v in obj)
+    if hasattr(obj, "__dict__") and not callable(obj):
+        obj.__dict__ = {k: _materialise(v, arena) for k, v in obj.__dict__.items()}
+        return obj
+    return obj
+
+
+def pack_arena(weights, device=None):
+    """Kernel-ready weights (svcmi.weights.VitsWeights / WhisperWeights / ...: nested containers of PACKED fp32 tensors) ->
+    (skeleton, flat fp32 arena).  The arena is what SURVEY.md 8e broadcasts: weight-norm already folded, GEMM layouts already
+    made, so a receiving rank does no folding or packing -- it only takes views (``unpack_arena``)."""
+    tensors, total = [], [0]
+    skel = _skeleton(weights, tensors, total)
+    dev = device if device is not None else (tensors[0][1].device if tensors else "cpu")
+    arena = torch.zeros(max(total[0], 1), dtype=torch.float32, device=dev)
+    for off, t in tensors:
+        arena[off:off + t.numel()].copy_(t.detach().reshape(-1))
+    return skel, arena
+
+
+def unpack_arena(skel, arena):
+    """Rebuild the weight object around views of ``arena`` (in place in the skeleton)."""
+    return _materialise(skel, arena)
+
+
+def broadcast_packed(weights, src=0, device="cpu", group=None):
+    """ONE collective for a whole model: rank ``src`` passes its packed weight object, the others ``None``; everybody gets
+    back an equivalent object whose tensors are views of one flat arena on ``device`` (a single large RCCL broadcast over
+    xGMI; the small skeleton travels as a pickled object).  World size 1: the object is returned unchanged."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return weights
+    rank = dist.get_rank(group)
+    if rank == src:
+        skel, arena = pack_arena(weights, device)
+        meta = [(skel, arena.numel())]
+    else:
+        meta = [None]
+    dist.broadcast_object_list(meta, src=src, group=group)
+    skel, n = meta[0]
+    if rank != src:
+        arena = torch.empty(n, dtype=torch.float32, device=device)
+    dist.broadcast(arena, src=src, group=group)
+    return unpack_arena(skel, arena)
+
+
+def plan_batches(n_utterances, world, rank, batch):
+    """BASELINE.json configs[3]: ``n_utterances`` equal-length clips sharded over ``world`` ranks (LPT on equal costs = an even
+    split, 512 -> 64 per GPU at 8), this rank's share cut into batches of ``batch`` (the last one may be short).
+    Returns a list of utterance-id lists."""
+    mine = shard_utterances([1] * n_utterances, world)[rank]
+    return [mine[i:i + batch] for i in range(0, len(mine), batch)]
+
+
 def arena_checksum(sd):
     """fp64 digest used by the tests to check every rank holds the same weights."""
     return float(sum(v.double().sum().item() + v.double().abs().sum().item() for v in sd.values()))

@@ -87,6 +87,12 @@ class SynthesizerInfer:
     def parameters(self):
         return iter(self.state_dict().values())
 
+    def load_packed(self, weights, device):
+        """Adopt kernel-ready weights (a ``svcmi.weights.VitsWeights`` whose tensors live on ``device``, e.g. the views of
+        the arena ``svcmi.dist.broadcast_packed`` delivered): no folding / packing happens on this rank."""
+        self._w, self._device = weights, torch.device(device)
+        return self
+
     def _weights(self):
         if self._w is None:
             dev = self._device or torch.device("cuda" if self.ops.on_gpu else "cpu")

@@ -75,9 +75,11 @@ class WhisperEncoderModel:
     """What ``load_model`` returns: the reference returns a ``Whisper`` whose decoder was deleted; callers
     only touch ``.encoder`` (whisper/inference.py:47,59)."""
 
-    def __init__(self, ckpt, device, ops=None):
+    def __init__(self, ckpt, device, ops=None, packed=None):
+        """``packed``: an already packed ``svcmi.weights.WhisperWeights`` on ``device`` (``svcmi.dist.broadcast_packed``);
+        ``ckpt`` is then ignored."""
         self.ops = ops if ops is not None else Ops()
-        self.weights = PW.WhisperWeights(ckpt, device)
+        self.weights = packed if packed is not None else PW.WhisperWeights(ckpt, device)
         self.dims = self.weights.dims
         self.encoder = AudioEncoder(self.weights, self.ops)
         self.device = torch.device(device)
