@@ -337,3 +337,27 @@ def stress_floor(sd, hp, d, lens, o_src, o_wav, wav):
     floor = float((o_wav.double() - o64).abs().max())
     assert floor <= 3e-4, f"stress set is ill-conditioned: fp32 vs fp64 oracle {floor:.2e}"
     return dict(oracle_fp32_vs_fp64=floor, wave_vs_fp64=float((wav.detach().cpu().double() - o64).abs().max()))
+
+
+def check_streaming_decoder(ops, device, hp, T, tiles, B=1, seed=41):
+    """In-chunk time tiling of the generator (SynthesizerInfer.stream_frames, BASELINE.json configs[4]): every tile size
+    gives the SAME BITS (halo 32 frames >= the exact receptive field of 30.9 frames, position-independent kernel arithmetic, split-K pinned off), a
+    single tile covering the chunk is the untiled network, and the result stays at fp32 round-off from the default path
+    (which lets the library pick split-K).  Returns the max difference to the default path."""
+    m, sd = make_model(hp, ops, device)
+    d = I.synth_clip(T=T, hp=hp, seed=seed, B=B)
+    src = m.pitch2source(d["pit"], noise=(d["rand_ini"], d["src_noise"]))
+    run = lambda: m.inference(d["ppg"], d["vec"], d["pit"], d["spk"], d["lengths"], src, noise=d["enc_noise"]).clone()
+    base = run()
+    m.stream_frames = 10 * T                 # one tile: the untiled generator with split-K off
+    whole = run()
+    outs = []
+    for S in tiles:
+        m.stream_frames = S
+        outs.append(run())
+    m.stream_frames = None
+    for S, o in zip(tiles, outs):
+        assert torch.equal(o, whole), (S, float((o - whole).abs().max()))
+    err = maxerr(whole, base)
+    assert err <= 1e-5, err
+    return err

@@ -176,6 +176,33 @@ def test_30s_clip_second_chunk_against_oracle(ops):
     assert err <= E.WAVE_TOL
 
 
+def test_streaming_decoder_is_bit_identical_and_matches_oracle_on_30s_chunk(ops):
+    """configs[4]: the time-tiled ("streaming") generator inside the reference chunks of a 30 s clip.  Tiles of 256 / 500 / 1000
+    frames reproduce the untiled generator bit for bit at base.yaml widths (B = 2, T = 1300), and the second chunk of the 30 s
+    clip run through svc_infer WITH tiling matches the oracle like the untiled path does."""
+    from svcmi import DummyRetrieval, svc_infer
+    hp = C.base_hp()
+    print("tiled vs default path:", E.check_streaming_decoder(ops, "cuda", hp, T=1300, tiles=(256, 500, 1000), B=2))
+    m, sd = E.make_model(hp, ops, "cuda")
+    T, hop = 3000, 320
+    d = I.synth_clip(T=T, hp=hp, seed=31, B=1)
+    plan = O.chunk_schedule(T, hop)
+    gen = torch.Generator().manual_seed(3)
+    enc_noises = [torch.randn(1, hp.vits.inter_channels, ce - cs, generator=gen) for (cs, ce, _, _) in plan]
+    m.stream_frames = 512
+    wav = svc_infer(m, DummyRetrieval(), d["spk"][0], d["pit"][0], d["ppg"][0], d["vec"][0], hp, "cuda",
+                    noise={"rand_ini": d["rand_ini"], "src_noise": d["src_noise"], "enc_noises": enc_noises}, write_pit_wav=False)
+    m.stream_frames = None
+    cs, ce, cso, ceo = plan[1]
+    with torch.no_grad():
+        o_src = O.pitch2source(sd, hp, d["pit"], d["rand_ini"], d["src_noise"])
+        o = O.synth_inference(sd, hp, d["ppg"][:, cs:ce], d["vec"][:, cs:ce], d["pit"][:, cs:ce], d["spk"],
+                              torch.tensor([ce - cs]), o_src[:, :, cs * hop:ce * hop], enc_noises[1])
+    err = float(np.abs(wav[2500 * hop:] - o[0, 0, cso:ceo].numpy()).max())
+    print(f"30 s clip, streaming decoder (512-frame tiles), chunk 2 vs oracle: err {err:.2e}")
+    assert wav.shape[0] == T * hop - 1 and err <= E.WAVE_TOL
+
+
 def test_run_to_run_bit_equality(ops):
     """No atomics in any reduction: identical launches give identical bits (cheap race detector)."""
     hp = C.tiny_hp()

@@ -34,6 +34,13 @@ class SynthesizerInfer:
         # GEMM operand precision of prior encoder / flow / generator: None = fp32 (parity default), "bf16x3" / "bf16" /
         # "f16" (Ops.use_precision).  Element-wise kernels, softmax, LayerNorm, SnakeAlias and accumulation stay fp32.
         self.precision = None
+        # Streaming decoder (BASELINE.json configs[4]): None = the generator sees a whole synthesis chunk;
+        # N = it runs over time tiles of N frames plus a STREAM_HALO-frame halo on each side that is computed and discarded.
+        # The generator's exact receptive field is < 31 frames (see STREAM_HALO) and every kernel's arithmetic for an output row is
+        # independent of the row's position in a launch, so the kept samples are BIT-IDENTICAL for every N (split-K is pinned
+        # off in this mode: its slice count would otherwise follow the problem size).  The reference's own chunk seams
+        # (svc_inference.py:94-131) are untouched: tiling happens inside a chunk.
+        self.stream_frames = None
         self._streams, self._streams_dev = None, None
 
     # ------------------------------------------------------------------ nn.Module-like surface
@@ -298,13 +305,34 @@ class SynthesizerInfer:
         ops.block_mean(xc, out=acc)
         return True
 
+    # Halo of the streaming decoder, in frames.  SURVEY.md A.4 measured an EFFECTIVE receptive field of -23.3 .. +23.7 frames
+    # (fp64 perturbation test); the exact support of the FIR chain is wider, because the Kaiser tails it ignores are ~1e-3:
+    # per side, in output samples: conv_pre 3 frames = 960; ups 480 + 64 + 16 + 4 + 2; an AMP block with k = 11 adds
+    # (5 + 15 + 25) + 3 * 5 + 6 * 6 = 96 samples at its stage's rate = 96 * (64 + 16 + 4 + 2 + 1) = 8352; output layer 9:
+    # 9887 samples = 30.9 frames.  24 frames left a 9e-8 leak (measured, MI355X); 32 makes tiling bit-exact.
+    STREAM_HALO = 32
+
     def _generator(self, w, ops, z, spk, source):
+        """The generator over a whole chunk, or -- with ``stream_frames`` -- over time tiles with a discarded halo."""
+        S, H = self.stream_frames, self.STREAM_HALO
+        if not S:
+            return self._generator_tile(w, ops, z, spk, source, 0)
+        B, T, _ = z.shape
+        hop = w.hop
+        out = torch.empty(B, 1, T * hop, dtype=torch.float32, device=z.device)
+        for t0 in range(0, T, S):
+            a, b, n = max(0, t0 - H), min(T, t0 + S + H), min(S, T - t0)
+            o = self._generator_tile(w, ops, z[:, a:b].contiguous(), spk, source[:, a * hop:b * hop].contiguous(), 1)
+            out[:, :, t0 * hop:(t0 + n) * hop] = o[:, :, (t0 - a) * hop:(t0 - a + n) * hop]
+        return out
+
+    def _generator_tile(self, w, ops, z, spk, source, split_k):
         """Generator.inference, vits_decoder/generator.py:175-200 (+ SpeakerAdapter :36-47, AMPBlock bigv.py:50-58).
-        z [B,T,U] time-major, source [B, hop*T] -> [B,1,hop*T]."""
+        z [B,T,U] time-major, source [B, hop*T] -> [B,1,hop*T].  ``split_k``: 0 = library heuristic, 1 = off (streaming)."""
         B, T, U = z.shape
         sb = ops.conv(spk.view(B, 1, -1), w.ad_w, w.ad_b).view(B, 2 * U)
         x = ops.layernorm(z, sb[:, :U], sb[:, U:], per_batch_affine=True)
-        x = ops.conv(x, w.pre_conv_w, w.pre_conv_b, ksize=7, pad=3, act=ACT_MISH)
+        x = ops.conv(x, w.pre_conv_w, w.pre_conv_b, ksize=7, pad=3, act=ACT_MISH, split_k=split_k)
         if self._stop_after == "gen_pre":
             return x
         for st in w.stages:
@@ -314,15 +342,15 @@ class SynthesizerInfer:
                 # stream -- one VALU kernel instead of padded GEMM launches (105 / 63 us for < 0.1 GFLOP)
                 fuse_up = st["cp"] <= 12
                 y = None if fuse_up else ops.conv(x, st["up_w"], st["up_b"], ksize=st["up_taps"], pad=st["up_pad"],
-                                                  t_out=t_in).view(B, t_in * st["u"], st["cp"])
+                                                  t_out=t_in, split_k=split_k).view(B, t_in * st["u"], st["cp"])
                 y = ops.upsample_noise(x, st["up_w"], st["up_b"], st["up_taps"], st["up_pad"], st["u"], st["cp"], source,
                                        st["nz_w"], st["nz_b"], st["nz_k"], st["nz_stride"], st["nz_pad"], y=y)
             else:
-                y = ops.conv(x, st["up_w"], st["up_b"], ksize=st["up_taps"], pad=st["up_pad"], t_out=t_in)
+                y = ops.conv(x, st["up_w"], st["up_b"], ksize=st["up_taps"], pad=st["up_pad"], t_out=t_in, split_k=split_k)
                 y = y.view(B, t_in * st["u"], st["cp"])
                 ops.conv(source, st["nz_w"], st["nz_b"], ksize=st["nz_k"], stride=st["nz_stride"], pad=st["nz_pad"],
                          c_in=1, ldx=1, t_in=source.shape[1], t_out=y.shape[1], accumulate=True, out=y,
-                         x_bstride=source.stride(0))
+                         x_bstride=source.stride(0), split_k=split_k)
             acc = torch.empty_like(y)
             nb = len(st["blocks"])
             # The nb AMP blocks of a stage (generator.py:188-194) only share their input; each runs its 3 iterations as
