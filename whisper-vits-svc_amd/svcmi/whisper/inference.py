@@ -28,8 +28,12 @@ class AudioEncoder:
         # own accelerator path is fp16: whisper/inference.py:22-23,43-44) route the linear layers through
         # svcmi_conv_gemm_lp.  LayerNorm, softmax, GELU, residual stream and accumulation stay fp32 in every mode.
         self.precision = None
+        self.small_m_rows = 1024                 # above this many GEMM rows the library's own tile heuristic takes over
         self.lp_split_o, self.lp_split_mlp = 2, 4
-        self.lp_tile_qkv = self.lp_tile_o = self.lp_tile_mlp1 = self.lp_tile_mlp2 = 0      # 0 = library heuristic
+        # measured (scripts/microbench.py lp, profiles/r02a_microbench_lp.log): the two N = n_state projections run best on 64x128
+        # tiles with 2 / 4 K slices (17 vs 22 us, 37 vs 38 us at Tw = 500); QKV / MLP-up follow the library heuristic
+        self.lp_tile_qkv = self.lp_tile_mlp1 = 0      # 0 = library heuristic
+        self.lp_tile_o = self.lp_tile_mlp2 = 9        # SVCMI_CONV_TILE_64x128 >> 8
 
     @torch.no_grad()
     def __call__(self, mel, noise=None, noise_scale=0.1):
@@ -42,6 +46,11 @@ class AudioEncoder:
         split_o, split_mlp = (self.lp_split_o, self.lp_split_mlp) if lp else (self.split_o, self.split_mlp)
         tile_qkv, tile_o, tile_m1, tile_m2 = (self.lp_tile_qkv, self.lp_tile_o, self.lp_tile_mlp1, self.lp_tile_mlp2) if lp else \
             (0, self.tile_o, self.tile_mlp, self.tile_mlp)
+        if mel.shape[0] * ((mel.shape[2] + 1) // 2) > self.small_m_rows:
+            # batched windows (BASELINE.json configs[3] / [4]): M = B * Tw rows fill the chip with large tiles; the K slices and
+            # the 64x80 tiles above are a single-window (M = 500 .. 750) tuning
+            split_o = split_mlp = 1
+            tile_qkv = tile_o = tile_m1 = tile_m2 = 0
         dev = w.lnp_g.device
         mel = mel.to(dev, torch.float32).contiguous()
         if noise is not None:
