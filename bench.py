@@ -381,7 +381,7 @@ def main():
     rank, local_rank, world = D.init_from_env()
     assert world == args.gpus or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (svcmi has no CPU path)"
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", local_rank % torch.cuda.device_count())     # (> 1 rank per device only under SVCMI_DIST_BACKEND=gloo)
     torch.cuda.set_device(device)
     ops = Ops()
     hp = C.base_hp()

@@ -22,12 +22,14 @@ def init_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
-        if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+        # SVCMI_DIST_BACKEND=gloo lets several ranks share ONE GPU (RCCL refuses duplicate devices): used to exercise the
+        # multi-rank code path of bench.py / the folder driver on a single-GPU box; production = nccl (RCCL over xGMI)
+        backend = backend or os.environ.get("SVCMI_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     elif torch.cuda.is_available():
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())
     return rank, local_rank, world
 
 
