@@ -109,6 +109,25 @@ def main():
                         us = timeit(lambda: ops.conv_group(probs))
                         print(f"group C={C} n={n} d={d} tile={tile} nst={nst}: {us:8.1f} us  {fl / us / 1e6:7.1f} TF/s", flush=True)
         ops.lib.svcmi_tune_set(b"group_nst", 0)
+    if "lpgroup" in what:     # grouped AMP-stage GEMMs with 16-bit operands: 64-row vs 128-row right-sized tiles, batch 1 and 16
+        for B in (1, 16):
+            # (128-row tiles 7 / 5 were tried for the 16-bit kernels too and lose everywhere, e.g. bf16, B = 16: 598 vs 549 us at 80
+            # channels, 1268 vs 875 us at 40 -- these launches move 0.9-1.8 GB of activations and sit at ~2 TB/s)
+            for (C, n, tls) in ((160, 5000, (0,)), (80, 20000, (6,)), (40, 80000, (4,))):
+                g = torch.Generator().manual_seed(0)
+                xs = [torch.randn(B, n, C, generator=g).cuda() for _ in range(3)]
+                rs = [torch.randn(B, n, C, generator=g).cuda() for _ in range(3)]
+                outs = [torch.empty(B, n, C, device="cuda") for _ in range(3)]
+                ws = [PW.pack_conv(torch.randn(C, C, k, generator=g) / math.sqrt(C * k)).cuda() for k in (3, 7, 11)]
+                bs = [torch.randn(C, generator=g).cuda() for _ in range(3)]
+                fl = sum(2.0 * B * n * C * C * k for k in (3, 7, 11))
+                for prec in (None, "bf16x3", "bf16"):
+                    for tile in tls:
+                        probs = [dict(x=xs[j], w=ws[j], bias=bs[j], ksize=k, dilation=3, pad=(k - 1) * 3 // 2, res=rs[j], out=outs[j],
+                                      tile=tile) for j, k in enumerate((3, 7, 11))]
+                        with ops.use_precision(prec):
+                            us = timeit(lambda: ops.conv_group(probs), iters=10, warm=2)
+                        print(f"lpgroup B={B} C={C} n={n} {prec or 'f32':6s} tile={tile}: {us:8.1f} us  {fl / us / 1e6:7.1f} TF/s", flush=True)
     if "ampgroup" in what:    # grouped fused SnakeAlias+conv half-steps of the narrow stages: time steps per thread
         filt = torch.tensor([0.00202896, 0.00938947, -0.02554346, -0.05765738, 0.12857258, 0.44320980, 0.44320980,
                              0.12857258, -0.05765738, -0.02554346, 0.00938947, 0.00202896], device="cuda")

@@ -217,6 +217,7 @@ static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((un
 static inline int svcmi_ticket(int* counter) { return (*counter)++; }   // blocks run one after another in the emulator
 static inline void svcmi_lds_read16(svcmi_f32x4& dst, const float* p, svcmi_f32x4&) { memcpy(&dst, p, 16); }
 static inline void svcmi_lds_arrive(svcmi_f32x4&) {}
+static inline void svcmi_lds_landed(svcmi_f32x4&) {}
 static inline void svcmi_pin(svcmi_f32x16&) {}
 static inline void svcmi_pin(svcmi_f32x4&) {}
 // LDS-DMA emulation (buffer form): lane l copies its 16 (4) bytes from rsrc.base + voff to lds_wave_base + 16*l

@@ -281,11 +281,12 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
         if constexpr (P16) c = svcmi_mfma_16x16x4(a, b, c);
         else c = svcmi_mfma_32x32x2(a, b, c);
     };
-    auto frags_arrive = [&](svcmi_f32x4 (&a4)[WM], svcmi_f32x4 (&b4)[WN]) {
+    auto frags_arrive = [&](svcmi_f32x4 (&a4)[WM], svcmi_f32x4 (&b4)[WN]) {      // one s_waitcnt, every fragment pinned behind it
+        svcmi_lds_arrive(a4[0]);
 #pragma unroll
-        for (int i = 0; i < WM; ++i) svcmi_lds_arrive(a4[i]);
+        for (int i = 1; i < WM; ++i) svcmi_lds_landed(a4[i]);
 #pragma unroll
-        for (int j = 0; j < WN; ++j) svcmi_lds_arrive(b4[j]);
+        for (int j = 0; j < WN; ++j) svcmi_lds_landed(b4[j]);
     };
     // Reduced precision.  Sub-step s of a K-step contracts the 16 (32x32x16: s = 0, 1) or all 32 (16x16x32) k of the step: the
     // lane reads 16-byte chunk q = 2s + (lane>>5) resp. lane>>4 of its 16-bit B row(s) and the fp32 A chunks q and q + 4.
@@ -303,12 +304,14 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
             for (int j = 0; j < WN; ++j) svcmi_lds_read16(b8[h][j], Bb + h * BTILE + j * FR * BROW + pb, tie);
     };
     auto frags_arrive_lp = [&](svcmi_f32x4 (&a8)[WM][2], svcmi_f32x4 (&b8)[NB][WN]) {
+        svcmi_lds_arrive(a8[0][0]);
+        svcmi_lds_landed(a8[0][1]);
 #pragma unroll
-        for (int i = 0; i < WM; ++i) { svcmi_lds_arrive(a8[i][0]); svcmi_lds_arrive(a8[i][1]); }
+        for (int i = 1; i < WM; ++i) { svcmi_lds_landed(a8[i][0]); svcmi_lds_landed(a8[i][1]); }
 #pragma unroll
         for (int h = 0; h < NB; ++h)
 #pragma unroll
-            for (int j = 0; j < WN; ++j) svcmi_lds_arrive(b8[h][j]);
+            for (int j = 0; j < WN; ++j) svcmi_lds_landed(b8[h][j]);
     };
     // fp32 fragment (chunks q | q+4) -> packed 16-bit operand(s): hi = round(x), lo = round(x - hi) (bf16x3 only)
     auto round_frag = [&](const svcmi_f32x4 (&r)[2], svcmi_u32x4& hi, svcmi_u32x4& lo) {

@@ -124,6 +124,9 @@ __device__ __forceinline__ void svcmi_lds_read16(svcmi_f32x4& dst, const float* 
     asm volatile("ds_read_b128 %0, %2" : "=v"(dst), "+v"(tie) : "v"(a) : "memory");
 }
 __device__ __forceinline__ void svcmi_lds_arrive(svcmi_f32x4& d) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d)::"memory"); }
+// The same ordering pin without the instruction: after ONE svcmi_lds_arrive every outstanding LDS read of the wave has landed, the
+// other fragment registers only need to be named so that no consumer floats above that wait.
+__device__ __forceinline__ void svcmi_lds_landed(svcmi_f32x4& d) { asm volatile("" : "+v"(d)::"memory"); }
 
 // Order fence for a register-only value: nothing that produces `v` is scheduled below, nothing that consumes it above.
 __device__ __forceinline__ void svcmi_pin(svcmi_f32x16& v) { asm volatile("" : "+a"(v)); }   // "a": stays in the accumulator file

@@ -39,9 +39,12 @@ class Ops:
         self.timeline = None     # set to a list to record (kernel, work, start_event, end_event) per launch
         # GEMM operand precision (include/svcmi.h: enum svcmi_precision).  fp32 is the parity default; "bf16x3" / "bf16" /
         # "f16" route every eligible convolution through svcmi_conv_gemm_lp with a 16-bit weight image packed on first use
-        # (cached on the fp32 weight tensor).  Convolutions below `lp_min_flops` stay fp32: nothing to gain there.
+        # (cached on the fp32 weight tensor).  Launches below `lp_min_flops` stay fp32: a GEMM of < ~1.5 GFLOP is latency-bound
+        # on this chip (8-17 us whatever the operand type; measured: the 75 small prior / flow GEMMs of a 10 s clip cost the same
+        # 1.35 ms through either kernel), so rounding its operands buys nothing and costs accuracy.  At batch 16 the same
+        # layers are 16x the work and cross the threshold.
         self.precision = PREC_F32
-        self.lp_min_flops = 2.0e7
+        self.lp_min_flops = 1.5e9
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
