@@ -73,6 +73,7 @@ struct ConvArgs {
     int ksize, stride, dil, pad, rshift, act, flags;
     const unsigned short* w16;   // reduced precision: 16-bit weight image, row n = [hi: ldw16 values][lo: ldw16 values, bf16x3 only]
     int ldw16;
+    int vec;                     // 1: y / res / bias / workspace rows are 16-byte aligned multiples of 4 floats -> float4 epilogue
     int ktot;                    // ksize * c_in
     int split;                   // K slices (1 = none)
     int mt, nt;                  // tile grid (time x channels)
@@ -101,6 +102,25 @@ __device__ __forceinline__ float epilogue(const ConvArgs& p, float v, float bias
     v *= p.alpha;
     if (p.flags & SVCMI_CONV_ACCUMULATE) v += *dst;
     return masked ? 0.f : v;
+}
+
+// four consecutive output channels at once: the same arithmetic per component as `epilogue`, 16-byte accesses (the scalar loop
+// spent 5-9 us of a 53-73 us Whisper launch issuing 4-byte loads and stores: scripts/microbench.py ablation)
+__device__ __forceinline__ void epilogue4(const ConvArgs& p, float4 v, const float* bias_n, const float* res_n, float* dst, bool masked) {
+    float o[4] = {v.x, v.y, v.z, v.w};
+    float bv[4] = {0.f, 0.f, 0.f, 0.f}, rv[4] = {0.f, 0.f, 0.f, 0.f}, yo[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias_n) { const float4 t = *reinterpret_cast<const float4*>(bias_n); bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w; }
+    if (res_n) { const float4 t = *reinterpret_cast<const float4*>(res_n); rv[0] = t.x; rv[1] = t.y; rv[2] = t.z; rv[3] = t.w; }
+    if (p.flags & SVCMI_CONV_ACCUMULATE) { const float4 t = *reinterpret_cast<const float4*>(dst); yo[0] = t.x; yo[1] = t.y; yo[2] = t.z; yo[3] = t.w; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float q = act_apply(o[e] + bv[e], p.act);
+        if (res_n) q += rv[e];
+        q *= p.alpha;
+        if (p.flags & SVCMI_CONV_ACCUMULATE) q += yo[e];
+        o[e] = masked ? 0.f : q;
+    }
+    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
 __device__ __forceinline__ int div_magic(int q, unsigned magic) {   // q / c_in, exact while q * c_in < 2^32
@@ -484,6 +504,14 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
     if (p.split > 1 || (p.flags & SVCMI_CONV_PARTIALS)) {   // raw partial tile into this slice's slab
         float* wsb = p.ws + ((long long)b * p.split + slice) * p.t_out * p.n_out;
         if (!p.cnt) {        // no ticket counters: splitk_reduce_kernel sums the slabs in a second launch
+            if (p.vec) {
+                for (int e = tid; e < BM * (BN / 4); e += 256) {
+                    const int ml = e / (BN / 4), nl = (e - ml * (BN / 4)) * 4;
+                    if (ml < mvalid && nl < nvalid)
+                        *reinterpret_cast<float4*>(wsb + (long long)(m0 + ml) * p.n_out + n0 + nl) = *reinterpret_cast<const float4*>(Cs + ml * CLD + nl);
+                }
+                return;
+            }
             for (int e = tid; e < BM * BN; e += 256) {
                 const int ml = e / BN, nl = e - ml * BN;
                 if (ml < mvalid && nl < nvalid) wsb[(long long)(m0 + ml) * p.n_out + n0 + nl] = Cs[ml * CLD + nl];
@@ -536,6 +564,16 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
     float* yb = p.y + (long long)b * p.y_bs;
     const float* rbp = p.res ? p.res + (long long)b * p.r_bs : nullptr;
     const bool mask_out = (p.flags & SVCMI_CONV_MASK_OUT) != 0;
+    if (p.vec) {
+        for (int e = tid; e < BM * (BN / 4); e += 256) {
+            const int ml = e / (BN / 4), nl = (e - ml * (BN / 4)) * 4;
+            if (ml >= mvalid || nl >= nvalid) continue;
+            const int t = m0 + ml, n = n0 + nl;
+            epilogue4(p, *reinterpret_cast<const float4*>(Cs + ml * CLD + nl), p.bias ? p.bias + n : nullptr,
+                      rbp ? rbp + (long long)t * p.ldr + n : nullptr, yb + (long long)t * p.ldy + n, mask_out && t >= len);
+        }
+        return;
+    }
     for (int e = tid; e < BM * BN; e += 256) {
         const int ml = e / BN, nl = e - ml * BN;
         if (ml >= mvalid || nl >= nvalid) continue;
@@ -681,6 +719,12 @@ int prepare(const svcmi_conv_desc* d, ConvArgs& a, int& mode, int prec = PREC_F3
     a.ldw = d->ldw; a.ldy = d->ldy; a.ldr = d->ldr;
     a.ksize = d->ksize; a.stride = d->stride; a.dil = d->dilation; a.pad = d->pad; a.rshift = d->x_row_shift;
     a.act = d->act; a.flags = d->flags; a.alpha = d->alpha;
+    {
+        const auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+        a.vec = d->n_out % 4 == 0 && d->ldy % 4 == 0 && d->y_bstride % 4 == 0 && al16(d->y) &&
+                (!d->bias || al16(d->bias)) && (!d->res || (d->ldr % 4 == 0 && d->res_bstride % 4 == 0 && al16(d->res))) &&
+                (!d->workspace || al16(d->workspace));
+    }
     a.ktot = d->ksize * d->c_in;
     a.magic = d->c_in == 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d->c_in - 1) / (unsigned)d->c_in);
     const bool vec = (d->c_in % 4 == 0) && (d->ldx % 4 == 0) && (d->x_bstride % 4 == 0) && (((uintptr_t)d->x & 15) == 0);
