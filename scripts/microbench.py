@@ -162,6 +162,12 @@ def main():
         gemm(ops, "encp_pre", 1000, 1280, 192, k=5, tiles=(0,), splits=(1, 0, 4, 8))
         gemm(ops, "dec_pre", 1000, 192, 320, k=7, tiles=(0,), splits=sp)
         gemm(ops, "up0", 1000, 320, 800, k=3, tiles=(0,), splits=sp)
+    if "wtune" in what:       # Whisper window GEMMs as the encoder launches them (raw split-K slabs for the two N = n_state projections)
+        for T in (500, 750):
+            gemm(ops, "whisper_qkv", T, 1280, 3840, tiles=(1, 6, 2), splits=(1,))
+            gemm(ops, "whisper_mlp1", T, 1280, 5120, tiles=(1, 6, 7, 2), splits=(1,))
+            gemm(ops, "whisper_o", T, 1280, 1280, tiles=(1, 6), splits=(1, 2, 3, 4), partials=True)
+            gemm(ops, "whisper_mlp2", T, 5120, 1280, tiles=(1, 6), splits=(2, 4, 6, 8), partials=True)
     if "wp16" in what:        # Whisper shapes on the 16x16x4 tiles (128x80 gives exactly 256 blocks for N = 5120)
         gemm(ops, "whisper_qkv", 500, 1280, 3840, tiles=(1, 6, 7), splits=(1,))
         gemm(ops, "whisper_o", 500, 1280, 1280, res=True, tiles=(1, 6, 7), splits=(4, 2, 3))
