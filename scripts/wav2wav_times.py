@@ -35,6 +35,7 @@ def timed(fn, reps=5):
 
 def main():
     secs = float(sys.argv[1]) if len(sys.argv) > 1 else 10.0
+    prec = sys.argv[2] if len(sys.argv) > 2 else None      # GEMM operand precision of all four networks (None = fp32)
     ops, dev, hp = Ops(), "cuda", C.base_hp()
     n = int(16000 * secs)
     g = torch.Generator().manual_seed(0)
@@ -47,6 +48,7 @@ def main():
     model.load_state_dict(W.make_vits_state(hp, seed=1234))
     model.eval()
     model.to(dev)
+    whisper.encoder.precision = hubert.precision = crepe.precision = model.precision = prec
     wav_d = wav.to(dev)
     rows = []
     ms, mel = timed(lambda: WA.log_mel_spectrogram(wav_d, ops=ops, device=dev))
@@ -74,6 +76,7 @@ def main():
     total = sum(r[1] for r in rows)
     for name, ms in rows:
         print(f"{name:52s} {ms:8.2f} ms")
+    print(f"precision: {prec or 'fp32'}")
     print(f"{'total':52s} {total:8.2f} ms for {secs:g} s of audio = {secs * 1e3 / total:.0f}x real time (T = {T} frames, out {tuple(out.shape)})")
 
 

@@ -199,12 +199,13 @@ def check_hubert_against_oracle(ops, device, dims, n, heads, tol=TIGHT):
     return err
 
 
-def check_hubert_golden(ops, device, tol=TIGHT):
+def check_hubert_golden(ops, device, tol=TIGHT, precision=None):
     """svcmi.hubert at the reference dimensions vs the reference HubertSoft.units itself (golden fixture)."""
     from svcmi.hubert import load_model
     g = golden("hubert_soft_1s")
     sd = W.make_hubert_state()
     m = load_model(sd, device, ops=ops)
+    m.precision = precision
     gen = torch.Generator().manual_seed(int(g["seed"]))
     wav = torch.randn(1, 1, int(g["n"]), generator=gen) * 0.3
     err = maxerr(m.units(wav), _t(g["units"]))
@@ -244,11 +245,12 @@ def check_crepe_against_oracle(ops, device, capacity, n, tol=2e-5):
     return err, float(same.mean())
 
 
-def check_crepe_golden(ops, device, tol=2e-5):
+def check_crepe_golden(ops, device, tol=2e-5, precision=None):
     """svcmi.pitch.Crepe at the reference's `full` capacity vs the reference crepe package itself (golden fixture)."""
     from svcmi.pitch import decode, load_crepe
     g = golden("crepe_full_1s")
     m = load_crepe(W.make_crepe_state("full"), device, ops=ops)
+    m.precision = precision
     audio = crepe_test_audio(int(g["n"]), int(g["seed"]))
     prob = m.probabilities(audio, hop=320).cpu()
     err = maxerr(prob, _t(g["prob"]))

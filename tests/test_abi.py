@@ -52,6 +52,16 @@ def test_argument_validation_needs_no_gpu(hip_so):
     assert lib.svcmi_conv_gemm_group_f32(descs, 0, None) == -1 and lib.svcmi_conv_gemm_group_f32(descs, 4, None) == -1
     assert lib.svcmi_conv_gemm_group_f32(descs, 2, None) == -1                    # null operands inside the descriptors
     assert lib.svcmi_snake_conv_group_f32((_lib.SnakeConvDesc * 3)(), 0, None, 1, 10, 20, 20, None) == -1
+    # reduced-precision entry points: unknown precision / null descriptors / bad image geometry are rejected before any launch
+    assert lib.svcmi_conv_gemm_lp(None, 1, None) == -1 and lib.svcmi_conv_gemm_lp(ctypes.byref(d), 0, None) == -1
+    assert lib.svcmi_conv_gemm_lp(ctypes.byref(d), 7, None) == -1
+    assert lib.svcmi_conv_gemm_group_lp(descs, 2, 1, None) == -1 and lib.svcmi_conv_gemm_group_lp(descs, 2, 9, None) == -1
+    buf16 = (ctypes.c_float * 256)()
+    p16 = ctypes.cast(buf16, ctypes.c_void_p)
+    assert lib.svcmi_pack_weights_lp(None, 4, 32, 1, p16, 32, None) == -1            # null source
+    assert lib.svcmi_pack_weights_lp(p16, 4, 32, 0, p16, 32, None) == -1             # fp32 is not a packable precision
+    assert lib.svcmi_pack_weights_lp(p16, 4, 40, 2, p16, 48, None) == -1             # ldw16 must be a multiple of 32
+    assert lib.svcmi_pack_weights_lp(p16, 4, 40, 2, p16, 32, None) == -1             # ldw16 < ldw
     assert lib.svcmi_block_mean_f32(None, 3, None, 16, None) == -1
     buf = (ctypes.c_float * 64)()
     p = ctypes.cast(buf, ctypes.c_void_p)

@@ -160,3 +160,12 @@ def test_whisper_15s_window_modes(ops, whisper):
         REPORT[f"whisper15s_{mode}"] = dict(ppg_rel_err=e, lp_launches=n_lp)
         print(f"whisper 15 s {mode}: rel err {e:.2e}, {n_lp} lp launches")
         assert n_lp >= 24 * 4 and e <= PPG_REL_BOUND[mode]
+
+
+def test_extractors_in_bf16x3_match_the_reference_goldens(ops):
+    """Rows N3 with split-bf16 GEMM operands: HuBERT-Soft units and CREPE posteriors against the REFERENCE's own outputs
+    (tests/golden/hubert_soft_1s.npz, crepe_full_1s.npz) -- an fp32-class result (tolerances 5x the fp32 ones)."""
+    e_h = E.check_hubert_golden(ops, "cuda", tol=5e-4, precision="bf16x3")
+    e_c = E.check_crepe_golden(ops, "cuda", tol=1e-4, precision="bf16x3")
+    REPORT["extractors_bf16x3"] = dict(hubert_units_max_abs=e_h, crepe_posterior_max_abs=e_c)
+    print(f"bf16x3 extractors: hubert units err {e_h:.2e}, crepe posterior err {e_c:.2e}")

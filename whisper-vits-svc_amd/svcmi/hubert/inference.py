@@ -24,6 +24,7 @@ class HubertSoft:
         self.ops = ops if ops is not None else Ops()
         self.device = torch.device(device)
         self.w = PW.HubertWeights(state_dict, self.device)
+        self.precision = None        # GEMM operand precision (Ops.use_precision): None = fp32; the reference's CUDA path is fp16 (:20-21)
 
     def eval(self):
         return self
@@ -36,6 +37,10 @@ class HubertSoft:
     @torch.no_grad()
     def units(self, wav):
         """wav [B, 1, n] (or [n]) float at 16 kHz -> soft units [B, T, proj] on the device."""
+        with self.ops.use_precision(self.precision):
+            return self._units(wav)
+
+    def _units(self, wav):
         w, ops = self.w, self.ops
         x = wav.to(self.device, torch.float32)
         if x.dim() == 1:

@@ -29,10 +29,15 @@ class Crepe:
         self.ops = ops if ops is not None else Ops()
         self.device = torch.device(device)
         self.w = PW.CrepeWeights(state_dict, self.device)
+        self.precision = None        # GEMM operand precision (Ops.use_precision): None = fp32
 
     @torch.no_grad()
     def probabilities(self, audio, hop=320, batch_size=512):
         """audio [n] float @16 kHz -> sigmoid outputs [1 + n // hop, 360] (device tensor), batches of ``batch_size`` frames."""
+        with self.ops.use_precision(self.precision):
+            return self._probabilities(audio, hop, batch_size)
+
+    def _probabilities(self, audio, hop, batch_size):
         w, ops = self.w, self.ops
         audio = audio.to(self.device, torch.float32).contiguous().view(-1)
         total = 1 + audio.numel() // hop
