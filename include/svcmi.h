@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SVCMI_ABI_VERSION 15
+#define SVCMI_ABI_VERSION 16
 
 enum svcmi_status { SVCMI_OK = 0, SVCMI_EINVAL = -1, SVCMI_EUNSUPPORTED = -2, SVCMI_EALIGN = -3 };
 
@@ -345,6 +345,28 @@ int svcmi_row_sqnorm_f32(const float* x, int32_t ldx, int64_t rows, int32_t d, f
 int svcmi_knn_blend_f32(const float* x, int32_t ldx, const float* bank, int32_t ldb, const float* dots, int64_t ldd,
                         const float* bank_sq, float* out, int32_t ldo, int32_t t, int32_t n, int32_t d, int32_t k,
                         float ratio, void* stream);
+
+/* The reference's own index type: faiss IVF-Flat searched with nprobe = 1 (feature_retrieval/index.py:145-151 builds
+ * index_factory("IVF{n},Flat", METRIC_L2) and sets nprobe = 1; :57-62 search_and_reconstruct; :163-166 read_index).  faiss 1.7.4 is
+ * pinned by the reference's requirements.txt and not vendored; its published algorithm is restated (parity unpinned: no faiss here):
+ *   ivf_assign:   coarse quantizer = IndexFlatL2 over the nlist centroids: assign[i] = argmin_j max(0, |x_i|^2 + cent_sq[j] -
+ *                 2*dots[i, j]) with dots = X * Centroids^T from svcmi_conv_gemm_f32 (ties -> smaller j); dist (optional) = that
+ *                 minimum.  Also the assignment step of the k-means that trains the centroids (Clustering.cpp).
+ *   ivf_blend:    the inverted list of cell assign[i] = rows [list_off[a], list_off[a+1]) of `bank` (stored vectors grouped by cell,
+ *                 insertion order inside a cell) is scanned with exact distances sum_c (x - b)^2; the k (<= 8) nearest, ascending (ties ->
+ *                 earlier row), get weight (1/dist)^2 normalised and out[i] = (1 - ratio) * x[i] + ratio * sum_q weight_q * bank[nn_q].
+ *                 A cell with fewer than k vectors uses the ones it has, an empty cell leaves x[i] unchanged (faiss pads with label -1
+ *                 and a NaN reconstruction there, which makes the reference emit a NaN frame).  out_idx [t][k] (optional): the chosen
+ *                 rows of `bank`, -1 padded; out_dist [t][k] (optional): their distances, +inf padded.
+ *   segment_mean: k-means centroid update: out[c] = mean of x[order[r]], r in [seg_off[c], seg_off[c+1]), summed in that order;
+ *                 an empty segment leaves out[c] untouched. */
+int svcmi_ivf_assign_f32(const float* x, int32_t ldx, const float* dots, int64_t ldd, const float* cent_sq, int32_t t,
+                         int32_t nlist, int32_t d, int32_t* assign, float* dist, void* stream);
+int svcmi_ivf_blend_f32(const float* x, int32_t ldx, const int32_t* assign, const int32_t* list_off, const float* bank,
+                        int32_t ldb, float* out, int32_t ldo, int32_t t, int32_t d, int32_t k, float ratio,
+                        int32_t* out_idx, float* out_dist, void* stream);
+int svcmi_segment_mean_f32(const float* x, int32_t ldx, const int32_t* order, const int32_t* seg_off, float* out, int32_t ldo,
+                           int32_t segments, int32_t d, void* stream);
 
 /* int16 side output, vits_decoder/generator.py:167-173: clamp(32768*x, -32768, 32767) truncated to short. */
 int svcmi_source2wav_i16(const float* x, int16_t* y, int64_t n, void* stream);

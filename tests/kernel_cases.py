@@ -218,6 +218,75 @@ def check_knn_blend(ops, device, t=37, n=301, d=64, k=3, ratio=0.5):
     _close(got_t, want, 2e-5, "knn_blend tensor")
 
 
+def _blobs(g, n, d, centres=8, spread=1.0):
+    c = torch.randn(centres, d, generator=g) * 4.0
+    return (c[torch.randint(0, centres, (n,), generator=g)] + spread * torch.randn(n, d, generator=g)).numpy()
+
+
+def check_ivf_index(ops, device, t=37, n=600, d=32, k=3, ratio=0.5, nlist=9, tmp_path=None):
+    """The reference's index type (IVF-Flat, nprobe = 1): coarse assignment + list scan + RVC blend through the host index class vs
+    the numpy restatement of faiss's algorithm (oracle/retrieval_oracle.py ivf_*), on an index whose lists are deliberately ragged
+    (one empty cell, one with fewer than k vectors)."""
+    from oracle import retrieval_oracle as RO
+    from svcmi.ivf_index import IvfFlatFeatureIndex
+    g = _g(7 + t + n + k)
+    bank = _blobs(g, n, d)
+    feats = _blobs(g, t, d)
+    cent = bank[torch.randperm(n, generator=g)[:nlist].numpy()].copy()
+    cent[nlist - 1] = 1.0e3                                     # a cell nothing falls into
+    cell, _ = RO.coarse_assign(bank, cent)
+    thin = int(np.bincount(cell, minlength=nlist)[:nlist - 1].argmin())
+    keep = np.ones(n, bool)
+    keep[np.flatnonzero(cell == thin)[max(k - 1, 1):]] = False   # leave k - 1 vectors in the thinnest cell
+    bank, cell = bank[keep], cell[keep]
+    ids = np.arange(len(bank), dtype=np.int64) * 3 + 1           # labels are not row numbers
+    lists = [(bank[cell == c], ids[cell == c]) for c in range(nlist)]
+    off = np.zeros(nlist + 1, np.int32)
+    off[1:] = np.cumsum([len(i) for _, i in lists])
+    index = IvfFlatFeatureIndex(cent, off, np.concatenate([v for v, _ in lists]), np.concatenate([i for _, i in lists]),
+                                ratio, k, device=device, ops=ops)
+    feats[0] = cent[thin] + 1e-3                                  # make sure the thin cell is probed
+    want_cell, _ = RO.coarse_assign(feats, cent)
+    dist_w, lab_w, rec_w = RO.ivf_search(feats, cent, lists, k)
+    dist, lab, rec = index.search_and_reconstruct(feats, k)
+    assert np.array_equal(lab, lab_w), "ivf labels"
+    fin = np.isfinite(dist_w)
+    assert np.array_equal(np.isfinite(dist), fin) and np.allclose(dist[fin], dist_w[fin], rtol=2e-5), "ivf distances"
+    assert np.array_equal(np.isnan(rec), np.isnan(rec_w)) and np.array_equal(rec[~np.isnan(rec)], rec_w[~np.isnan(rec_w)]), "ivf vectors"
+    assert (lab_w[0] >= 0).sum() == max(k - 1, 1), "the thin cell was not probed"
+    got = index.retriv(feats)
+    _close(torch.from_numpy(got), torch.from_numpy(RO.ivf_retriv(feats, cent, lists, ratio, k)), 2e-5, f"ivf_blend t={t} n={n} d={d} k={k}")
+    got_t = index.retriv(torch.from_numpy(feats).to(device))
+    assert got_t.device.type == torch.device(device).type and np.array_equal(got_t.cpu().numpy(), got)
+    if tmp_path is not None:                                      # faiss file layout: save -> load -> same answers
+        f = tmp_path / "t.index"
+        index.save(f)
+        again = IvfFlatFeatureIndex.from_faiss(f, ratio, k, device=device, ops=ops)
+        assert np.array_equal(again.retriv(feats), got) and again.ntotal == len(bank) and again.nlist == nlist
+    return want_cell
+
+
+def check_ivf_train(ops, device, n=900, d=16, blobs=6, n_ivf=None):
+    """faiss's k-means + add (svcmi.ivf_index.train_kmeans / IvfFlatFeatureIndex.train) vs the numpy restatement on separated blobs:
+    same permutations (std::mt19937 replay), assignments equal, centroids to fp32 summation-order tolerance."""
+    from oracle import retrieval_oracle as RO
+    from svcmi.ivf_index import IvfFlatFeatureIndex, faiss_rand_perm, ivf_list_count
+    g = _g(31 + n + d)
+    x = _blobs(g, n, d, centres=blobs, spread=0.5)
+    assert np.array_equal(faiss_rand_perm(50, 1235), RO.rand_perm(50, 1235))
+    index = IvfFlatFeatureIndex.train(x, device=device, ops=ops, n_ivf=n_ivf)
+    cent_w, lists_w = RO.ivf_build(x, n_ivf=n_ivf)
+    assert index.nlist == (n_ivf or ivf_list_count(n)) == len(lists_w)
+    _close(index.centroids, torch.from_numpy(cent_w), 2e-5, "k-means centroids")
+    off = index.list_off.cpu().numpy()
+    ids = index.ids.cpu().numpy()
+    same = sum(np.array_equal(ids[off[c]:off[c + 1]], lists_w[c][1]) for c in range(index.nlist))
+    assert same >= index.nlist - 1, f"{index.nlist - same} inverted lists differ"          # a boundary point may flip on round-off
+    assert index.ntotal == n and np.array_equal(np.sort(ids), np.arange(n))
+    assert np.array_equal(index.bank.cpu().numpy(), x[ids])
+    return index
+
+
 def check_channel_norm_gelu(ops, device, B=2, T=700, c=32):
     g = _g(5 + c)
     x = torch.randn(B, T, c, generator=g) * 2.0 + 0.7

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(hip_so):
         assert hasattr(lib, s), f"{s} declared in include/svcmi.h but not exported"
     lib.svcmi_build_info.restype = ctypes.c_char_p
     assert lib.svcmi_build_info() == b"hip:gfx950"
-    assert lib.svcmi_abi_version() == 15
+    assert lib.svcmi_abi_version() == 16
 
 
 def test_binding_table_matches_header():
@@ -67,6 +67,13 @@ def test_argument_validation_needs_no_gpu(hip_so):
     p = ctypes.cast(buf, ctypes.c_void_p)
     assert lib.svcmi_knn_blend_f32(p, 16, p, 16, p, 16, p, p, 16, 1, 16, 16, 9, 0.5, None) == -2   # k > 8: SVCMI_EUNSUPPORTED
     assert lib.svcmi_knn_blend_f32(p, 16, p, 16, p, 4, p, p, 16, 1, 4, 16, 5, 0.5, None) == -1   # k > n
+    assert lib.svcmi_ivf_assign_f32(p, 16, p, 2, p, 1, 4, 16, p, None, None) == -1                # ldd < nlist
+    assert lib.svcmi_ivf_assign_f32(p, 16, p, 4, p, 1, 4, 16, None, None, None) == -1             # no output
+    assert lib.svcmi_ivf_assign_f32(p, 18, p, 4, p, 1, 4, 18, p, None, None) == -3                # d % 4: SVCMI_EALIGN
+    assert lib.svcmi_ivf_blend_f32(p, 16, p, p, p, 16, p, 16, 1, 16, 9, 0.5, None, None, None) == -2   # k > 8
+    assert lib.svcmi_ivf_blend_f32(p, 16, p, p, p, 16, p, 16, 1, 16, 0, 0.5, None, None, None) == -1   # k < 1
+    assert lib.svcmi_ivf_blend_f32(p, 16, None, p, p, 16, p, 16, 1, 16, 1, 0.5, None, None, None) == -1  # no assignment
+    assert lib.svcmi_segment_mean_f32(p, 16, p, p, p, 8, 2, 16, None) == -1                       # ldo < d
     assert lib.svcmi_viterbi_decode(p, p, p, p, p, 4, 4, 0, 360, 16, None) == -2                 # band > 15
     assert lib.svcmi_viterbi_decode(p, p, p, p, p, 4, 4, 10, 5, 0, None) == -1                   # empty bin range
     assert lib.svcmi_tune_set(b"no_such_knob", 1) == -1

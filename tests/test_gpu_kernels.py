@@ -84,6 +84,16 @@ def test_knn_blend(ops, t, n, d, k, ratio):
     K.check_knn_blend(ops, "cuda", t, n, d, k, ratio)
 
 
+@pytest.mark.parametrize("t,n,d,k,ratio,nlist", [(2510, 60000, 1280, 3, 0.5, 1500), (2510, 20000, 256, 3, 0.5, 512), (37, 600, 32, 8, 0.25, 9), (300, 5000, 256, 1, 1.0, 70)])
+def test_ivf_index(ops, tmp_path, t, n, d, k, ratio, nlist):
+    K.check_ivf_index(ops, "cuda", t, n, d, k, ratio, nlist, tmp_path=tmp_path)
+
+
+@pytest.mark.parametrize("n,d,blobs,n_ivf", [(20000, 256, 24, None), (3000, 64, 10, 40)])
+def test_ivf_train(ops, n, d, blobs, n_ivf):
+    K.check_ivf_train(ops, "cuda", n, d, blobs, n_ivf)
+
+
 @pytest.mark.parametrize("n,c,B", [(333, 40, 2), (20000, 80, 1), (5000, 160, 1), (80000, 40, 1), (70, 16, 3)])
 def test_grouped_launches(ops, n, c, B):
     K.check_grouped_launches(ops, "cuda", B=B, n=n, c=c, ld=c)

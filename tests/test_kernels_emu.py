@@ -69,6 +69,16 @@ def test_knn_blend(ops, t, n, d, k, ratio):
     K.check_knn_blend(ops, "cpu", t, n, d, k, ratio)
 
 
+@pytest.mark.parametrize("t,n,d,k,ratio,nlist", [(9, 200, 16, 3, 0.5, 5), (6, 120, 32, 1, 1.0, 4), (5, 150, 16, 8, 0.25, 3)])
+def test_ivf_index(ops, tmp_path, t, n, d, k, ratio, nlist):
+    K.check_ivf_index(ops, "cpu", t, n, d, k, ratio, nlist, tmp_path=tmp_path)
+
+
+@pytest.mark.parametrize("n,d,blobs,n_ivf", [(240, 8, 4, None), (150, 8, 3, 5)])
+def test_ivf_train(ops, n, d, blobs, n_ivf):
+    K.check_ivf_train(ops, "cpu", n, d, blobs, n_ivf)
+
+
 @pytest.mark.parametrize("n,c", [(150, 40), (70, 80), (90, 16), (40, 32)])
 def test_grouped_launches(ops, n, c):
     K.check_grouped_launches(ops, "cpu", B=2, n=n, c=c, ld=c)
@@ -122,3 +132,30 @@ def test_argument_errors_are_reported(ops):
         ops.conv(x, w, ksize=2)          # ldw < ksize*c_in
     with pytest.raises(Exception):
         ops.attention(torch.zeros(1, 4, 3 * 20), heads=1, scale=1.0)   # head_dim 20 unsupported
+
+
+def test_svc_train_retrieval_cli_writes_loadable_indexes(ops, tmp_path, monkeypatch):
+    """svc_train_retrieval.py of the reference end to end on the emulated kernels: data_svc/{hubert,whisper}/<spk>/*.npy ->
+    data_svc/indexes/<spk>/{hubert,whisper}.index (faiss layout) -> load_retrieve_index -> retriv."""
+    import numpy as np
+    from svcmi import feature_retrieval as FR, ivf_index as IV, svc_train_retrieval as TR
+    rng = np.random.default_rng(11)
+    base = tmp_path / "data_svc"
+    for kind, d in (("hubert", 8), ("whisper", 16)):
+        (base / kind / "spk0").mkdir(parents=True)
+        for j in range(2):
+            np.save(base / kind / "spk0" / f"{j}.npy", rng.standard_normal((60, d)).astype(np.float32))
+    (base / "indexes").mkdir()
+    for kind in ("hubert", "whisper"):
+        TR.create_index(kind, "p_", "spk0", base, base / "indexes", 200_000, 10_000, 1, device="cpu", ops=ops)
+    f = base / "indexes" / "spk0" / "p_whisper.index"
+    raw = IV.read_faiss_ivf_flat(f)
+    assert raw["ntotal"] == 120 and raw["nlist"] == IV.ivf_list_count(120) == 3 and raw["nprobe"] == 1
+    with pytest.raises(FileExistsError):
+        TR.create_index("whisper", "p_", "spk0", base, base / "indexes", 200_000, 10_000, 1, device="cpu", ops=ops)
+    index = FR.load_retrieve_index(f, 0.5, 2, device="cpu", ops=ops)
+    assert isinstance(index, IV.IvfFlatFeatureIndex)
+    x = rng.standard_normal((5, 16)).astype(np.float32)
+    y = index.retriv(x)
+    assert y.shape == x.shape and np.isfinite(y).all() and not np.allclose(y, x)
+    assert TR.build_parser().parse_args([]).compress_features_after == 200_000

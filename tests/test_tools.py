@@ -151,3 +151,74 @@ def test_retrieval_oracle_search_matches_sklearn_brute_force():
     scores, got = RO.knn_search(x, bank, 3)
     assert np.array_equal(got, ids)
     assert np.allclose(scores, dist, rtol=1e-5)
+
+
+def test_mt19937_replay_matches_std_mt19937():
+    """faiss's RandomGenerator is std::mt19937; the C++ standard fixes its 10000th output for the default seed 5489 at 4123659995
+    (first output 3499211612) -- numpy's legacy RandomState reproduces the stream, which is what rand_perm / split_clusters replay."""
+    from oracle import retrieval_oracle as RO
+    from svcmi import ivf_index as IV
+    draws = IV._mt_draws(5489, 10000)
+    assert draws[0] == 3499211612 and draws[9999] == 4123659995
+    assert np.array_equal(draws, RO._mt19937(5489, 10000))
+    p = IV.faiss_rand_perm(1000, 1234)
+    assert np.array_equal(np.sort(p), np.arange(1000)) and np.array_equal(p, RO.rand_perm(1000, 1234))
+    assert p[0] == 0 + int(IV._mt_draws(1234, 1)[0]) % 1000          # first swap partner, rand_perm's definition
+
+
+def test_faiss_ivf_flat_file_layout(tmp_path):
+    """Byte-for-byte layout of faiss 1.7.4 ``write_index(IndexIVFFlat)`` (impl/index_write.cpp: write_ivf_header, write_index_header,
+    write_direct_map, write_InvertedLists) built by hand here, against the writer; then the reader on both a 'full' and a 'sprs' file."""
+    import struct
+    from svcmi import ivf_index as IV
+    d, nlist = 4, 3
+    cent = np.arange(nlist * d, dtype=np.float32).reshape(nlist, d)
+    vecs = [np.full((2, d), 1.5, np.float32), np.zeros((0, d), np.float32), np.full((1, d), -2.0, np.float32)]
+    ids = [np.array([7, 9], np.int64), np.zeros(0, np.int64), np.array([4], np.int64)]
+    hdr = lambda n: struct.pack("<i", d) + struct.pack("<q", n) + struct.pack("<qq", 1 << 20, 1 << 20) + b"\x01" + struct.pack("<i", 1)
+    want = (b"IwFl" + hdr(3) + struct.pack("<QQ", nlist, 1)
+            + b"IxF2" + hdr(nlist) + struct.pack("<Q", nlist * d) + cent.tobytes()
+            + b"\x00" + struct.pack("<Q", 0)
+            + b"ilar" + struct.pack("<QQ", nlist, 4 * d) + b"full" + struct.pack("<Q", nlist) + struct.pack("<QQQ", 2, 0, 1)
+            + vecs[0].tobytes() + ids[0].tobytes() + vecs[2].tobytes() + ids[2].tobytes())
+    f = tmp_path / "a.index"
+    IV.write_faiss_ivf_flat(f, cent, vecs, ids)
+    assert f.read_bytes() == want
+    r = IV.read_faiss_ivf_flat(f)
+    assert (r["d"], r["ntotal"], r["nlist"], r["nprobe"], r["metric"], r["is_trained"]) == (d, 3, nlist, 1, 1, True)
+    assert np.array_equal(r["centroids"], cent)
+    for (v, i), v0, i0 in zip(r["lists"], vecs, ids):
+        assert np.array_equal(v, v0) and np.array_equal(i, i0)
+    # sparse size table: at most half of the lists non-empty
+    g = tmp_path / "b.index"
+    IV.write_faiss_ivf_flat(g, cent, [vecs[1], vecs[1], vecs[2]], [ids[1], ids[1], ids[2]])
+    raw = g.read_bytes()
+    assert b"sprs" + struct.pack("<Q", 2) + struct.pack("<QQ", 2, 1) in raw
+    r = IV.read_faiss_ivf_flat(g)
+    assert [len(i) for _, i in r["lists"]] == [0, 0, 1] and np.array_equal(r["lists"][2][1], ids[2])
+    (tmp_path / "c.index").write_bytes(b"IxF2" + raw[4:])
+    with pytest.raises(ValueError):
+        IV.read_faiss_ivf_flat(tmp_path / "c.index")
+
+
+def test_ivf_oracle_degenerates_to_exhaustive_search():
+    """One cell = every vector probed: the IVF restatement must then equal the exhaustive one (and sklearn's, by the test above);
+    with more cells every returned neighbour lies in the query's own cell and is the nearest there."""
+    from oracle import retrieval_oracle as RO
+    rng = np.random.default_rng(5)
+    bank = rng.standard_normal((400, 16)).astype(np.float32)
+    x = rng.standard_normal((30, 16)).astype(np.float32)
+    ids = np.arange(400, dtype=np.int64)
+    dist, lab, rec = RO.ivf_search(x, bank[:1] * 0, [(bank, ids)], 4)
+    want_d, want_i = RO.knn_search(x, bank, 4)
+    assert np.array_equal(lab, want_i) and np.allclose(dist, want_d, rtol=1e-6) and np.array_equal(rec, bank[want_i])
+    assert np.allclose(RO.ivf_retriv(x, bank[:1] * 0, [(bank, ids)], 0.5, 4), RO.retriv(x, bank, 0.5, 4), atol=1e-6)
+    cent, lists = RO.ivf_build(bank, n_ivf=8, niter=5)
+    cell, _ = RO.coarse_assign(x, cent)
+    dist, lab, _ = RO.ivf_search(x, cent, lists, 2)
+    for i in range(len(x)):
+        own = lists[int(cell[i])][1]
+        assert set(lab[i][lab[i] >= 0]) <= set(own.tolist())
+        d2 = ((x[i] - bank[own]) ** 2).sum(1)
+        assert np.isclose(dist[i, 0], d2.min(), rtol=1e-5)
+    assert sum(len(i) for _, i in lists) == 400

@@ -8,7 +8,7 @@ DEFAULT_LIB = os.path.join(HERE, "libsvcmi.so")
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_MISH, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4, 5
 CONV_ACCUMULATE, CONV_MASK_IN, CONV_MASK_OUT, CONV_PARTIALS = 1, 2, 4, 8
-ABI_VERSION = 15
+ABI_VERSION = 16
 PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16 = 0, 1, 2, 3
 PRECISIONS = {None: 0, "f32": 0, "fp32": 0, "bf16x3": 1, "bf16": 2, "f16": 3, "fp16": 3}
 CONV_TILE_64x128 = 9
@@ -71,6 +71,9 @@ SIGNATURES = {
     "svcmi_viterbi_decode": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "svcmi_row_sqnorm_f32": (c_int, [_P, _I, _L, _I, _P, _P]),
     "svcmi_knn_blend_f32": (c_int, [_P, _I, _P, _I, _P, _L, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "svcmi_ivf_assign_f32": (c_int, [_P, _I, _P, _L, _P, _I, _I, _I, _P, _P, _P]),
+    "svcmi_ivf_blend_f32": (c_int, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _F, _P, _P, _P]),
+    "svcmi_segment_mean_f32": (c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "svcmi_snake_post_supported": (c_int, [_I, _I, _I]),
     "svcmi_snake_post_f32": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "svcmi_conv_gemm_group_f32": (c_int, [_P, _I, _P]),

@@ -1,15 +1,15 @@
 """Feature retrieval on the GPU (row N4): the reference's optional faiss kNN blend of the content features
-(feature_retrieval/index.py:57-94, retrieval.py:31-44, svc_inference.py:25-58) as an exact brute-force search.
+(feature_retrieval/index.py:57-94, retrieval.py:31-44, svc_inference.py:25-58).
 
-The reference keeps one faiss IVF-Flat index per feature kind (whisper PPG, HuBERT vec) and, per synthesis chunk, replaces
-each frame by ``(1 - ratio) * x + ratio * sum_q w_q * nn_q`` with ``w = (1/d2)^2`` normalised over the k nearest stored
-vectors (squared-L2 metric).  faiss is not part of this stack: the stored vectors live in HBM as one [n, d] fp32 matrix,
-the candidate scores are one svcmi_conv_gemm_f32 launch (X * Bank^T) and ``svcmi_knn_blend_f32`` does selection, exact
-re-measurement and the blend.  The search is exact (what IVF gives with nprobe = nlist); the reference's nprobe = 1 is
-an approximation of it, so results agree whenever IVF's probed cell holds the true neighbours.
+The reference keeps one faiss IVF-Flat index (nprobe = 1, squared-L2 metric) per feature kind (whisper PPG, HuBERT vec) and, per
+synthesis chunk, replaces each frame by ``(1 - ratio) * x + ratio * sum_q w_q * nn_q`` with ``w = (1/d2)^2`` normalised over the k
+nearest stored vectors.  faiss is not part of this stack.  Two index kinds answer ``retriv``:
 
-Index files: a ``.npy`` [n, d] float32 matrix of the speaker's training features (the rows the reference adds to its
-index, feature_retrieval/train.py); faiss ``.index`` files cannot be read without faiss.
+* ``IvfFlatFeatureIndex`` (ivf_index.py) -- the reference's own semantics: one probed cell per frame, exact scan of its list.  Reads and
+  writes the reference's ``.index`` files (faiss IndexIVFFlat layout) and trains like ``svc_train_retrieval.py``;
+* ``KnnFeatureIndex`` (here) -- an exact brute-force search over a ``.npy`` [n, d] bank (what IVF gives with nprobe = nlist): the stored
+  vectors live in HBM as one matrix, the candidate scores are one svcmi_conv_gemm_f32 launch (X * Bank^T) and ``svcmi_knn_blend_f32``
+  does selection, exact re-measurement and the blend.  The two agree whenever IVF's probed cell holds the true neighbours.
 """
 import glob
 import os
@@ -18,6 +18,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
+from .ivf_index import IvfFlatFeatureIndex
 from .ops import Ops
 from .svc_inference import IRetrieval
 
@@ -81,16 +82,15 @@ class KnnFeatureIndex:
 
 
 def load_retrieve_index(filepath, ratio, n_nearest_vectors, device="cuda", ops=None):
-    """index.py:163-166 for ``.npy`` feature banks."""
+    """index.py:163-166: a faiss IVF-Flat ``.index`` file (the reference's format) -> ``IvfFlatFeatureIndex`` (nprobe = 1 semantics);
+    a ``.npy`` [n, d] feature bank -> ``KnnFeatureIndex`` (exact search)."""
     filepath = str(filepath)
     if not os.path.exists(filepath):
-        faiss_file = filepath[:-4] if filepath.endswith(".index.npy") else filepath
-        if faiss_file.endswith(".index") and os.path.exists(faiss_file):
-            raise FileNotFoundError(
-                f"{faiss_file} is a faiss index, which this stack cannot read (faiss is not installed): rebuild the bank from the "
-                f"speaker's feature files with svcmi.feature_retrieval.build_index_bank(<data_svc/whisper|hubert/spk>, '{filepath}')")
-        raise FileNotFoundError(f"retrieval feature bank {filepath} not found (see build_index_bank)")
-    return KnnFeatureIndex(np.load(filepath), ratio, n_nearest_vectors, device=device, ops=ops)
+        raise FileNotFoundError(f"retrieval index {filepath} not found (python -m svcmi.svc_train_retrieval builds .index files, "
+                                f"build_index_bank .npy banks)")
+    if filepath.endswith(".npy"):
+        return KnnFeatureIndex(np.load(filepath), ratio, n_nearest_vectors, device=device, ops=ops)
+    return IvfFlatFeatureIndex.from_faiss(filepath, ratio, n_nearest_vectors, device=device, ops=ops)
 
 
 def build_index_bank(feature_dir, out_path=None):
@@ -129,15 +129,21 @@ def get_speaker_name_from_path(speaker_path):
 
 
 def create_retrival(cli_args, device="cuda"):
-    """svc_inference.py:25-58 with ``.npy`` banks: data_svc/indexes/<speaker>/<prefix>{hubert,whisper}.index.npy unless
-    ``--hubert-index-path / --whisper-index-path`` are given."""
+    """svc_inference.py:25-58: data_svc/indexes/<speaker>/<prefix>{hubert,whisper}.index unless ``--hubert-index-path /
+    --whisper-index-path`` are given (a path ending in .npy selects the exact-search bank)."""
     from .svc_inference import DummyRetrieval
     if not cli_args.enable_retrieval:
         return DummyRetrieval()
     base_path = Path(".").absolute() / "data_svc" / "indexes" / get_speaker_name_from_path(cli_args.spk)
     prefix = cli_args.retrieval_index_prefix
-    hubert_path = cli_args.hubert_index_path or base_path / f"{prefix}hubert.index.npy"
-    whisper_path = cli_args.whisper_index_path or base_path / f"{prefix}whisper.index.npy"
+
+    def default(kind):
+        ivf = base_path / f"{prefix}{kind}.index"
+        bank = base_path / f"{prefix}{kind}.index.npy"
+        return bank if (bank.exists() and not ivf.exists()) else ivf
+
+    hubert_path = cli_args.hubert_index_path or default("hubert")
+    whisper_path = cli_args.whisper_index_path or default("whisper")
     ops = Ops()
     kw = dict(ratio=cli_args.retrieval_ratio, n_nearest_vectors=cli_args.n_retrieval_vectors, device=device, ops=ops)
     return KnnIndexRetrieval(hubert_index=load_retrieve_index(hubert_path, **kw),

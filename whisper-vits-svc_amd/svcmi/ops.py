@@ -426,6 +426,37 @@ class Ops:
                    _ptr(bank_sq), _ptr(out), out.stride(0), x.shape[0], bank.shape[0], x.shape[1], k, ratio, self._stream())
         return out
 
+    def ivf_assign(self, x, dots, cent_sq, want_dist=False):
+        """x [t, d], dots [t, >= nlist] = x @ centroids.T -> int32 [t] nearest centroid (+ its BLAS-form distance)."""
+        self._chk(x, dots, cent_sq)
+        t = x.shape[0]
+        assign = torch.empty(t, dtype=torch.int32, device=x.device)
+        dist = torch.empty(t, dtype=torch.float32, device=x.device) if want_dist else None
+        self._call("svcmi_ivf_assign_f32", _ptr(x), x.stride(0), _ptr(dots), dots.stride(0), _ptr(cent_sq), t, cent_sq.shape[0],
+                   x.shape[1], _ptr(assign), _ptr(dist) if want_dist else 0, self._stream())
+        return (assign, dist) if want_dist else assign
+
+    def ivf_blend(self, x, assign, list_off, bank, k, ratio, out=None, want_neighbours=False):
+        """x [t, d], assign int32 [t], list_off int32 [nlist + 1], bank [n, d] grouped by cell -> blended [t, d]
+        (+ int32 [t, k] bank rows, float [t, k] distances)."""
+        self._chk(x, bank, out)
+        t = x.shape[0]
+        if out is None:
+            out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        idx = torch.empty(t, k, dtype=torch.int32, device=x.device) if want_neighbours else None
+        dist = torch.empty(t, k, dtype=torch.float32, device=x.device) if want_neighbours else None
+        self._call("svcmi_ivf_blend_f32", _ptr(x), x.stride(0), _ptr(assign), _ptr(list_off), _ptr(bank), bank.stride(0), _ptr(out),
+                   out.stride(0), t, x.shape[1], k, ratio, _ptr(idx) if want_neighbours else 0, _ptr(dist) if want_neighbours else 0,
+                   self._stream())
+        return (out, idx, dist) if want_neighbours else out
+
+    def segment_mean(self, x, order, seg_off, out):
+        """out[c] = mean of x[order[seg_off[c]:seg_off[c+1]]] (empty segments untouched)."""
+        self._chk(x, out)
+        self._call("svcmi_segment_mean_f32", _ptr(x), x.stride(0), _ptr(order), _ptr(seg_off), _ptr(out), out.stride(0),
+                   seg_off.shape[0] - 1, x.shape[1], self._stream())
+        return out
+
     def source2wav(self, x):
         self._chk(x)
         x = x.contiguous()

@@ -192,12 +192,12 @@ def build_parser():
     p.add_argument("--shift", type=int, default=0, help="Pitch shift key.")
     p.add_argument("--enable-retrieval", action="store_true", help="Enable index feature retrieval")
     p.add_argument("--retrieval-index-prefix", default="",
-                   help="retrieval index file prefix. Will load file %%prefix%%hubert.index.npy/%%prefix%%whisper.index.npy")
+                   help="retrieval index file prefix. Will load file %%prefix%%hubert.index/%%prefix%%whisper.index")
     p.add_argument("--retrieval-ratio", type=float, default=.5, help="ratio of feature retrieval effect. Must be in range 0..1")
     p.add_argument("--n-retrieval-vectors", type=int, default=3, choices=range(1, 9), metavar="[1-8]",
                    help="get n nearest vectors from retrieval index (1..8)")
-    p.add_argument("--hubert-index-path", required=False, help="path to a hubert feature bank (.npy [n, 256])")
-    p.add_argument("--whisper-index-path", required=False, help="path to a whisper feature bank (.npy [n, 1280])")
+    p.add_argument("--hubert-index-path", required=False, help="path to a hubert IVF-Flat .index (or a .npy [n, 256] bank: exact search)")
+    p.add_argument("--whisper-index-path", required=False, help="path to a whisper IVF-Flat .index (or a .npy [n, 1280] bank: exact search)")
     p.add_argument("--whisper", type=str, default=os.path.join("whisper_pretrain", "large-v2.pt"))
     p.add_argument("--hubert", type=str, default=os.path.join("hubert_pretrain", "hubert-soft-0d54a1f4.pt"))
     p.add_argument("--crepe", type=str, default=os.path.join("crepe", "assets", "full.pth"))
