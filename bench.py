@@ -17,6 +17,10 @@ device inside the step.  `--config` selects the other BASELINE.json configuratio
     4  30 s clips per rank through the reference schedule: two 15 s Whisper windows (Tw = 750 each, fp16 GEMM operands like
        the reference's .half() accelerator path), T = 3000 frames -> synthesis chunks [0,2510) / [2490,3000) with the halo
        trim of svc_inference.py:101-131
+Clips in flight (`--inflight`, default 4 for config 1): a step is still ONE batch-1 clip through the whole path, but the K timed steps are
+replayed round-robin on 4 lanes (HIP stream + captured HIP graph + own static buffers each, svcmi/lanes.py), so that one clip's
+latency-bound launches run beside another clip's Whisper GEMMs; `ms_per_step` = wall time / K (the throughput figure), and
+`config.single_stream` carries the same K steps on ONE lane (= the latency of a clip, the round-1 way of running this line).
 With N GPUs every rank runs its own clips (weak scaling; config 3: strong); rank 0 makes and PACKS the weights once and all
 ranks receive the packed arena through one RCCL broadcast per model; the hot loop has no collective.
 
@@ -36,6 +40,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "whisper-vits-svc_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # one hardware queue per lane of clips in flight (svcmi/lanes.py); read at HIP init
 
 import torch  # noqa: E402
 
@@ -361,10 +367,10 @@ def main():
     ap.add_argument("--utterances", type=int, default=512, help="config 3: total utterances of the job")
     ap.add_argument("--eager", action="store_true", help="do not replay a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=1,
+    ap.add_argument("--inflight", type=int, default=None,
                     help="clips (steps) in flight per GPU: N > 1 replays N independently captured graphs round-robin on N HIP streams, so "
-                         "one clip's latency-bound prior / flow / generator launches run beside the next clip's Whisper GEMMs "
-                         "(throughput mode; the judged default is 1 = one clip at a time, ms_per_step = latency)")
+                         "one clip's latency-bound prior / flow / generator launches run beside the next clip's Whisper GEMMs.  Default 4 "
+                         "for config 1 (config.single_stream then reports the one-clip-at-a-time figure too), 1 otherwise")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--precision", default=None, choices=["f32", "bf16x3", "bf16", "f16"],
                     help="GEMM operand precision of BOTH networks (fp32 accumulate in every mode).  Default per config: 1 and 3 f32 "
@@ -374,6 +380,7 @@ def main():
     args.batch = args.batch or d_batch
     args.seconds = args.seconds or d_secs
     args.steps = args.steps if args.steps is not None else (2 if args.config == 3 else 20)
+    args.inflight = args.inflight if args.inflight is not None else (4 if args.config == 1 else 1)
     args.warmup = args.warmup if args.warmup is not None else (1 if args.config == 3 else 3)
     wprec, sprec = (args.precision, args.precision) if args.precision else (d_wprec, d_sprec)
     norm = lambda p: None if p in (None, "f32") else p
@@ -417,50 +424,52 @@ def main():
         whisper.encoder.precision = norm(wprec)
     wl = WORKLOADS[args.config](ops, device, whisper, model, hp, args, rank, world)
 
-    graph = None
-    if not args.eager:
-        if args.config == 3:            # the per-batch pipeline is the graph; the shard loop around it stays on the host
-            g1, gout = build_graph(wl.one_batch)
-            if g1 is not None:
-                wl.graph_one_batch = lambda: (g1.replay(), gout)[1]
-                graph = g1
-        else:
-            graph, gout = build_graph(wl.step)
-    run = (lambda: graph.replay()) if (graph is not None and args.config != 3) else (lambda: wl.step())
-    if args.inflight > 1:
-        assert args.config != 3 and not args.eager, "--inflight needs the captured single-step graph (configs 1, 2, 4)"
-        lanes = []
-        for i in range(args.inflight):      # every lane: own static inputs / outputs, own capture stream (= own split-K workspace)
-            wli = wl if i == 0 else WORKLOADS[args.config](ops, device, whisper, model, hp, args, rank, world)
-            si = torch.cuda.Stream()
-            gi, _ = build_graph(wli.step, stream=si)
-            assert gi is not None, "graph capture failed"
-            lanes.append((si, gi))
-        turn = [0]
+    def timed(run_fn, sync_fn, steps, warmup):
+        for _ in range(warmup):
+            run_fn()
+        sync_fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t_start = time.perf_counter()
+        for _ in range(steps):
+            run_fn()
+        sync_fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t_start
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
 
-        def run():
-            si, gi = lanes[turn[0] % len(lanes)]
-            turn[0] += 1
-            with torch.cuda.stream(si):
-                gi.replay()
-    for _ in range(args.warmup):
-        run()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    graph, lanes, single = None, None, None
+    inflight = 1 if (args.eager or args.config == 3) else args.inflight
+    if not args.eager and args.config == 3:     # the per-batch pipeline is the graph; the shard loop around it stays on the host
+        g1, gout = build_graph(wl.one_batch)
+        if g1 is not None:
+            wl.graph_one_batch = lambda: (g1.replay(), gout)[1]
+            graph = g1
+        run = wl.step
+    elif not args.eager:
+        from svcmi.lanes import GraphLanes
+        # every lane: own static inputs / outputs (its own Workload), own capture stream (= own split-K workspace in Ops)
+        # (lane i of rank r converts the clips seeded r + world * i: every lane its own clip)
+        wls = [wl] + [WORKLOADS[args.config](ops, device, whisper, model, hp, args, rank + world * i, world) for i in range(1, inflight)]
+        lanes = GraphLanes([w.step for w in wls])
+        graph = lanes.graphs[0]
+        if inflight > 1:                          # the same K steps one clip at a time: latency of a clip, reported beside the line
+            dt = timed(lambda: lanes.launch(0), lanes.synchronize, args.steps, args.warmup)
+            single = {"ms_per_step": round(1000.0 * dt / args.steps, 3),
+                      "value": round(wl.audio_seconds_per_step * world / (dt / args.steps), 2)}
+        run = lanes.launch
+    else:
+        run = wl.step
+    elapsed = timed(run, lanes.synchronize if lanes is not None else torch.cuda.synchronize, args.steps, args.warmup)
     ms_per_step = 1000.0 * elapsed / args.steps
     audio_s = wl.total_audio_seconds if wl.scaling == "strong" else wl.audio_seconds_per_step * world
     value = audio_s / (ms_per_step / 1000.0)
@@ -475,9 +484,13 @@ def main():
         "dtype": dtype, "data": "synthetic (seeded mel/vec/F0/speaker, random-init weights of the named architecture)",
         "config": {"workload": f"{wl.workload}; {prec_txt}",
                    "launch": ("hipGraph replay" if graph is not None else "eager") +
-                             (f", {args.inflight} clips in flight on {args.inflight} streams" if args.inflight > 1 else ""),
+                             (f", {inflight} clips in flight (one lane = HIP stream + graph + static buffers each; GPU_MAX_HW_QUEUES="
+                              f"{os.environ.get('GPU_MAX_HW_QUEUES')})" if inflight > 1 else ""),
+                   "clips_in_flight": inflight,
                    "per_gpu_value": round(value / world, 2), "realtime_factor": round(value / world, 2)},
     }
+    if single is not None:
+        out["config"]["single_stream"] = single
     if rank == 0 and not args.no_roofline:
         fn = wl.one_batch if args.config == 3 else wl.step
         agg = roofline_pass(wl, fn)

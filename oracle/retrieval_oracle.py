@@ -111,9 +111,11 @@ def kmeans_faiss(x, k, niter=25, seed=1234, max_points_per_centroid=256):
     for _ in range(niter):
         assign, _ = coarse_assign(x, cent)
         hassign = np.bincount(assign, minlength=k).astype(np.float64)
-        new = np.zeros_like(cent)
-        np.add.at(new, assign, x)                       # rows accumulate in index order (compute_centroids, one slice)
+        new = np.zeros_like(cent)                       # compute_centroids: per-cluster sums of the assigned rows
+        order = np.argsort(assign, kind="stable")
         nz = hassign > 0
+        starts = np.concatenate([[0], np.cumsum(hassign.astype(np.int64))[:-1]])
+        new[nz] = np.add.reduceat(x[order], starts[nz], axis=0)
         new[nz] *= (np.float32(1.0) / hassign[nz].astype(np.float32))[:, None]
         cent = new
         rng = np.random.RandomState(1234)               # split_clusters: RandomGenerator rng(1234)

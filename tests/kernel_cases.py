@@ -253,7 +253,7 @@ def check_ivf_index(ops, device, t=37, n=600, d=32, k=3, ratio=0.5, nlist=9, tmp
     fin = np.isfinite(dist_w)
     assert np.array_equal(np.isfinite(dist), fin) and np.allclose(dist[fin], dist_w[fin], rtol=2e-5), "ivf distances"
     assert np.array_equal(np.isnan(rec), np.isnan(rec_w)) and np.array_equal(rec[~np.isnan(rec)], rec_w[~np.isnan(rec_w)]), "ivf vectors"
-    assert (lab_w[0] >= 0).sum() == max(k - 1, 1), "the thin cell was not probed"
+    assert (lab_w[0] >= 0).sum() == min(len(lists[thin][1]), k) <= max(k - 1, 1), "the thin cell was not probed"
     got = index.retriv(feats)
     _close(torch.from_numpy(got), torch.from_numpy(RO.ivf_retriv(feats, cent, lists, ratio, k)), 2e-5, f"ivf_blend t={t} n={n} d={d} k={k}")
     got_t = index.retriv(torch.from_numpy(feats).to(device))
@@ -266,24 +266,42 @@ def check_ivf_index(ops, device, t=37, n=600, d=32, k=3, ratio=0.5, nlist=9, tmp
     return want_cell
 
 
-def check_ivf_train(ops, device, n=900, d=16, blobs=6, n_ivf=None):
-    """faiss's k-means + add (svcmi.ivf_index.train_kmeans / IvfFlatFeatureIndex.train) vs the numpy restatement on separated blobs:
-    same permutations (std::mt19937 replay), assignments equal, centroids to fp32 summation-order tolerance."""
+def check_ivf_train(ops, device, n=900, d=16, blobs=6, n_ivf=None, exact=True):
+    """faiss's k-means + add (svcmi.ivf_index.train_kmeans / IvfFlatFeatureIndex.train) vs the numpy restatement: same permutations
+    (std::mt19937 replay); ONE Lloyd step from the same start must agree (assignment flips only at fp32 ties); the full 25
+    iterations agree centroid by centroid when the clusters are separated (``exact``: n_ivf <= blobs), and otherwise -- k-means
+    amplifies a single flipped boundary point -- in the quantisation error they reach."""
     from oracle import retrieval_oracle as RO
-    from svcmi.ivf_index import IvfFlatFeatureIndex, faiss_rand_perm, ivf_list_count
+    from svcmi.ivf_index import IvfFlatFeatureIndex, faiss_rand_perm, ivf_list_count, train_kmeans
     g = _g(31 + n + d)
     x = _blobs(g, n, d, centres=blobs, spread=0.5)
+    k = n_ivf or ivf_list_count(n)
     assert np.array_equal(faiss_rand_perm(50, 1235), RO.rand_perm(50, 1235))
+    xd = torch.from_numpy(x).to(device)
+    one = train_kmeans(xd, k, ops, niter=1).cpu().numpy()
+    one_w = RO.kmeans_faiss(x, k, niter=1)
+    close = np.isclose(one, one_w, rtol=1e-4, atol=1e-4).all(1)
+    # |x|^2 + |c|^2 - 2 x.c carries ~1e-7 * |x|^2 of round-off (faiss's own BLAS path does too): at d = 1280 a few of 20 000 boundary
+    # points change cells between two summation orders, each moving two centroids by (x - c) / count
+    assert close.mean() >= 0.95, f"one Lloyd step: {int((~close).sum())} of {k} centroids differ"
+    assert np.abs(one - one_w).max() <= 0.05 * np.abs(one_w).max(), float(np.abs(one - one_w).max())
     index = IvfFlatFeatureIndex.train(x, device=device, ops=ops, n_ivf=n_ivf)
     cent_w, lists_w = RO.ivf_build(x, n_ivf=n_ivf)
-    assert index.nlist == (n_ivf or ivf_list_count(n)) == len(lists_w)
-    _close(index.centroids, torch.from_numpy(cent_w), 2e-5, "k-means centroids")
+    assert index.nlist == k == len(lists_w)
     off = index.list_off.cpu().numpy()
     ids = index.ids.cpu().numpy()
-    same = sum(np.array_equal(ids[off[c]:off[c + 1]], lists_w[c][1]) for c in range(index.nlist))
-    assert same >= index.nlist - 1, f"{index.nlist - same} inverted lists differ"          # a boundary point may flip on round-off
     assert index.ntotal == n and np.array_equal(np.sort(ids), np.arange(n))
     assert np.array_equal(index.bank.cpu().numpy(), x[ids])
+    assert all(np.all(np.diff(ids[off[c]:off[c + 1]]) > 0) for c in range(k)), "rows keep their insertion order inside a cell"
+    if exact:
+        _close(index.centroids, torch.from_numpy(cent_w), 2e-5, "k-means centroids")
+        same = sum(np.array_equal(ids[off[c]:off[c + 1]], lists_w[c][1]) for c in range(k))
+        assert same >= k - 1, f"{k - same} inverted lists differ"          # a boundary point may flip on round-off
+    else:
+        cent = index.centroids.cpu().numpy()
+        err = lambda c: float(RO.coarse_assign(x, c)[1].min(1).mean())
+        e, e_w = err(cent), err(cent_w)
+        assert abs(e - e_w) <= 0.02 * e_w, f"quantisation error {e:.4f} vs restatement {e_w:.4f}"
     return index
 
 

@@ -89,9 +89,9 @@ def test_ivf_index(ops, tmp_path, t, n, d, k, ratio, nlist):
     K.check_ivf_index(ops, "cuda", t, n, d, k, ratio, nlist, tmp_path=tmp_path)
 
 
-@pytest.mark.parametrize("n,d,blobs,n_ivf", [(20000, 256, 24, None), (3000, 64, 10, 40)])
-def test_ivf_train(ops, n, d, blobs, n_ivf):
-    K.check_ivf_train(ops, "cuda", n, d, blobs, n_ivf)
+@pytest.mark.parametrize("n,d,blobs,n_ivf,exact", [(20000, 256, 24, None, False), (3000, 64, 10, 5, True), (3000, 64, 10, 40, False), (20000, 1280, 8, 200, False)])
+def test_ivf_train(ops, n, d, blobs, n_ivf, exact):
+    K.check_ivf_train(ops, "cuda", n, d, blobs, n_ivf, exact)
 
 
 @pytest.mark.parametrize("n,c,B", [(333, 40, 2), (20000, 80, 1), (5000, 160, 1), (80000, 40, 1), (70, 16, 3)])

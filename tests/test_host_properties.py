@@ -130,3 +130,16 @@ def test_streaming_decoder_tiling_covers_every_sample_once(T, S, B):
     m.stream_frames = S
     tiled = m._generator(w, None, z, None, src)
     assert tiled.shape == whole.shape == (B, 1, T * hop) and torch.equal(tiled, whole)
+
+
+def test_graph_lanes_refuse_to_run_without_a_gpu():
+    """Clips in flight are HIP streams + graphs: no CPU stand-in."""
+    import torch
+    from svcmi.lanes import GraphLanes, want_hw_queues
+    want_hw_queues(8)
+    import os
+    assert os.environ["GPU_MAX_HW_QUEUES"].isdigit()
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError):
+        GraphLanes([lambda: None])

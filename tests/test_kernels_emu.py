@@ -74,9 +74,9 @@ def test_ivf_index(ops, tmp_path, t, n, d, k, ratio, nlist):
     K.check_ivf_index(ops, "cpu", t, n, d, k, ratio, nlist, tmp_path=tmp_path)
 
 
-@pytest.mark.parametrize("n,d,blobs,n_ivf", [(240, 8, 4, None), (150, 8, 3, 5)])
-def test_ivf_train(ops, n, d, blobs, n_ivf):
-    K.check_ivf_train(ops, "cpu", n, d, blobs, n_ivf)
+@pytest.mark.parametrize("n,d,blobs,n_ivf,exact", [(240, 8, 8, None, True), (150, 8, 3, 5, False)])
+def test_ivf_train(ops, n, d, blobs, n_ivf, exact):
+    K.check_ivf_train(ops, "cpu", n, d, blobs, n_ivf, exact)
 
 
 @pytest.mark.parametrize("n,c", [(150, 40), (70, 80), (90, 16), (40, 32)])
