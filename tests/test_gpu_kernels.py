@@ -89,7 +89,7 @@ def test_ivf_index(ops, tmp_path, t, n, d, k, ratio, nlist):
     K.check_ivf_index(ops, "cuda", t, n, d, k, ratio, nlist, tmp_path=tmp_path)
 
 
-@pytest.mark.parametrize("n,d,blobs,n_ivf,exact", [(20000, 256, 24, None, False), (3000, 64, 10, 5, True), (3000, 64, 10, 40, False), (20000, 1280, 8, 200, False)])
+@pytest.mark.parametrize("n,d,blobs,n_ivf,exact", [(20000, 256, 24, None, False), (3000, 64, 10, 5, True), (3000, 64, 10, 40, False), (20000, 1280, 12, 8, True)])
 def test_ivf_train(ops, n, d, blobs, n_ivf, exact):
     K.check_ivf_train(ops, "cuda", n, d, blobs, n_ivf, exact)
 
