@@ -154,19 +154,40 @@ class ShardedUtterances(Workload):
         self.outputs = torch.empty(len(ids), 1, self.T * 320, device=device)     # the converted shard stays in HBM
         self.workload = (f"configs[3]: {args.utterances} x {args.seconds:g}s utterances sharded over {world} GPU(s) ({len(ids)} on this rank), "
                          f"batches of {self.B}, full pipeline incl. Whisper-24L")
-        self.graph_one_batch = None
+        self.lanes, self.lane_inputs = None, [(self.mel, self.vec, self.pit, self.spk)]
 
     def one_batch(self, noise=None):
         return Workload.step(self, noise)
 
+    def lane_fn(self, lane):
+        """The per-batch pipeline on lane ``lane``'s own static inputs (lane 0: the tensors ``one_batch`` uses)."""
+        while len(self.lane_inputs) <= lane:
+            self.lane_inputs.append(tuple(t.clone() for t in self.lane_inputs[0]))
+        mel, vec, pit, spk = self.lane_inputs[lane]
+        m = self.model
+
+        def fn():
+            ppg50 = self.whisper.encoder(mel, torch.randn_like(mel), 0.1)[:, :self.keep]
+            return m.inference_ppg50(ppg50, vec, pit, spk, self.lengths, m.pitch2source(pit))
+        return fn
+
     def step(self, noise=None):
+        """One pass over this rank's shard: batch j runs on lane j % lanes (stage-in copy, graph replay and stage-out copy all on
+        that lane's stream), so consecutive batches overlap; without lanes (--eager) the batches run back to back."""
         done = 0
-        for b in self.batches:
+        for j, b in enumerate(self.batches):
             n = len(b)
-            for dst, src in zip((self.mel, self.vec, self.pit, self.spk), self.all):
-                dst[:n].copy_(src[done:done + n])
-            out = self.graph_one_batch() if self.graph_one_batch is not None else self.one_batch()
-            self.outputs[done:done + n].copy_(out[:n])
+            if self.lanes is None:
+                for dst, src in zip(self.lane_inputs[0], self.all):
+                    dst[:n].copy_(src[done:done + n])
+                self.outputs[done:done + n].copy_(self.one_batch()[:n])
+            else:
+                l = j % len(self.lanes)
+                with torch.cuda.stream(self.lanes.streams[l]):
+                    for dst, src in zip(self.lane_inputs[l], self.all):
+                        dst[:n].copy_(src[done:done + n])
+                    self.lanes.graphs[l].replay()
+                    self.outputs[done:done + n].copy_(self.lanes.outputs[l][:n])
             done += n
         return self.outputs
 
@@ -381,7 +402,7 @@ def main():
     args.batch = args.batch or d_batch
     args.seconds = args.seconds or d_secs
     args.steps = args.steps if args.steps is not None else (2 if args.config == 3 else 20)
-    args.inflight = args.inflight if args.inflight is not None else (4 if args.config == 1 else 1)
+    args.inflight = args.inflight if args.inflight is not None else {1: 4, 2: 3, 3: 2, 4: 4}[args.config]
     args.warmup = args.warmup if args.warmup is not None else (1 if args.config == 3 else 3)
     wprec, sprec = (args.precision, args.precision) if args.precision else (d_wprec, d_sprec)
     norm = lambda p: None if p in (None, "f32") else p
@@ -449,12 +470,11 @@ def main():
         return dt
 
     graph, lanes, single = None, None, None
-    inflight = 1 if (args.eager or args.config == 3) else args.inflight
-    if not args.eager and args.config == 3:     # the per-batch pipeline is the graph; the shard loop around it stays on the host
-        g1, gout = build_graph(wl.one_batch)
-        if g1 is not None:
-            wl.graph_one_batch = lambda: (g1.replay(), gout)[1]
-            graph = g1
+    inflight = 1 if args.eager else args.inflight
+    if not args.eager and args.config == 3:     # the per-batch pipeline is the graph (one per lane); the shard loop around it stays on the host
+        from svcmi.lanes import GraphLanes
+        lanes = wl.lanes = GraphLanes([wl.lane_fn(l) for l in range(inflight)])
+        graph = lanes.graphs[0]
         run = wl.step
     elif not args.eager:
         from svcmi.lanes import GraphLanes
