@@ -2,6 +2,7 @@
 HuBERT window plans, the pitch shift and CSV round trip, and the LPT sharding -- the product's copies against the oracle's
 restatements and against the invariants the reference's loops rely on."""
 import numpy as np
+import pytest
 from hypothesis import given, settings, strategies as st
 
 from oracle import svc_oracle as O
