@@ -23,7 +23,8 @@ class AudioEncoder:
         # N = n_state projections, and the 64x80 tile of the 16x16x4 policy where it balances the 256 CUs better than
         # 64x64 (N = 5120 -> 8 x 64 = 512 blocks; N = 1280 with 2-4 K slices); the QKV projection stays on 64x64.
         self.split_o, self.split_mlp = 2, 4
-        self.tile_o = self.tile_mlp = 6          # SVCMI_CONV_TILE_P16_64x80 >> 8
+        self.tile_qkv = 0                        # 0 = library heuristic (64x64 at M = 500)
+        self.tile_o = self.tile_mlp1 = self.tile_mlp2 = 6          # SVCMI_CONV_TILE_P16_64x80 >> 8
         # GEMM operand precision of this encoder: None = fp32 (parity default); "bf16x3" / "bf16" / "f16" (the reference's
         # own accelerator path is fp16: whisper/inference.py:22-23,43-44) route the linear layers through
         # svcmi_conv_gemm_lp.  LayerNorm, softmax, GELU, residual stream and accumulation stay fp32 in every mode.
@@ -45,7 +46,7 @@ class AudioEncoder:
         lp = ops.precision != 0
         split_o, split_mlp = (self.lp_split_o, self.lp_split_mlp) if lp else (self.split_o, self.split_mlp)
         tile_qkv, tile_o, tile_m1, tile_m2 = (self.lp_tile_qkv, self.lp_tile_o, self.lp_tile_mlp1, self.lp_tile_mlp2) if lp else \
-            (0, self.tile_o, self.tile_mlp, self.tile_mlp)
+            (self.tile_qkv, self.tile_o, self.tile_mlp1, self.tile_mlp2)
         if mel.shape[0] * ((mel.shape[2] + 1) // 2) > self.small_m_rows:
             # batched windows (BASELINE.json configs[3] / [4]): M = B * Tw rows fill the chip with large tiles; the K slices and
             # the 64x80 tiles above are a single-window (M = 500 .. 750) tuning
