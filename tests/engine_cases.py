@@ -395,3 +395,25 @@ def check_clips_in_flight(ops, device, lanes=3, rounds=3, T=300, layers=4):
         assert torch.equal(L.outputs[i], want[i]), f"lane {i}: max diff {float((L.outputs[i] - want[i]).abs().max()):.3e}"
     i = L.launch()
     assert torch.equal(L.wait(i), want[i]) and len(L) == lanes
+
+
+def check_chunk_streams(ops, device, T=5300, streams=3):
+    """svc_infer with the synthesis chunks of one clip in flight on ``streams`` HIP streams vs one after the other: same launches, pinned
+    noise -> bit-identical waveform (3 chunks: full, full, remainder)."""
+    from svcmi import DummyRetrieval, svc_infer
+    hp = C.tiny_hp()
+    m, _ = make_model(hp, ops, device)
+    d = I.synth_clip(T=T, hp=hp, seed=4, B=1)
+    gen = torch.Generator().manual_seed(78)
+    plan = O.chunk_schedule(T, 320)
+    assert len(plan) >= 3
+    enc_noises = [torch.randn(1, hp.vits.inter_channels, ce - cs, generator=gen) for (cs, ce, _, _) in plan]
+    args = (m, DummyRetrieval(), d["spk"][0], d["pit"][0], d["ppg"][0], d["vec"][0], hp, device)
+    kw = dict(noise={"rand_ini": d["rand_ini"], "src_noise": d["src_noise"], "enc_noises": enc_noises}, write_pit_wav=False)
+    m.chunk_streams = 1
+    want = svc_infer(*args, **kw)
+    m.chunk_streams = streams
+    for _ in range(3):
+        got = svc_infer(*args, **kw)
+        assert np.array_equal(got, want), float(np.abs(got - want).max())
+    assert len(m.__dict__.get("_svcmi_chunk_streams", [])) == (streams if str(device) != "cpu" else 0)

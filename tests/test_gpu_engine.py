@@ -219,6 +219,10 @@ def test_clips_in_flight_are_bit_identical_to_single_stream(ops):
     E.check_clips_in_flight(ops, "cuda")
 
 
+def test_svc_infer_chunks_in_flight_are_bit_identical(ops):
+    E.check_chunk_streams(ops, "cuda")
+
+
 def test_whisper_10s_against_oracle(ops):
     """Whisper-24L at the 10 s shape: mel [1,80,1000] -> [1,500,1280] vs the oracle."""
     from svcmi.whisper.inference import load_model

@@ -6,6 +6,7 @@ launches one kernel on the current stream and returns its output tensor.
 """
 import contextlib
 import ctypes
+import os
 
 import torch
 
@@ -24,6 +25,9 @@ class Ops:
     same kernel source and passes it in explicitly)."""
 
     def __init__(self, lib=None):
+        # streams that should overlap (clips / chunks in flight, lanes.py) each need their own hardware queue; the runtime reads
+        # this when HIP initialises, so it only helps if no HIP call was made yet (the CLIs set it first thing)
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
         self.lib = lib if lib is not None else _lib.load_library()
         self.build = self.lib.svcmi_build_info().decode()
         self.on_gpu = self.build.startswith("hip")

@@ -13,6 +13,8 @@ a chunk, so the schedule is part of the numerics; the final sample is dropped be
 import os
 
 import numpy as np
+import contextlib
+
 import torch
 
 from .vits import consts as K
@@ -74,6 +76,16 @@ def chunk_schedule(all_frame, hop_size, out_chunk=K.CHUNK_FRAMES, hop_frame=K.HA
     return plan
 
 
+def _chunk_streams(model, dev, n):
+    """``n`` side streams cached on the model (none for n <= 1)."""
+    if n <= 1:
+        return []
+    pool = model.__dict__.setdefault("_svcmi_chunk_streams", [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=dev))
+    return pool[:n]
+
+
 @torch.no_grad()
 def svc_infer(model, retrieval, spk, pit, ppg, vec, hp, device, noise=None, write_pit_wav=True, return_tensor=False):
     """svc_inference.py:77-134.  spk [spk_dim], pit [T] Hz, ppg [T, ppg_dim], vec [T, vec_dim] (already
@@ -95,18 +107,33 @@ def svc_infer(model, retrieval, spk, pit, ppg, vec, hp, device, noise=None, writ
     retrieval = retrieval if retrieval is not None else DummyRetrieval()
     passthrough = isinstance(retrieval, DummyRetrieval)
     pieces = []
-    for i, (cs, ce, cso, ceo) in enumerate(chunk_schedule(n, hop)):
-        sub_ppg, sub_vec = ppg[cs:ce], vec[cs:ce]
-        if getattr(retrieval, "on_device", False):      # svcmi.feature_retrieval.KnnIndexRetrieval: the GPU kNN blend
-            sub_ppg, sub_vec = retrieval.retriv_whisper(sub_ppg), retrieval.retriv_hubert(sub_vec)
-        elif not passthrough:      # user hook works on CPU tensors (feature_retrieval/retrieval.py:11-28)
-            sub_ppg = retrieval.retriv_whisper(sub_ppg.cpu()).to(dev)
-            sub_vec = retrieval.retriv_hubert(sub_vec.cpu()).to(dev)
-        sub_len = torch.tensor([ce - cs], dtype=torch.int64)
-        enc_noise = None if noise is None else noise["enc_noises"][i]
-        sub_out = model.inference(sub_ppg.unsqueeze(0), sub_vec.unsqueeze(0), pit[cs:ce].unsqueeze(0), spk, sub_len,
-                                  source[:, :, cs * hop:ce * hop], noise=enc_noise)
-        pieces.append(sub_out[0, 0, cso:ceo])
+    plan = chunk_schedule(n, hop)
+    # Chunks are independent once the source is made: with ``model.chunk_streams = N`` > 1 they are issued round-robin on N HIP streams
+    # (clips in flight, svcmi/lanes.py: one chunk's latency-bound launches run beside another chunk's GEMMs); same launches, same
+    # results.  User retrieval hooks work on CPU tensors and keep the serial order.
+    side = []
+    if dev.type == "cuda" and len(plan) > 1 and (passthrough or getattr(retrieval, "on_device", False)):
+        side = _chunk_streams(model, dev, min(int(getattr(model, "chunk_streams", 1) or 1), len(plan)))
+    main_stream = torch.cuda.current_stream(dev) if side else None
+    for s in side:
+        s.wait_stream(main_stream)
+    for i, (cs, ce, cso, ceo) in enumerate(plan):
+        with (torch.cuda.stream(side[i % len(side)]) if side else contextlib.nullcontext()):
+            sub_ppg, sub_vec = ppg[cs:ce], vec[cs:ce]
+            if getattr(retrieval, "on_device", False):      # svcmi.feature_retrieval.KnnIndexRetrieval: the GPU kNN blend
+                sub_ppg, sub_vec = retrieval.retriv_whisper(sub_ppg), retrieval.retriv_hubert(sub_vec)
+            elif not passthrough:      # user hook works on CPU tensors (feature_retrieval/retrieval.py:11-28)
+                sub_ppg = retrieval.retriv_whisper(sub_ppg.cpu()).to(dev)
+                sub_vec = retrieval.retriv_hubert(sub_vec.cpu()).to(dev)
+            sub_len = torch.tensor([ce - cs], dtype=torch.int64)
+            enc_noise = None if noise is None else noise["enc_noises"][i]
+            sub_out = model.inference(sub_ppg.unsqueeze(0), sub_vec.unsqueeze(0), pit[cs:ce].unsqueeze(0), spk, sub_len,
+                                      source[:, :, cs * hop:ce * hop], noise=enc_noise)
+            pieces.append(sub_out[0, 0, cso:ceo])
+    for s in side:
+        main_stream.wait_stream(s)
+    for p in pieces if side else ():
+        p.record_stream(main_stream)              # allocated on a side stream, read by the concatenation below
     out = torch.cat(pieces)
     return out if return_tensor else out.cpu().numpy()
 
@@ -206,4 +233,6 @@ def build_parser():
 
 
 if __name__ == "__main__":
+    from svcmi.lanes import want_hw_queues
+    want_hw_queues()                      # before the first HIP call: the chunk streams of svc_infer get their own hardware queues
     main(build_parser().parse_args())

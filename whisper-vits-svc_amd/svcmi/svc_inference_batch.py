@@ -121,6 +121,8 @@ def build_parser():
 
 
 if __name__ == "__main__":
+    from svcmi.lanes import want_hw_queues
+    want_hw_queues()                      # before the first HIP call: the chunk streams of svc_infer get their own hardware queues
     run_batch(build_parser().parse_args())
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()

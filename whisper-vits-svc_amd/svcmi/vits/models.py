@@ -41,6 +41,10 @@ class SynthesizerInfer:
         # off in this mode: its slice count would otherwise follow the problem size).  The reference's own chunk seams
         # (svc_inference.py:94-131) are untouched: tiling happens inside a chunk.
         self.stream_frames = None
+        # svc_infer: synthesis chunks of one clip in flight on this many HIP streams (1 = one after the other, the reference's order);
+        # results do not depend on it (bit-identical, tests/test_gpu_engine.py); a 3-minute song: 59.3 -> 48.4 ms with 3 streams
+        # (profiles/r02w_chunk_streams.log).
+        self.chunk_streams = 3
         self._streams, self._streams_dev = None, None
 
     # ------------------------------------------------------------------ nn.Module-like surface
