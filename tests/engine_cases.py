@@ -417,3 +417,19 @@ def check_chunk_streams(ops, device, T=5300, streams=3):
         got = svc_infer(*args, **kw)
         assert np.array_equal(got, want), float(np.abs(got - want).max())
     assert len(m.__dict__.get("_svcmi_chunk_streams", [])) == (streams if str(device) != "cpu" else 0)
+
+
+def check_hubert_windows_batched(ops, device, dims, seconds=45.0):
+    """pred_vec's 20 s window loop with equal windows as one batch vs one window at a time: same units (fp32 round-off)."""
+    from svcmi.hubert import load_model
+    from svcmi.hubert.inference import units_windowed, window_plan
+    m = load_model(W.make_hubert_state(dims), device, ops=ops)
+    audio = (torch.randn(int(seconds * 16000), generator=torch.Generator().manual_seed(8)) * 0.3).numpy()
+    plan = window_plan(audio.shape[0])
+    assert len(plan) == 3 and plan[0][1] - plan[0][0] == plan[1][1] - plan[1][0] != plan[2][1] - plan[2][0]
+    got = units_windowed(m, audio)
+    solo = units_windowed(m, audio, max_batch=1)
+    assert got.shape == solo.shape
+    err = maxerr(got, solo.cpu())
+    assert err <= 2e-5 * max(1.0, float(solo.abs().max())), err
+    return err

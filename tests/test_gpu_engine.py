@@ -65,6 +65,10 @@ def test_hubert_soft_10s_against_oracle(ops):
     print(E.check_hubert_against_oracle(ops, "cuda", C.HUBERT_SOFT, n=160000, heads=12))
 
 
+def test_hubert_equal_windows_run_as_one_batch(ops):
+    E.check_hubert_windows_batched(ops, "cuda", C.HUBERT_SOFT)
+
+
 def test_hubert_tiny_against_oracle(ops):
     print(E.check_hubert_against_oracle(ops, "cuda", C.HUBERT_TINY_TEST, n=4000, heads=4))
 
@@ -265,28 +269,33 @@ def test_outlier_stress_weights_against_oracle(ops):
 
 
 def test_pred_ppg_two_windows_against_oracle(ops):
-    """Row a2 (whisper/inference.py:32-62): a 18.2 s clip = one full 15 s window (n = 1500 mel frames, Tw = 750, all kept)
-    + a ragged remainder window (odd mel length, kept = samples // 320 < Tw) through ``pred_ppg_from_mel`` with explicit
-    noise, against ``oracle.pred_ppg_from_mel``: values, window seam and total length."""
+    """Row a2 (whisper/inference.py:32-62): a 33.2 s clip = two full 15 s windows (n = 1500 mel frames, Tw = 750, all kept; the engine
+    runs them as one batch) + a ragged remainder window (odd mel length, kept = samples // 320 < Tw) through ``pred_ppg_from_mel``
+    with explicit noise, against ``oracle.pred_ppg_from_mel`` (window by window, as the reference does): values, window seams and
+    total length; and the batched windows against the same windows run solo."""
     from svcmi.whisper.inference import load_model, pred_ppg_from_mel, window_plan
     ck = W.make_whisper_state(C.WHISPER_LARGE_V2)
     wm = load_model(ck, "cuda", ops=ops)
-    n_samples = 15 * 16000 + 51733
+    n_samples = 2 * 15 * 16000 + 51733
     plan = window_plan(n_samples)
-    assert [(e - s_) for (s_, e, _) in plan] == [240000, 51733] and [k for (_, _, k) in plan] == [750, 161]
+    assert [(e - s_) for (s_, e, _) in plan] == [240000, 240000, 51733] and [k for (_, _, k) in plan] == [750, 750, 161]
     g = torch.Generator().manual_seed(23)
     mels = [(torch.randn(80, (e - s_) // 160, generator=g) * 0.5).clamp(-1, 1.5) for (s_, e, _) in plan]      # audio.py:87: n // 160 frames
     noises = [torch.randn(m_.shape, generator=g) for m_ in mels]
     keep = [k for (_, _, k) in plan]
-    assert mels[1].shape[1] == 323 and (mels[1].shape[1] + 1) // 2 == 162 > keep[1]                            # the trim really drops a frame
+    assert mels[2].shape[1] == 323 and (mels[2].shape[1] + 1) // 2 == 162 > keep[2]                            # the trim really drops a frame
     got = pred_ppg_from_mel(wm, mels, keep, mel_noises=[z.cuda() for z in noises])
+    solo = pred_ppg_from_mel(wm, mels, keep, mel_noises=[z.cuda() for z in noises], max_batch=1)
     with torch.no_grad():
         ref = O.pred_ppg_from_mel(ck["model_state_dict"], C.WHISPER_LARGE_V2, mels, noises, keep)
-    assert got.shape == ref.shape == (750 + 161, 1280)
+    assert got.shape == ref.shape == (1500 + 161, 1280)
     scale = float(ref.abs().max())
-    err_w1, err_w2 = E.maxerr(got[:750], ref[:750]), E.maxerr(got[750:], ref[750:])
-    print(f"pred_ppg 2 windows: err window 1 (Tw=750) {err_w1:.2e}, window 2 (Tw=162, kept 161) {err_w2:.2e}, |ppg|max {scale:.2f}")
-    assert max(err_w1, err_w2) <= 1e-4 * max(1.0, scale)
+    errs = [E.maxerr(got[a:b], ref[a:b]) for a, b in ((0, 750), (750, 1500), (1500, 1661))]
+    err_solo = E.maxerr(solo, ref)
+    print(f"pred_ppg 3 windows: err windows 1 + 2 (Tw=750, one batch) {errs[0]:.2e} {errs[1]:.2e}, window 3 (Tw=162, kept 161) {errs[2]:.2e}, "
+          f"solo windows {err_solo:.2e}, |ppg|max {scale:.2f}")
+    assert max(errs + [err_solo]) <= 1e-4 * max(1.0, scale)
+    assert torch.equal(got[1500:], solo[1500:])                 # the remainder window is the same launch either way
 
 
 def test_cli_main_wav_to_wav(ops, tmp_path, monkeypatch):

@@ -101,5 +101,19 @@ def pred_vec(model, wavPath, vecPath, device):
     """hubert/inference.py:25-50: float32 [T, 256] .npy (hop 320)."""
     from ..whisper.audio import load_audio
     audio = load_audio(wavPath)
-    out = [model.units(torch.from_numpy(audio[s:e]).view(1, 1, -1))[0] for (s, e) in window_plan(audio.shape[0])]
-    np.save(vecPath, torch.cat(out, 0).cpu().numpy(), allow_pickle=False)
+    np.save(vecPath, units_windowed(model, audio).cpu().numpy(), allow_pickle=False)
+
+
+@torch.no_grad()
+def units_windowed(model, audio, max_batch=8):
+    """The reference's 20 s window loop (hubert/inference.py:31-48); consecutive windows of equal length run as one batch."""
+    plan = window_plan(audio.shape[0])
+    out, i = [], 0
+    while i < len(plan):
+        j = i + 1
+        while j < len(plan) and j - i < max_batch and plan[j][1] - plan[j][0] == plan[i][1] - plan[i][0]:
+            j += 1
+        wav = torch.stack([torch.from_numpy(audio[s:e]) for (s, e) in plan[i:j]]).unsqueeze(1)
+        out.extend(model.units(wav))
+        i = j
+    return torch.cat(out, 0)

@@ -108,17 +108,24 @@ def load_model(path, device, ops=None):
 
 
 @torch.no_grad()
-def pred_ppg_from_mel(whisper, mels, kept_frames, mel_noises=None):
+def pred_ppg_from_mel(whisper, mels, kept_frames, mel_noises=None, max_batch=8):
     """The encoder half of whisper/inference.py:32-62 starting at the mel tensor (the hot-path contract
     starts there): per 15 s window ``mel + 0.1*randn`` (:46,58) -> encoder -> first
-    ``len//320`` frames (:40,48).  Returns a device tensor [T50, state]."""
-    out = []
-    for i, (mel, keep) in enumerate(zip(mels, kept_frames)):
-        dev = whisper.device
-        mel = mel.to(dev, torch.float32)
-        nz = torch.randn_like(mel) if mel_noises is None else mel_noises[i]
-        ppg = whisper.encoder(mel.unsqueeze(0), nz.unsqueeze(0), 0.1)[0]
-        out.append(ppg[:keep])
+    ``len//320`` frames (:40,48).  Returns a device tensor [T50, state].  The reference runs the windows one after the other; they are
+    independent, so consecutive windows of equal length (all but the remainder window) go through the encoder as ONE batch of up to
+    ``max_batch`` -- M = B * 750 rows fill the chip where a single window's GEMMs are launch-bound (bench.py configs[4] times exactly
+    this)."""
+    out, i, dev = [None] * len(mels), 0, whisper.device
+    while i < len(mels):
+        j = i + 1
+        while j < len(mels) and j - i < max_batch and mels[j].shape == mels[i].shape:
+            j += 1
+        mel = torch.stack([m.to(dev, torch.float32) for m in mels[i:j]])
+        nz = torch.randn_like(mel) if mel_noises is None else torch.stack([z.to(dev, torch.float32) for z in mel_noises[i:j]])
+        ppg = whisper.encoder(mel, nz, 0.1)
+        for k in range(i, j):
+            out[k] = ppg[k - i, :kept_frames[k]]
+        i = j
     return torch.cat(out, 0)
 
 
