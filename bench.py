@@ -93,13 +93,11 @@ class Workload:
                          f"+ base.yaml prior/flow/NSF-BigVGAN")
 
     def step(self, noise=None):
-        """The timed unit.  noise=None draws on the device (as the reference does per call)."""
-        m = self.model
-        mel_noise = torch.randn_like(self.mel) if noise is None else noise["mel_noise"]
-        ppg50 = self.whisper.encoder(self.mel, mel_noise, 0.1)[:, :self.keep]
-        src = m.pitch2source(self.pit, noise=None if noise is None else (noise["rand_ini"], noise["src_noise"]))
-        return m.inference_ppg50(ppg50, self.vec, self.pit, self.spk, self.lengths, src,
-                                 noise=None if noise is None else noise["enc_noise"])
+        """The timed unit (svcmi.serving.convert_step on this workload's tensors).  noise=None draws on the device (as the reference
+        does per call)."""
+        from svcmi.serving import convert_step
+        buf = dict(mel=self.mel, vec=self.vec, pit=self.pit, spk=self.spk, lengths=self.lengths)
+        return convert_step(self.model, self.whisper, buf, self.keep, noise)
 
 
 class FlowDecoderBatch(Workload):
@@ -481,7 +479,14 @@ def main():
         # every lane: own static inputs / outputs (its own Workload), own capture stream (= own split-K workspace in Ops)
         # (lane i of rank r converts the clips seeded r + world * i: every lane its own clip)
         wls = [wl] + [WORKLOADS[args.config](ops, device, whisper, model, hp, args, rank + world * i, world) for i in range(1, inflight)]
-        lanes = GraphLanes([w.step for w in wls])
+        if args.config == 1:       # the product's serving object: N lanes of one (B, T) bucket, every lane staged with its own clip
+            from svcmi.serving import ClipLanes
+            cl = ClipLanes(model, whisper, wl.T, wl.B, lanes=inflight, device=device)
+            for i, w in enumerate(wls):
+                cl.stage(i, mel=w.mel, vec=w.vec, pit=w.pit, spk=w.spk, lengths=w.lengths)
+            lanes = cl.capture().lanes
+        else:
+            lanes = GraphLanes([w.step for w in wls])
         graph = lanes.graphs[0]
         if inflight > 1 and not args.no_single_stream:   # the same K steps one clip at a time: latency of a clip, reported beside the line
             dt = timed(lambda: lanes.launch(0), lanes.synchronize, args.steps, args.warmup)

@@ -433,3 +433,32 @@ def check_hubert_windows_batched(ops, device, dims, seconds=45.0):
     err = maxerr(got, solo.cpu())
     assert err <= 2e-5 * max(1.0, float(solo.abs().max())), err
     return err
+
+
+def check_clip_lanes(ops, device, lanes=3, requests=7, T=300, layers=4):
+    """svcmi.serving.ClipLanes: ``requests`` different clips (own inputs, pinned noise, one of them ragged) submitted through ``lanes`` lanes,
+    collected in order, each against the same conversion run eagerly on the current stream -- bit-identical."""
+    from svcmi.serving import ClipLanes, convert_step
+    from svcmi.whisper.inference import load_model
+    hp = C.base_hp()
+    m, _ = make_model(hp, ops, device)
+    wm = load_model(W.make_whisper_state(dict(C.WHISPER_LARGE_V2, n_audio_layer=layers)), device, ops=ops)
+    cl = ClipLanes(m, wm, T, B=1, lanes=lanes, device=device, pinned_noise=True)
+    reqs, want = [], []
+    for i in range(requests):
+        d = {k: v.to(device) for k, v in I.synth_clip(T=T, hp=hp, seed=70 + i, B=1, ppg=False).items()}
+        lens = torch.tensor([T if i != 2 else T - 37], dtype=torch.int32, device=device)
+        noise = {k: d[k] for k in ("mel_noise", "rand_ini", "src_noise", "enc_noise")}
+        buf = dict(mel=d["mel"], vec=d["vec"], pit=d["pit"], spk=d["spk"], lengths=lens)
+        reqs.append((buf, noise))
+        want.append(convert_step(m, wm, buf, T // 2, noise).clone())
+    pending, got = [], []
+    for buf, noise in reqs:
+        if len(pending) == lanes:                         # all lanes busy: collect the oldest first
+            got.append(cl.result(pending.pop(0)))
+        pending.append(cl.submit(noise=noise, lengths=buf["lengths"], **{k: buf[k] for k in ("mel", "vec", "pit", "spk")}))
+    got += [cl.result(t) for t in pending]
+    assert len(got) == requests
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert torch.equal(g, w), f"request {i}: max diff {float((g - w).abs().max()):.3e}"
+    assert not torch.equal(want[0], want[1])

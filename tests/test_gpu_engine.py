@@ -223,6 +223,10 @@ def test_clips_in_flight_are_bit_identical_to_single_stream(ops):
     E.check_clips_in_flight(ops, "cuda")
 
 
+def test_clip_lanes_serving_object_matches_eager_conversions(ops):
+    E.check_clip_lanes(ops, "cuda")
+
+
 def test_svc_infer_chunks_in_flight_are_bit_identical(ops):
     E.check_chunk_streams(ops, "cuda")
 
