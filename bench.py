@@ -41,7 +41,8 @@ for p in (ROOT, os.path.join(ROOT, "whisper-vits-svc_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # one hardware queue per lane of clips in flight (svcmi/lanes.py); read at HIP init
+if not os.environ.get("GPU_MAX_HW_QUEUES", "").isdigit() or int(os.environ["GPU_MAX_HW_QUEUES"]) < 8:
+    os.environ["GPU_MAX_HW_QUEUES"] = "8"         # one hardware queue per lane of clips in flight (svcmi/lanes.py); read at HIP init
 
 import torch  # noqa: E402
 
