@@ -1,65 +1,61 @@
 #!/usr/bin/env python
-"""In-situ wall time of each pipeline segment on the GPU box: the bench step is captured as HIP graphs that stop after
-successive segments (whisper | prior encoder | flow | generator pre | stage 0..4 | output layer) and the replay times are
-differenced.  Unlike a rocprofv3 trace this measures the un-instrumented graph, multi-stream overlap included.
-Usage: python scripts/stage_times.py [--ungrouped [--streams]]"""
+"""In-situ time of each segment of the synthesizer on the GPU box, one clip at a time and with clips in flight: the synthesizer is
+captured as HIP graphs that stop after successive segments (pitch2source + prior encoder | flow | generator pre | stage 0..4 | output
+layer), replayed on 1 and 4 lanes (svcmi.lanes.GraphLanes) and differenced.  Unlike a rocprofv3 trace this measures the un-instrumented
+graphs, overlap included (rocprofv3 serialises the hardware queues).  Usage: python scripts/stage_times.py [precision]"""
 import os
 import sys
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "whisper-vits-svc_amd")):
     sys.path.insert(0, p)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch  # noqa: E402
 
-import bench  # noqa: E402
-from svcmi import Ops  # noqa: E402
-from workload import config as C  # noqa: E402
-from workload import weights as W  # noqa: E402
+from svcmi import Ops, SynthesizerInfer, weights as PW  # noqa: E402
+from svcmi.lanes import GraphLanes  # noqa: E402
+from workload import config as C, inputs as I, weights as W  # noqa: E402
 
 
-def replay_ms(g, iters=30):
-    for _ in range(3):
-        g.replay()
+def rate(lanes, clips=32):
+    for _ in range(2 * len(lanes)):
+        lanes.launch()
+    lanes.synchronize()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        g.replay()
-    e1.record()
+    t = time.perf_counter()
+    for _ in range(clips):
+        lanes.launch()
+    lanes.synchronize()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters
+    return (time.perf_counter() - t) / clips * 1e3
 
 
 def main():
+    prec = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] != "f32" else None
+    dev = torch.device("cuda")
     ops = Ops()
     hp = C.base_hp()
-    wl = bench.Workload(ops, "cuda", 1, 10.0, W.make_whisper_state(C.WHISPER_LARGE_V2), W.make_vits_state(hp, seed=1234), hp, seed=100)
-    if "--ungrouped" in sys.argv:        # the pre-r01i structure: one launch per AMP block and step (serial, or forked streams)
-        wl.model.grouped_blocks = False
-        wl.model.parallel_blocks = "--streams" in sys.argv
-    full_step = wl.step
+    model = SynthesizerInfer(hp.data.filter_length // 2 + 1, hp.data.segment_size // hp.data.hop_length, hp, ops=ops)
+    model.load_packed(PW.VitsWeights(W.make_vits_state(hp, seed=1234), hp, dev), dev)
+    model.precision = prec
 
-    def whisper_only():
-        mel_noise = torch.randn_like(wl.mel)
-        return wl.whisper.encoder(wl.mel, mel_noise, 0.1)[:, :wl.keep]
+    def syn_fn(i):
+        d = I.synth_clip(T=1000, hp=hp, seed=100 + i, B=1, ppg=False)
+        vec, pit, spk, lens = d["vec"].to(dev), d["pit"].to(dev), d["spk"].to(dev), d["lengths"].to(dev, torch.int32)
+        ppg50 = torch.randn(1, 500, 1280, device=dev)
+        return lambda: model.inference_ppg50(ppg50, vec, pit, spk, lens, model.pitch2source(pit))
 
-    stops = [("whisper", None), ("prior", "prior"), ("flow", "flow"), ("gen_pre", "gen_pre")] + \
-            [(f"stage{i}", ("stage", i)) for i in range(5)] + [("post", "full")]
-    prev, rows = 0.0, []
+    stops = [("source+prior", "prior"), ("flow", "flow"), ("gen_pre", "gen_pre")] + [(f"stage{i}", ("stage", i)) for i in range(5)] + [("post", None)]
+    prev = [0.0, 0.0]
     for name, stop in stops:
-        if name == "whisper":
-            wl.step = whisper_only
-        else:
-            wl.step = full_step
-            wl.model._stop_after = None if stop == "full" else stop
-        g, _ = bench.build_graph(wl)
-        ms = replay_ms(g)
-        rows.append((name, ms, ms - prev))
-        prev = ms
-        del g
-    for name, ms, d in rows:
-        print(f"{name:8s} cumulative {ms:7.3f} ms   segment {d:6.3f} ms", flush=True)
+        model._stop_after = stop
+        r = [rate(GraphLanes([syn_fn(i) for i in range(n)])) for n in (1, 4)]
+        print(f"{prec or 'f32'} {name:13s} cumulative 1 lane {r[0]:6.3f} ms, 4 lanes {r[1]:6.3f} ms / clip   segment {r[0] - prev[0]:6.3f} / {r[1] - prev[1]:6.3f} ms",
+              flush=True)
+        prev = r
+    model._stop_after = None
 
 
 if __name__ == "__main__":
