@@ -416,7 +416,8 @@ def check_chunk_streams(ops, device, T=5300, streams=3):
     for _ in range(3):
         got = svc_infer(*args, **kw)
         assert np.array_equal(got, want), float(np.abs(got - want).max())
-    assert len(m.__dict__.get("_svcmi_chunk_streams", [])) == (streams if str(device) != "cpu" else 0)
+    pools = m.__dict__.get("_svcmi_chunk_streams", {})
+    assert sum(len(v) for v in pools.values()) == (streams if str(device) != "cpu" else 0)
 
 
 def check_hubert_windows_batched(ops, device, dims, seconds=45.0):

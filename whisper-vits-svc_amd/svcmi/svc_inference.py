@@ -14,6 +14,7 @@ import os
 
 import numpy as np
 import contextlib
+import threading
 
 import torch
 
@@ -80,7 +81,8 @@ def _chunk_streams(model, dev, n):
     """``n`` side streams cached on the model (none for n <= 1)."""
     if n <= 1:
         return []
-    pool = model.__dict__.setdefault("_svcmi_chunk_streams", [])
+    pools = model.__dict__.setdefault("_svcmi_chunk_streams", {})      # per calling thread: concurrent conversions do not share side streams
+    pool = pools.setdefault(threading.get_ident(), [])
     while len(pool) < n:
         pool.append(torch.cuda.Stream(device=dev))
     return pool[:n]

@@ -10,6 +10,7 @@ afterwards -- utterances are independent.  Outputs land in ``./_s
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m svcmi.svc_inference_batch ...
 """
 import os
+import threading
 import time
 
 import numpy as np
@@ -69,7 +70,8 @@ class Converter:
         from .pitch import inference as pitch_inf
         from .svc_inference import DummyRetrieval, shift_pitch, svc_infer
         from .whisper import inference as whisper_inf
-        ppg_p, vec_p = self.tmp + ".ppg.npy", self.tmp + ".vec.npy"
+        tmp = f"{self.tmp}.{threading.get_ident()}"          # one set of intermediates per worker thread
+        ppg_p, vec_p = tmp + ".ppg.npy", tmp + ".vec.npy"
         whisper_inf.pred_ppg(self.whisper, wav_path, ppg_p, self.device)
         hubert_inf.pred_vec(self.hubert, wav_path, vec_p, self.device)
         pit = pitch_inf.compute_f0_sing(wav_path, self.device, model=self.crepe)
@@ -92,12 +94,45 @@ def run_batch(args, converter_factory=Converter, backend=None):
     mine = D.shard_utterances(cost, world)[rank]
     device = torch.device("cuda", local_rank) if torch.cuda.is_available() else torch.device("cpu")
     conv = converter_factory(args, device, rank, world)
-    t0, audio_s = time.perf_counter(), 0.0
+    t0 = time.perf_counter()
     sr = conv.hp.data.sampling_rate
-    for i in mine:
-        out = conv.convert(os.path.join(args.wave, waves[i]))
-        write(os.path.join(OUT_PATH, waves[i]), sr, out)
-        audio_s += len(out) / sr
+    seconds = [0.0] * len(mine)
+
+    def work(slot):
+        out = conv.convert(os.path.join(args.wave, waves[mine[slot]]))
+        write(os.path.join(OUT_PATH, waves[mine[slot]]), sr, out)
+        seconds[slot] = len(out) / sr
+
+    workers = max(1, min(int(getattr(args, "workers", 1) or 1), len(mine)))
+    if workers == 1 or not torch.cuda.is_available():
+        for slot in range(len(mine)):
+            work(slot)
+    else:
+        # files in flight (svcmi/lanes.py): every worker thread converts its files on its own HIP stream, so one file's launch chains
+        # (and its host-side work: file I/O, CSV quantisation, launch overhead) overlap another file's GEMMs
+        nxt, lock, errors = [0], threading.Lock(), []
+
+        def loop():
+            try:
+                with torch.cuda.stream(torch.cuda.Stream(device=device)):
+                    while True:
+                        with lock:
+                            slot = nxt[0]
+                            nxt[0] += 1
+                        if slot >= len(mine) or errors:
+                            return
+                        work(slot)                       # (convert() ends with a D2H copy: the stream is drained)
+            except BaseException as e:      # noqa: BLE001 -- re-raised on the main thread
+                errors.append(e)
+
+        threads = [threading.Thread(target=loop, name=f"svcmi-worker-{k}") for k in range(workers)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+    audio_s = sum(seconds)
     if torch.cuda.is_available():
         torch.cuda.synchronize()
     rates = D.gather_stats(audio_s / max(time.perf_counter() - t0, 1e-9))
@@ -117,6 +152,8 @@ def build_parser():
     p.add_argument("--whisper", type=str, default=os.path.join("whisper_pretrain", "large-v2.pt"))
     p.add_argument("--hubert", type=str, default=os.path.join("hubert_pretrain", "hubert-soft-0d54a1f4.pt"))
     p.add_argument("--crepe", type=str, default=os.path.join("crepe", "assets", "full.pth"))
+    p.add_argument("--workers", type=int, default=3,
+                   help="files in flight per GPU: worker threads, each converting its files on its own HIP stream (1 = the reference's order)")
     return p
 
 
