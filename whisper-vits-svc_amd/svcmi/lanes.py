@@ -3,8 +3,9 @@
 At batch 1 a clip is ~270 dependent launches, a third of them latency-bound (prior encoder, flow, the narrow generator stages: 8-17 us
 each for a few hundred MFLOP) and every GEMM launch spends 8-10 us of its 20-65 us outside the matrix pipe (operand round trip, epilogue,
 drain).  HIP has no programmatic dependent launch to overlap consecutive kernels of ONE chain, but kernels of DIFFERENT clips are
-independent: with each clip's chain on its own HIP stream -- mapped to its own hardware queue -- the command processor co-schedules one
-clip's small launches beside another clip's Whisper GEMMs.  A lane = a HIP stream + a HIP graph captured on it + the static input /
+independent: with each clip's chain on its own HIP stream -- mapped to its own hardware queue -- the command processor fills one clip's
+launch gaps, ramp-ups and tails with another clip's kernels (measured: per-launch fixed costs and launch chains overlap; two chip-filling
+kernels of different clips still take turns -- DESIGN.md section 5).  A lane = a HIP stream + a HIP graph captured on it + the static input /
 output tensors its step function closes over; the split-K workspace of ``Ops`` is keyed by stream, so lanes share nothing but the
 read-only weights.  Measured on MI355X (profiles/r02o_inflight_sweep.log, r02p_inflight_sweep.log): 1026 -> 1379 audio-s/s at batch 1, fp32, with 4 lanes on 8 hardware
 queues; per-clip results are bit-identical to a single-stream run (tests/test_gpu_engine.py).
