@@ -39,6 +39,7 @@ typedef float svcmi_f32x2 __attribute__((vector_size(8)));
 static inline svcmi_f32x2 svcmi_fma2(svcmi_f32x2 a, svcmi_f32x2 b, svcmi_f32x2 c) { return svcmi_f32x2{fmaf(a[0], b[0], c[0]), fmaf(a[1], b[1], c[1])}; }
 static inline svcmi_f32x2 svcmi_splat2(float v) { return svcmi_f32x2{v, v}; }
 static inline float svcmi_sgpr_const(float v) { return v; }
+static inline float svcmi_exp2(float x) { return exp2f(x); }
 
 typedef void* hipStream_t;
 

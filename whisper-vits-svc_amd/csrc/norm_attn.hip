@@ -250,6 +250,8 @@ constexpr int MAXW = 4;            // largest relative window
 constexpr int NREL = 2 * MAXW + 1;
 constexpr int BST = 12;            // row stride of the per-query band sums in LDS
 constexpr float NEG_BIG = -3.0e38f;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float MASKED2 = -1.0e4f * LOG2E;     // the reference's masked_fill value, in the log2 domain
 
 __device__ __forceinline__ float quarter_sum(float v) {    // sum over the 4 lane quarters (same lane & 15)
     v += __shfl_xor(v, 16);
@@ -286,6 +288,7 @@ __global__ __launch_bounds__(64 * NS) void attention_kernel(AttnArgs p) {
     const bool has_rel = p.rel_k != nullptr;
     const int W = p.window;
     const int nrel = has_rel ? 2 * W + 1 : 0;
+    const float scale2 = p.scale * LOG2E;              // softmax in the log2 domain (v_exp_f32 computes 2^x)
 
     if (has_rel) {
         for (int i = tid; i < nrel * D; i += 64 * NS) { Ek[i] = p.rel_k[i]; Ev[i] = p.rel_v[i]; }
@@ -359,6 +362,7 @@ __global__ __launch_bounds__(64 * NS) void attention_kernel(AttnArgs p) {
         }
         // ---- scores of this lane: keys kt + 16u + 4*g4 + r, query qi
         const bool diag = has_rel && (kt + 31 >= q0 - W) && (kt <= q0 + 15 + W);    // wave-uniform
+        const bool clean = kt + 32 <= (len < T ? len : T) && q0 + 16 <= len;         // wave-uniform: no masked or out-of-range entry
         float sv[2][4];
         float mt = NEG_BIG;
 #pragma unroll
@@ -374,16 +378,18 @@ __global__ __launch_bounds__(64 * NS) void attention_kernel(AttnArgs p) {
                     for (int e = 0; e < NREL; ++e) add = (rel == e && e < nrel) ? R[e] : add;
                     a += add;
                 }
-                a *= p.scale;
-                if (qi >= len || key >= len) a = -1.0e4f;       // masked_fill(mask == 0, -1e4)
-                if (key >= T) a = NEG_BIG;                      // beyond the sequence: weight 0
+                a *= scale2;                                    // scores live in the log2 domain: exp(s - m) = 2^(s' - m')
+                if (!clean) {                                   // (wave-uniform: a step entirely inside the valid rows skips the compares)
+                    if (qi >= len || key >= len) a = MASKED2;   // masked_fill(mask == 0, -1e4)
+                    if (key >= T) a = NEG_BIG;                  // beyond the sequence: weight 0
+                }
                 sv[u][r] = a;
                 mt = fmaxf(mt, a);
             }
         mt = fmaxf(mt, __shfl_xor(mt, 16));
         mt = fmaxf(mt, __shfl_xor(mt, 32));
         const float mnew = fmaxf(mrun, mt);
-        const float corr = expf(mrun - mnew);
+        const float corr = svcmi_exp2(mrun - mnew);
         mrun = mnew;
         lrun *= corr;
 #pragma unroll
@@ -395,7 +401,7 @@ __global__ __launch_bounds__(64 * NS) void attention_kernel(AttnArgs p) {
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                pv[u][r] = expf(sv[u][r] - mnew);               // exp(NEG_BIG - finite) == 0 for keys >= T
+                pv[u][r] = svcmi_exp2(sv[u][r] - mnew);         // 2^(NEG_BIG - finite) == 0 for keys >= T
                 lrun += pv[u][r];
             }
         if (diag) {
@@ -461,7 +467,7 @@ __global__ __launch_bounds__(64 * NS) void attention_kernel(AttnArgs p) {
         for (int e = 0; e < NREL; ++e) bs[e] = 0.f;
 #pragma unroll
         for (int ww = 0; ww < NS; ++ww) {
-            const float cw = expf(Mpart[ww * 16 + ql] - mall);
+            const float cw = svcmi_exp2(Mpart[ww * 16 + ql] - mall);
             den = fmaf(cw, Lpart[ww * 16 + ql], den);
             const float4 ov = *reinterpret_cast<const float4*>(Opart + (ww * 16 + ql) * OLD + c4);
             num.x = fmaf(cw, ov.x, num.x); num.y = fmaf(cw, ov.y, num.y);
@@ -514,6 +520,7 @@ __global__ __launch_bounds__(64 * NS) void attention_q32_kernel(AttnArgs p) {
     const int T = p.t;
     const int len = p.lengths ? p.lengths[b] : T;
     const int q0 = qt * QB;
+    const float scale2 = p.scale * LOG2E;
 
     float qf[QT][DS][4];
 #pragma unroll
@@ -569,6 +576,7 @@ __global__ __launch_bounds__(64 * NS) void attention_q32_kernel(AttnArgs p) {
                     }
             }
         }
+        const bool clean = kt + 32 <= (len < T ? len : T) && q0 + QB <= len;          // wave-uniform: nothing to mask in this step
         float pv[QT][2][4];
 #pragma unroll
         for (int a = 0; a < QT; ++a) {
@@ -580,16 +588,18 @@ __global__ __launch_bounds__(64 * NS) void attention_q32_kernel(AttnArgs p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = kt + 16 * u + 4 * g4 + r;
-                    float v = sacc[a][u][r] * p.scale;
-                    if (qi >= len || key >= len) v = -1.0e4f;       // masked_fill(mask == 0, -1e4)
-                    if (key >= T) v = NEG_BIG;                      // beyond the sequence: weight 0
+                    float v = sacc[a][u][r] * scale2;               // log2 domain, as in attention_kernel
+                    if (!clean) {
+                        if (qi >= len || key >= len) v = MASKED2;   // masked_fill(mask == 0, -1e4)
+                        if (key >= T) v = NEG_BIG;                  // beyond the sequence: weight 0
+                    }
                     sv[u][r] = v;
                     mt = fmaxf(mt, v);
                 }
             mt = fmaxf(mt, __shfl_xor(mt, 16));
             mt = fmaxf(mt, __shfl_xor(mt, 32));
             const float mnew = fmaxf(mrun[a], mt);
-            const float corr = expf(mrun[a] - mnew);
+            const float corr = svcmi_exp2(mrun[a] - mnew);
             mrun[a] = mnew;
             lrun[a] *= corr;
 #pragma unroll
@@ -600,7 +610,7 @@ __global__ __launch_bounds__(64 * NS) void attention_q32_kernel(AttnArgs p) {
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    pv[a][u][r] = expf(sv[u][r] - mnew);
+                    pv[a][u][r] = svcmi_exp2(sv[u][r] - mnew);
                     lrun[a] += pv[a][u][r];
                 }
         }
@@ -643,7 +653,7 @@ __global__ __launch_bounds__(64 * NS) void attention_q32_kernel(AttnArgs p) {
         float4 num = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int ww = 0; ww < NS; ++ww) {
-            const float cw = expf(Mpart[ww * QB + ql] - mall);
+            const float cw = svcmi_exp2(Mpart[ww * QB + ql] - mall);
             den = fmaf(cw, Lpart[ww * QB + ql], den);
             const float4 ov = *reinterpret_cast<const float4*>(Opart + (ww * QB + ql) * OLD + c4);
             num.x = fmaf(cw, ov.x, num.x); num.y = fmaf(cw, ov.y, num.y);

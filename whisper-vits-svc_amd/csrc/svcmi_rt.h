@@ -28,6 +28,10 @@ __device__ __forceinline__ float svcmi_sgpr_const(float v) {
     return __builtin_bit_cast(float, i);
 }
 
+// 2^x as ONE transcendental instruction (v_exp_f32, 1 ulp; inputs below -126 give 0).  libm's expf is ~15 instructions; a softmax
+// that keeps its scores in the log2 domain (scores * log2 e folded into the scale) needs nothing more.
+__device__ __forceinline__ float svcmi_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 // D = A(32x2) * B(2x32) + C, exact fp32 (v_mfma_f32_32x32x2_f32).  Lane l supplies
 // A[i=l&31][k=l>>5] and B[k=l>>5][j=l&31]; C/D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5).
 __device__ __forceinline__ svcmi_f32x16 svcmi_mfma_32x32x2(float a, float b, svcmi_f32x16 c) {
