@@ -1,6 +1,8 @@
 """Property tests (hypothesis) of the host-side arithmetic of the path: the chunk schedule with its halo trim, the Whisper /
 HuBERT window plans, the pitch shift and CSV round trip, and the LPT sharding -- the product's copies against the oracle's
 restatements and against the invariants the reference's loops rely on."""
+import os
+
 import numpy as np
 import pytest
 from hypothesis import given, settings, strategies as st
@@ -144,3 +146,36 @@ def test_graph_lanes_refuse_to_run_without_a_gpu():
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError):
         GraphLanes([lambda: None])
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.lists(st.integers(min_value=0, max_value=5), min_size=1, max_size=12), st.sampled_from([4, 8, 12]), st.integers(min_value=0, max_value=2 ** 31))
+def test_faiss_ivf_flat_files_round_trip(sizes, d, seed):
+    """write_faiss_ivf_flat -> read_faiss_ivf_flat for arbitrary list occupancies (both size-table encodings: 'full' when more than half of
+    the lists are non-empty, 'sprs' otherwise), ids that are not row numbers, and the direct-map variants a faiss file may carry."""
+    import struct
+    import tempfile
+    from svcmi import ivf_index as IV
+    rng = np.random.default_rng(seed)
+    nlist = len(sizes)
+    cent = rng.standard_normal((nlist, d)).astype(np.float32)
+    vecs = [rng.standard_normal((m, d)).astype(np.float32) for m in sizes]
+    ids = [rng.integers(0, 2 ** 40, size=m).astype(np.int64) for m in sizes]
+    with tempfile.TemporaryDirectory() as tmp:
+        f = os.path.join(tmp, "x.index")
+        IV.write_faiss_ivf_flat(f, cent, vecs, ids)
+        raw = open(f, "rb").read()
+        assert (b"full" in raw) == (sum(1 for m in sizes if m) > nlist // 2)
+        r = IV.read_faiss_ivf_flat(f)
+        assert (r["d"], r["nlist"], r["ntotal"], r["nprobe"]) == (d, nlist, sum(sizes), 1)
+        assert np.array_equal(r["centroids"], cent)
+        for (v, i), v0, i0 in zip(r["lists"], vecs, ids):
+            assert np.array_equal(v, v0) and np.array_equal(i, i0)
+        # a direct map of type Array (1) with ntotal entries, as faiss writes when the index maintains one: skipped by the reader
+        dm = raw.index(b"ilar") - 9                                   # the 1 + 8 bytes of the empty NoMap record
+        n = sum(sizes)
+        g = os.path.join(tmp, "y.index")
+        with open(g, "wb") as out:
+            out.write(raw[:dm] + struct.pack("<bQ", 1, n) + np.arange(n, dtype="<i8").tobytes() + raw[dm + 9:])
+        r2 = IV.read_faiss_ivf_flat(g)
+        assert all(np.array_equal(a[1], b[1]) for a, b in zip(r2["lists"], r["lists"]))
