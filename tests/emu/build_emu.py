@@ -17,14 +17,15 @@ def build_emu(force=False):
     if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps):
         return OUT
     os.makedirs(OUT_DIR, exist_ok=True)
-    objs = []
-    for s in srcs:
-        o = os.path.join(OUT_DIR, os.path.basename(s) + ".o")
-        subprocess.run(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-Wno-psabi", "-DSVCMI_EMU", "-I", HERE, "-I", CSRC,
-                        "-x", "c++", "-c", s, "-o", o], check=True)
-        objs.append(o)
-    o = os.path.join(OUT_DIR, "hip_emu.o")
-    subprocess.run(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-Wno-psabi", "-I", HERE, "-c", os.path.join(HERE, "hip_emu.cpp"), "-o", o], check=True)
+    flags = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-Wno-psabi"]
+    jobs = [(flags + ["-DSVCMI_EMU", "-I", HERE, "-I", CSRC, "-x", "c++", "-c", s, "-o", os.path.join(OUT_DIR, os.path.basename(s) + ".o")])
+            for s in srcs]
+    jobs.append(flags + ["-I", HERE, "-c", os.path.join(HERE, "hip_emu.cpp"), "-o", os.path.join(OUT_DIR, "hip_emu.o")])
+    procs = [subprocess.Popen(j) for j in jobs]          # one compiler per file, in parallel (a fresh checkout builds this once per test run)
+    if any([p.wait() for p in procs]):
+        raise RuntimeError("emulator build failed")
+    objs = [j[-1] for j in jobs[:-1]]
+    o = jobs[-1][-1]
     subprocess.run(["g++", "-shared", "-o", OUT] + objs + [o], check=True)
     return OUT
 
