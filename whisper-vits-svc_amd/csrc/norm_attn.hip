@@ -674,15 +674,19 @@ int g_attn_q32 = -1;    // tuning knob ("attn_q32", -1 = heuristic | 0 | 1): two
 template <int D>
 int launch_attn(const AttnArgs& a_in, int batch, void* stream) {
     AttnArgs a = a_in;
-    // two query tiles per wave: measured (scripts/microbench.py attn) 149.7 vs 176.0 us at T = 1500 (20 heads, 2-way key split),
-    // but 33.5 vs 30.0 us at T = 500, where the launch is latency-bound -- so only for long sequences
-    const bool q32 = g_attn_q32 >= 0 ? (g_attn_q32 != 0 && !a.rel_k) : (!a.rel_k && D <= 64 && a.t >= 1024);
+    // two query tiles per wave: every K / V fragment a wave fetches feeds twice the MFMAs (16 instead of 8 FLOP per fetched byte).  Once a
+    // launch fills the chip that feed is what bounds the kernel (profiles/r02ae_attention_saturation.log: B = 16 x T = 500: 215 vs 283-323 us,
+    // 95 vs 63-72 TFLOP/s; B = 4: 63-67 vs 80-84 us; T = 1500: 139.5 vs 175 us); a single T = 500 window (640 blocks of one query tile) is
+    // latency-bound and keeps the one-tile kernel (29.3 vs 33.5 us)
+    const long long blocks16 = (long long)((a.t + 15) / 16) * a.heads * batch;
+    const bool q32 = g_attn_q32 >= 0 ? (g_attn_q32 != 0 && !a.rel_k) : (!a.rel_k && D <= 64 && (a.t >= 1024 || blocks16 >= 1280));
     if (q32) a.nq = (a.t + 31) / 32;
     // key-split NS: ~2 waves per SIMD (1024 SIMDs), but keep >= 64 keys per wave
     const long long blocks = (long long)a.nq * a.heads * batch;
     int ns = 1;
     while (ns < 8 && blocks * ns < 2048 && a.t >= 128 * ns) ns *= 2;
-    if (q32 && g_attn_q32 < 0) ns = 2;
+    if (q32 && g_attn_q32 < 0) ns = blocks >= 4096 ? 1 : (blocks >= 800 ? 2 : 4);      // measured: 1 / 2 / 4-way split at 5120 / 940-3840 / 640 blocks
+    if (q32 && a.t < 128 * ns) ns = a.t >= 256 ? 2 : 1;
     if (g_attn_ns) ns = g_attn_ns;
     dim3 grid((unsigned)blocks);
     if (q32) {
