@@ -350,6 +350,17 @@ ATTN_CASES_Q32 = [
     dict(id="q32_d16_T33_ns1", B=1, T=33, H=1, D=16, q32=True, ns=1),
     dict(id="q32_d64_T300_ns4", B=1, T=300, H=2, D=64, q32=True, ns=4),
 ]
+# The opt-in LDS-staged kernel ("attn_lds" knob, off by default; written at the end of round 2 after the GPU budget was spent): checked on
+# the emulator only until its first hardware run.
+ATTN_CASES_LDS = [
+    dict(id="lds_d64_T130_one_range", B=1, T=130, H=2, D=64, lds=True),
+    dict(id="lds_d64_T300_two_ranges", B=1, T=300, H=2, D=64, lds=True),
+    dict(id="lds_d64_ragged_T257", B=2, T=257, H=2, D=64, lengths=[257, 140], lds=True),
+    dict(id="lds_d32_T70", B=1, T=70, H=3, D=32, lds=True),
+    dict(id="lds_d16_T33", B=1, T=33, H=1, D=16, lds=True),
+    dict(id="lds_d64_T288_short_second_range", B=1, T=288, H=1, D=64, lds=True),
+]
+
 ATTN_CASES_LARGE = [
     dict(id="whisper_T500", B=1, T=500, H=20, D=64),
     dict(id="encp_T1000", B=1, T=1000, H=2, D=96, rel=True, W=4),
@@ -397,11 +408,14 @@ def check_attention(ops, c, device):
     dev = lambda t: None if t is None else t.to(device)
     if c.get("q32"):
         assert ops.lib.svcmi_tune_set(b"attn_q32", 1) == 0 and ops.lib.svcmi_tune_set(b"attn_ns", c.get("ns", 0)) == 0
+    if c.get("lds"):        # the opt-in LDS-staged kernel (K / V tiles shared by 4 query tiles of a block)
+        assert ops.lib.svcmi_tune_set(b"attn_lds", 1) == 0
     try:
         got = ops.attention(dev(qkv), H, scale, rel_k=dev(rel_k), rel_v=dev(rel_v), window=c.get("W", 0), lengths=dev(lengths))
     finally:
         ops.lib.svcmi_tune_set(b"attn_q32", -1)
         ops.lib.svcmi_tune_set(b"attn_ns", 0)
+        ops.lib.svcmi_tune_set(b"attn_lds", 0)
     _close(got, want, 2e-5, c["id"])
 
 

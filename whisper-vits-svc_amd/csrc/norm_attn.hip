@@ -667,6 +667,206 @@ __global__ __launch_bounds__(64 * NS) void attention_q32_kernel(AttnArgs p) {
     }
 }
 
+// Band-free attention with the K / V tiles of a head staged ONCE per block through LDS and shared by QT query tiles (VERDICT r1 item 6;
+// DESIGN.md section 8.1).  One block = QT x KS waves over QT * 16 queries of one head: wave (qt, ks) owns query tile qt and key range ks;
+// per 32-key step the QT waves of a key range fetch that range's next K and V tiles (2 x 8 KB at D = 64) with coalesced float4 loads into
+// registers, the block computes on the current tiles out of LDS (K fragments as ds_read_b128, V fragments as 32-bit reads along d), then
+// the fetched tiles go to the other LDS buffer and ONE block-wide barrier closes the step.  L2 -> CU traffic per launch drops by QT (32
+// FLOP per fetched byte at QT = 4 instead of 8); the KS partial states of a query tile merge through LDS as in attention_kernel.  Opt-in
+// ("attn_lds" tuning knob) until it has been measured on hardware: with QT = 4 a T = 500 x 20-head launch is only 160 blocks.
+template <int D, int QT, int KS>
+__global__ __launch_bounds__(64 * QT * KS) void attention_lds_kernel(AttnArgs p) {
+    constexpr int DS = D / 16, OLD = D + 4, NW = QT * KS, NT = 64 * NW, QB = 16 * QT;
+    constexpr int TLD = D + 4;                          // row stride of a staged tile: float4-aligned, rows 4 banks apart
+    constexpr int TILE = 32 * TLD;                      // one 32-key tile (K or V)
+    constexpr int STAGE = KS * 2 * 2 * TILE;            // [ks][buffer][K | V]
+    constexpr int MERGE = NW * 16 * OLD + 2 * NW * 16;  // partial O / max / sum of every wave (aliases the tiles after the last step)
+    __shared__ __attribute__((aligned(16))) float smem[STAGE > MERGE ? STAGE : MERGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = SVCMI_UNIFORM((int)(tid >> 6));
+    const int qt_l = w % QT, ks = w / QT;               // wave-uniform
+    const int lq = lane & 15, g4 = lane >> 4;
+    int L;
+    {
+        const int total = (int)gridDim.x, id = (int)blockIdx.x;
+        const int q8 = total >> 3, r8 = total & 7, xcd = id & 7, slot = id >> 3;
+        L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    }
+    const int qg = L % p.nq, hb = L / p.nq;             // p.nq = query GROUPS of QB rows
+    const int h = hb % p.heads, b = hb / p.heads;
+    const int T = p.t;
+    const int len = p.lengths ? p.lengths[b] : T;
+    const float scale2 = p.scale * LOG2E;
+    const int q0 = qg * QB + 16 * qt_l, qi = q0 + lq;
+
+    float qf[DS][4];
+    {
+        const float* qp = p.q + (long long)b * p.q_bs + (long long)(qi < T ? qi : T - 1) * p.ldq + h * D + 4 * g4;
+#pragma unroll
+        for (int s = 0; s < DS; ++s) {
+            const float4 t4 = *reinterpret_cast<const float4*>(qp + 16 * s);
+            qf[s][0] = t4.x; qf[s][1] = t4.y; qf[s][2] = t4.z; qf[s][3] = t4.w;
+        }
+    }
+    svcmi_f32x4 oacc[DS];
+#pragma unroll
+    for (int dt = 0; dt < DS; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) oacc[dt][r] = 0.f;
+    float mrun = NEG_BIG, lrun = 0.f;
+
+    const int per = ((T + KS - 1) / KS + 31) / 32 * 32;      // keys per key range, a multiple of the step
+    const int steps = per / 32;                              // every range runs the same number of steps (rows past T are masked)
+    const int jbeg = ks * per;
+    // staging role of this thread inside its key range: QT * 64 threads move 32 rows x D/4 float4 of K and of V per step
+    constexpr int F4 = D / 4, PER_T = (32 * F4 + 64 * QT - 1) / (64 * QT);
+    const int st = qt_l * 64 + lane;                         // 0 .. 64 * QT - 1
+    const float* kg = p.k + (long long)b * p.k_bs + h * D;
+    const float* vg = p.v + (long long)b * p.v_bs + h * D;
+    float* const Kt = smem + ks * 4 * TILE;                  // [buffer][K | V] of this key range
+    float4 kreg[PER_T], vreg[PER_T];
+    auto fetch = [&](int kt) {
+#pragma unroll
+        for (int j = 0; j < PER_T; ++j) {
+            const int idx = st + j * 64 * QT;
+            if (idx < 32 * F4) {
+                const int row = idx / F4, c4 = idx - row * F4;
+                const int key = kt + row;
+                const long long off = (long long)(key < T ? key : T - 1);
+                kreg[j] = *reinterpret_cast<const float4*>(kg + off * p.ldk + 4 * c4);
+                vreg[j] = *reinterpret_cast<const float4*>(vg + off * p.ldv + 4 * c4);
+            }
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < PER_T; ++j) {
+            const int idx = st + j * 64 * QT;
+            if (idx < 32 * F4) {
+                const int row = idx / F4, c4 = idx - row * F4;
+                *reinterpret_cast<float4*>(Kt + (buf * 2 + 0) * TILE + row * TLD + 4 * c4) = kreg[j];
+                *reinterpret_cast<float4*>(Kt + (buf * 2 + 1) * TILE + row * TLD + 4 * c4) = vreg[j];
+            }
+        }
+    };
+    fetch(jbeg);
+    stash(0);
+    __syncthreads();
+    for (int it = 0; it < steps; ++it) {
+        const int kt = jbeg + 32 * it, buf = it & 1;
+        if (it + 1 < steps) fetch(kt + 32);                 // uniform over the block
+        const float* Kc = Kt + (buf * 2 + 0) * TILE;
+        const float* Vc = Kt + (buf * 2 + 1) * TILE;
+        svcmi_f32x4 sacc[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sacc[u][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < DS; ++s) {
+            const float4 a0 = *reinterpret_cast<const float4*>(Kc + lq * TLD + 16 * s + 4 * g4);
+            const float4 a1 = *reinterpret_cast<const float4*>(Kc + (16 + lq) * TLD + 16 * s + 4 * g4);
+            sacc[0] = svcmi_mfma_16x16x4(a0.x, qf[s][0], sacc[0]);
+            sacc[1] = svcmi_mfma_16x16x4(a1.x, qf[s][0], sacc[1]);
+            sacc[0] = svcmi_mfma_16x16x4(a0.y, qf[s][1], sacc[0]);
+            sacc[1] = svcmi_mfma_16x16x4(a1.y, qf[s][1], sacc[1]);
+            sacc[0] = svcmi_mfma_16x16x4(a0.z, qf[s][2], sacc[0]);
+            sacc[1] = svcmi_mfma_16x16x4(a1.z, qf[s][2], sacc[1]);
+            sacc[0] = svcmi_mfma_16x16x4(a0.w, qf[s][3], sacc[0]);
+            sacc[1] = svcmi_mfma_16x16x4(a1.w, qf[s][3], sacc[1]);
+        }
+        const bool clean = kt + 32 <= (len < T ? len : T) && q0 + 16 <= len;     // wave-uniform
+        float sv[2][4];
+        float mt = NEG_BIG;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt + 16 * u + 4 * g4 + r;
+                float a = sacc[u][r] * scale2;
+                if (!clean) {
+                    if (qi >= len || key >= len) a = MASKED2;       // masked_fill(mask == 0, -1e4)
+                    if (key >= T) a = NEG_BIG;                      // beyond the sequence: weight 0
+                }
+                sv[u][r] = a;
+                mt = fmaxf(mt, a);
+            }
+        mt = fmaxf(mt, __shfl_xor(mt, 16));
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float mnew = fmaxf(mrun, mt);
+        // a key range that lies entirely past T has only NEG_BIG scores: keep its state empty (2^(NEG_BIG - NEG_BIG) would be 1)
+        const float corr = mnew > -1.0e38f ? svcmi_exp2(mrun - mnew) : 0.f;
+        mrun = mnew;
+        lrun *= corr;
+#pragma unroll
+        for (int dt = 0; dt < DS; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) oacc[dt][r] *= corr;
+        float pv[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pv[u][r] = mnew > -1.0e38f ? svcmi_exp2(sv[u][r] - mnew) : 0.f;
+                lrun += pv[u][r];
+            }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float* vr = Vc + (16 * u + 4 * g4 + r) * TLD + lq;
+#pragma unroll
+                for (int dt = 0; dt < DS; ++dt) oacc[dt] = svcmi_mfma_16x16x4(vr[16 * dt], pv[u][r], oacc[dt]);
+            }
+        if (it + 1 < steps) stash(buf ^ 1);
+        __syncthreads();                                    // next tiles visible; this step's tiles free for the step after next
+    }
+
+    // ---- merge the KS partial states of every query tile (the tiles are dead: the barrier above closed the last step)
+    float* const Opart = smem;                              // [NW][16][OLD]
+    float* const Mpart = Opart + NW * 16 * OLD;             // [NW][16]
+    float* const Lpart = Mpart + NW * 16;                   // [NW][16]
+    lrun = quarter_sum(lrun);
+    {
+        float* orow = Opart + (w * 16 + lq) * OLD + 4 * g4;
+#pragma unroll
+        for (int dt = 0; dt < DS; ++dt)
+            *reinterpret_cast<float4*>(orow + 16 * dt) = make_float4(oacc[dt][0], oacc[dt][1], oacc[dt][2], oacc[dt][3]);
+        if (g4 == 0) {
+            Mpart[w * 16 + lq] = mrun;
+            Lpart[w * 16 + lq] = lrun;
+        }
+    }
+    __syncthreads();
+    float* ob = p.o + (long long)b * p.o_bs + h * D;
+    for (int item = tid; item < QB * (D / 4); item += NT) {
+        const int qr = item / (D / 4), c4 = (item - qr * (D / 4)) * 4;      // qr: row inside the query group
+        const int qtl = qr >> 4, ql = qr & 15;
+        float mall = NEG_BIG;
+#pragma unroll
+        for (int k2 = 0; k2 < KS; ++k2) mall = fmaxf(mall, Mpart[(k2 * QT + qtl) * 16 + ql]);
+        float den = 0.f;
+        float4 num = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k2 = 0; k2 < KS; ++k2) {
+            const int ww = k2 * QT + qtl;
+            const float mw = Mpart[ww * 16 + ql];
+            const float cw = mw > -1.0e38f ? svcmi_exp2(mw - mall) : 0.f;
+            den = fmaf(cw, Lpart[ww * 16 + ql], den);
+            const float4 ov = *reinterpret_cast<const float4*>(Opart + (ww * 16 + ql) * OLD + c4);
+            num.x = fmaf(cw, ov.x, num.x); num.y = fmaf(cw, ov.y, num.y);
+            num.z = fmaf(cw, ov.z, num.z); num.w = fmaf(cw, ov.w, num.w);
+        }
+        const int qrow = qg * QB + qr;
+        if (qrow < T) {
+            const float inv = 1.0f / den;
+            *reinterpret_cast<float4*>(ob + (long long)qrow * p.ldo + c4) = make_float4(num.x * inv, num.y * inv, num.z * inv, num.w * inv);
+        }
+    }
+}
+
+int g_attn_lds = 0;     // tuning knob ("attn_lds", 0 | 1): the LDS-staged kernel for band-free attention, D <= 64 (off until measured)
 int g_attn_ns = 0;      // tuning knob (svcmi_tune_set("attn_ns", 0 | 1 | 2 | 4 | 8)); 0 = heuristic
 
 int g_attn_q32 = -1;    // tuning knob ("attn_q32", -1 = heuristic | 0 | 1): two query tiles per wave for band-free attention
@@ -680,6 +880,16 @@ int launch_attn(const AttnArgs& a_in, int batch, void* stream) {
     // latency-bound and keeps the one-tile kernel (29.3 vs 33.5 us)
     const long long blocks16 = (long long)((a.t + 15) / 16) * a.heads * batch;
     const bool q32 = g_attn_q32 >= 0 ? (g_attn_q32 != 0 && !a.rel_k) : (!a.rel_k && D <= 64 && (a.t >= 1024 || blocks16 >= 1280));
+    if constexpr (D <= 64) {
+        if (g_attn_lds && !a.rel_k) {
+            constexpr int QT = 4;
+            a.nq = (a.t + 16 * QT - 1) / (16 * QT);
+            dim3 g((unsigned)((long long)a.nq * a.heads * batch));
+            if (a.t >= 256) SVCMI_LAUNCH((attention_lds_kernel<D, QT, 2>), g, dim3(64 * QT * 2), 0, stream, a);
+            else SVCMI_LAUNCH((attention_lds_kernel<D, QT, 1>), g, dim3(64 * QT), 0, stream, a);
+            return SVCMI_LAST_ERROR();
+        }
+    }
     if (q32) a.nq = (a.t + 31) / 32;
     // key-split NS: ~2 waves per SIMD (1024 SIMDs), but keep >= 64 keys per wave
     const long long blocks = (long long)a.nq * a.heads * batch;
@@ -794,6 +1004,10 @@ extern "C" int svcmi_attn_tune_set(const char* name, int32_t value) {
     int i = 0;
     while (k[i] && name[i] == k[i]) ++i;
     if (k[i] == 0 && name[i] == 0 && (value == 0 || value == 1 || value == 2 || value == 4 || value == 8)) { g_attn_ns = value; return 0; }
+    const char* k4 = "attn_lds";
+    i = 0;
+    while (k4[i] && name[i] == k4[i]) ++i;
+    if (k4[i] == 0 && name[i] == 0 && (value == 0 || value == 1)) { g_attn_lds = value; return 0; }
     const char* k2 = "attn_q32";
     i = 0;
     while (k2[i] && name[i] == k2[i]) ++i;
