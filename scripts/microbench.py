@@ -220,6 +220,19 @@ def main():
                     print(f"attn T={T} H={H} D={D} rel={rel} q32={q32} ns={ns}: {us:8.1f} us  {4.0 * T * T * H * D / us / 1e6:7.1f} TF/s", flush=True)
         ops.lib.svcmi_tune_set(b"attn_ns", 0)
         ops.lib.svcmi_tune_set(b"attn_q32", -1)
+        # the opt-in LDS-staged kernel (K / V tiles shared by 4 query tiles x 2 key ranges per block) against the heuristic's choice,
+        # one window alone and chip-filling batches
+        for (B, T, H, D) in ((1, 500, 20, 64), (1, 750, 20, 64), (2, 750, 20, 64), (4, 500, 20, 64), (16, 500, 20, 64), (1, 1500, 20, 64)):
+            qkv = torch.randn(B, T, 3 * H * D, device="cuda")
+            out = torch.empty(B, T, H * D, device="cuda")
+            ref = None
+            for lds in (0, 1):
+                assert ops.lib.svcmi_tune_set(b"attn_lds", lds) == 0
+                us = timeit(lambda: ops.attention(qkv, H, D ** -0.5, out=out))
+                ref = out.clone() if ref is None else ref
+                print(f"attn B={B} T={T} H={H} D={D} lds={lds}: {us:8.1f} us  {4.0 * B * T * T * H * D / us / 1e6:7.1f} TF/s  "
+                      f"maxdiff vs heuristic kernel {float((out - ref).abs().max()):.1e}", flush=True)
+        ops.lib.svcmi_tune_set(b"attn_lds", 0)
 
 
 if __name__ == "__main__":
