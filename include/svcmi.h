@@ -244,8 +244,13 @@ int svcmi_snake_post_supported(int32_t c, int32_t ld, int32_t ksize);
 int svcmi_snake_post_f32(const float* x, const float* w, float* y, const float* alpha_log, const float* beta_log,
                          const float* filt, int32_t batch, int32_t len, int32_t c, int32_t ld, int32_t ksize, void* stream);
 
-/* Development knob for the tuning scripts: "amp_tt" in {0 (default), 1, 2, 4} = time steps per thread of
- * svcmi_snake_conv_f32.  Results never depend on it.  Returns 0, or SVCMI_EINVAL for an unknown name/value. */
+/* Development knobs for the tuning scripts (kernel SHAPE choices only: results never depend on them beyond fp32 re-association):
+ *   "amp_tt"   {0 = default, 1, 2, 4}   time steps per thread of svcmi_snake_conv_f32
+ *   "group_nst" {0 = default, 2, 3}     LDS ring depth of the grouped implicit-GEMM launches
+ *   "attn_ns"  {0 = heuristic, 1, 2, 4, 8}  key-split waves per block of svcmi_attention_f32
+ *   "attn_q32" {-1 = heuristic, 0, 1}   two query tiles per wave (band-free attention, head_dim <= 64)
+ *   "attn_lds" {0 = default, 1}         band-free attention with K / V tiles staged through LDS and shared by 4 query tiles per block
+ * Process-wide, not thread-safe against concurrent launches.  Returns 0, or SVCMI_EINVAL for an unknown name / value. */
 int svcmi_tune_set(const char* name, int32_t value);
 
 /* WaveNet gate, vits/commons.py:126-133 with input_b == 0 (vits/modules.py:190-193):
