@@ -249,7 +249,8 @@ int svcmi_snake_post_f32(const float* x, const float* w, float* y, const float* 
  *   "group_nst" {0 = default, 2, 3}     LDS ring depth of the grouped implicit-GEMM launches
  *   "attn_ns"  {0 = heuristic, 1, 2, 4, 8}  key-split waves per block of svcmi_attention_f32
  *   "attn_q32" {-1 = heuristic, 0, 1}   two query tiles per wave (band-free attention, head_dim <= 64)
- *   "attn_lds" {0 = default, 1}         band-free attention with K / V tiles staged through LDS and shared by 4 query tiles per block
+ *   "attn_lds" {0 = heuristic, -1 = never, 1, 10*QT+KS}  band-free attention with K / V tiles staged through LDS and shared by QT in
+ *              {2, 4, 8} query tiles x KS in {1, 2, 4} key ranges per block (1 = 4 x 2; compiled shapes 21 22 24 41 42 44 81 82)
  * Process-wide, not thread-safe against concurrent launches.  Returns 0, or SVCMI_EINVAL for an unknown name / value. */
 int svcmi_tune_set(const char* name, int32_t value);
 

@@ -207,6 +207,37 @@ def main():
                 us = timeit(lambda: ops.snake_conv(x, al, be, filt, w, bias, c=C, ksize=k, dilation=d, res=r, out=y))
                 print(f"amp tt={tt} C={C} n={n} k={k} d={d}: {us:8.1f} us  conv {2.0 * C * C * k * n / us / 1e6:6.1f} TF/s", flush=True)
         ops.lib.svcmi_tune_set(b"amp_tt", 0)
+    if "attnlds" in what:     # every compiled shape of the LDS-staged kernel (knob = 10 * QT + KS) against the heuristic's choice (0): alone and 4 streams
+        for (B, T, H, D) in ((1, 500, 20, 64), (2, 500, 20, 64), (4, 500, 20, 64), (16, 500, 20, 64), (1, 750, 20, 64), (2, 750, 20, 64), (1, 1500, 20, 64)):
+            qkv = torch.randn(B, T, 3 * H * D, device="cuda")
+            out = torch.empty(B, T, H * D, device="cuda")
+            ref = None
+            for code in (-1, 0, 21, 22, 24, 41, 42, 44, 81, 82):      # -1: the register-fed kernels, 0: the library heuristic
+                assert ops.lib.svcmi_tune_set(b"attn_lds", code) == 0
+                us = timeit(lambda: ops.attention(qkv, H, D ** -0.5, out=out))
+                ref = out.clone() if ref is None else ref
+                print(f"attnlds B={B} T={T} code={code:2d}: {us:8.1f} us  {4.0 * B * T * T * H * D / us / 1e6:7.1f} TF/s  "
+                      f"maxdiff {float((out - ref).abs().max()):.1e}", flush=True)
+        # four independent T = 500 windows on four streams (the clips-in-flight regime of bench.py)
+        streams = [torch.cuda.Stream() for _ in range(4)]
+        qs = [torch.randn(1, 500, 3 * 20 * 64, device="cuda") for _ in range(4)]
+        os_ = [torch.empty(1, 500, 20 * 64, device="cuda") for _ in range(4)]
+        for code in (-1, 22, 24, 41, 42, 44, 81, 82):
+            assert ops.lib.svcmi_tune_set(b"attn_lds", code) == 0
+            def run4():
+                for i, st in enumerate(streams):
+                    with torch.cuda.stream(st):
+                        for _ in range(20):
+                            ops.attention(qs[i], 20, 0.125, out=os_[i])
+            run4()
+            torch.cuda.synchronize()
+            import time as _t
+            t0 = _t.perf_counter()
+            run4()
+            torch.cuda.synchronize()
+            us = (_t.perf_counter() - t0) * 1e6 / 80
+            print(f"attnlds 4 streams x T=500 code={code:2d}: {us:8.1f} us per launch  {4.0 * 500 * 500 * 1280 / us / 1e6:7.1f} TF/s", flush=True)
+        ops.lib.svcmi_tune_set(b"attn_lds", 0)
     if "attn" in what:
         for (T, H, D, rel) in ((500, 20, 64, False), (1000, 2, 96, True), (1500, 20, 64, False), (2520, 2, 96, True)):
             qkv = torch.randn(1, T, 3 * H * D, device="cuda")

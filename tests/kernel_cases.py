@@ -350,15 +350,30 @@ ATTN_CASES_Q32 = [
     dict(id="q32_d16_T33_ns1", B=1, T=33, H=1, D=16, q32=True, ns=1),
     dict(id="q32_d64_T300_ns4", B=1, T=300, H=2, D=64, q32=True, ns=4),
 ]
-# The opt-in LDS-staged kernel ("attn_lds" knob, off by default; written at the end of round 2 after the GPU budget was spent): checked on
-# the emulator only until its first hardware run.
+# The LDS-staged kernel: K / V tiles of a head staged once per block and shared by QT query tiles x KS key ranges ("attn_lds" knob =
+# 10 * QT + KS; 1 = the 4 x 2 / 4 x 1 default shape).  Every compiled shape, ragged lengths, ranges that lie entirely past T.
 ATTN_CASES_LDS = [
-    dict(id="lds_d64_T130_one_range", B=1, T=130, H=2, D=64, lds=True),
-    dict(id="lds_d64_T300_two_ranges", B=1, T=300, H=2, D=64, lds=True),
-    dict(id="lds_d64_ragged_T257", B=2, T=257, H=2, D=64, lengths=[257, 140], lds=True),
-    dict(id="lds_d32_T70", B=1, T=70, H=3, D=32, lds=True),
-    dict(id="lds_d16_T33", B=1, T=33, H=1, D=16, lds=True),
-    dict(id="lds_d64_T288_short_second_range", B=1, T=288, H=1, D=64, lds=True),
+    dict(id="lds_d64_T130_one_range", B=1, T=130, H=2, D=64, lds=1),
+    dict(id="lds_d64_T300_two_ranges", B=1, T=300, H=2, D=64, lds=1),
+    dict(id="lds_d64_ragged_T257", B=2, T=257, H=2, D=64, lengths=[257, 140], lds=1),
+    dict(id="lds_d32_T70", B=1, T=70, H=3, D=32, lds=1),
+    dict(id="lds_d16_T33", B=1, T=33, H=1, D=16, lds=1),
+    dict(id="lds_d64_T288_short_second_range", B=1, T=288, H=1, D=64, lds=1),
+    dict(id="lds21_d64_T77", B=1, T=77, H=2, D=64, lds=21),
+    dict(id="lds22_d64_ragged_T131", B=2, T=131, H=2, D=64, lengths=[131, 64], lds=22),
+    dict(id="lds24_d64_T200", B=1, T=200, H=2, D=64, lds=24),
+    dict(id="lds24_d32_T40_empty_ranges", B=1, T=40, H=1, D=32, lds=24),
+    dict(id="lds44_d64_T300", B=1, T=300, H=1, D=64, lds=44),
+    dict(id="lds81_d64_T150", B=1, T=150, H=2, D=64, lds=81),
+    dict(id="lds82_d64_ragged_T260", B=2, T=260, H=1, D=64, lengths=[200, 260], lds=82),
+]
+# the same kernel at the sizes it is selected for (GPU only)
+ATTN_CASES_LDS_LARGE = [
+    dict(id="lds42_whisper_T500", B=1, T=500, H=20, D=64, lds=42),
+    dict(id="lds42_whisper_T750_B2", B=2, T=750, H=20, D=64, lds=42),
+    dict(id="lds81_whisper_T500_B4", B=4, T=500, H=20, D=64, lds=81),
+    dict(id="lds24_whisper_T500", B=1, T=500, H=20, D=64, lds=24),
+    dict(id="lds82_T1500", B=1, T=1500, H=4, D=64, lds=82),
 ]
 
 ATTN_CASES_LARGE = [
@@ -408,8 +423,8 @@ def check_attention(ops, c, device):
     dev = lambda t: None if t is None else t.to(device)
     if c.get("q32"):
         assert ops.lib.svcmi_tune_set(b"attn_q32", 1) == 0 and ops.lib.svcmi_tune_set(b"attn_ns", c.get("ns", 0)) == 0
-    if c.get("lds"):        # the opt-in LDS-staged kernel (K / V tiles shared by 4 query tiles of a block)
-        assert ops.lib.svcmi_tune_set(b"attn_lds", 1) == 0
+    if c.get("lds"):        # the LDS-staged kernel, forced to one of its compiled shapes
+        assert ops.lib.svcmi_tune_set(b"attn_lds", int(c["lds"])) == 0
     try:
         got = ops.attention(dev(qkv), H, scale, rel_k=dev(rel_k), rel_v=dev(rel_v), window=c.get("W", 0), lengths=dev(lengths))
     finally:

@@ -866,7 +866,7 @@ __global__ __launch_bounds__(64 * QT * KS) void attention_lds_kernel(AttnArgs p)
     }
 }
 
-int g_attn_lds = 0;     // tuning knob ("attn_lds", 0 | 1): the LDS-staged kernel for band-free attention, D <= 64 (off until measured)
+int g_attn_lds = 0;     // tuning knob ("attn_lds"): 0 = heuristic, -1 = never, 1 / 10 * QT + KS = force the LDS-staged kernel (band-free, D <= 64)
 int g_attn_ns = 0;      // tuning knob (svcmi_tune_set("attn_ns", 0 | 1 | 2 | 4 | 8)); 0 = heuristic
 
 int g_attn_q32 = -1;    // tuning knob ("attn_q32", -1 = heuristic | 0 | 1): two query tiles per wave for band-free attention
@@ -881,12 +881,33 @@ int launch_attn(const AttnArgs& a_in, int batch, void* stream) {
     const long long blocks16 = (long long)((a.t + 15) / 16) * a.heads * batch;
     const bool q32 = g_attn_q32 >= 0 ? (g_attn_q32 != 0 && !a.rel_k) : (!a.rel_k && D <= 64 && (a.t >= 1024 || blocks16 >= 1280));
     if constexpr (D <= 64) {
-        if (g_attn_lds && !a.rel_k) {
-            constexpr int QT = 4;
-            a.nq = (a.t + 16 * QT - 1) / (16 * QT);
+        // LDS-staged kernel, 8 query tiles per block: measured on MI355X (profiles/r03a_attnlds.log) it wins where its blocks fill the chip
+        // evenly -- one resident round of <= 256 blocks of 16 waves (B = 2 x T = 500: 43.8 vs 47.7 us, B = 2 x T = 750: 63.8 vs 73.6,
+        // T = 1500: 120 vs 132) or many rounds (B = 16 x T = 500: 195 vs 237 us = 105 TFLOP/s) -- and loses at 1.25 blocks per CU
+        // (B = 4: 80-86 vs 69 us) and for one T = 500 window alone (80 blocks: 43 vs 29.6 us), which keep the kernels below.
+        int lds_code = g_attn_lds < 0 ? 0 : g_attn_lds;
+        if (g_attn_lds == 0 && g_attn_q32 < 0 && g_attn_ns == 0 && !a.rel_k && D == 64) {     // (the other knobs force the older kernels)
+            const long long blocks8 = (long long)((a.t + 127) / 128) * a.heads * batch;
+            if (blocks8 >= 1024) lds_code = 81;
+            else if (blocks8 >= 128 && blocks8 <= 256 && a.t >= 256) lds_code = 82;
+        }
+        if (lds_code && !a.rel_k) {
+            // knob value = 10 * QT + KS (1 = the default shape 4 x 2, one key range for short sequences)
+            int code = lds_code == 1 ? (a.t >= 256 ? 42 : 41) : lds_code;
+            const int qt = code / 10;
+            a.nq = (a.t + 16 * qt - 1) / (16 * qt);
             dim3 g((unsigned)((long long)a.nq * a.heads * batch));
-            if (a.t >= 256) SVCMI_LAUNCH((attention_lds_kernel<D, QT, 2>), g, dim3(64 * QT * 2), 0, stream, a);
-            else SVCMI_LAUNCH((attention_lds_kernel<D, QT, 1>), g, dim3(64 * QT), 0, stream, a);
+            switch (code) {
+                case 21: SVCMI_LAUNCH((attention_lds_kernel<D, 2, 1>), g, dim3(64 * 2), 0, stream, a); break;
+                case 22: SVCMI_LAUNCH((attention_lds_kernel<D, 2, 2>), g, dim3(64 * 4), 0, stream, a); break;
+                case 24: SVCMI_LAUNCH((attention_lds_kernel<D, 2, 4>), g, dim3(64 * 8), 0, stream, a); break;
+                case 41: SVCMI_LAUNCH((attention_lds_kernel<D, 4, 1>), g, dim3(64 * 4), 0, stream, a); break;
+                case 42: SVCMI_LAUNCH((attention_lds_kernel<D, 4, 2>), g, dim3(64 * 8), 0, stream, a); break;
+                case 44: SVCMI_LAUNCH((attention_lds_kernel<D, 4, 4>), g, dim3(64 * 16), 0, stream, a); break;
+                case 81: SVCMI_LAUNCH((attention_lds_kernel<D, 8, 1>), g, dim3(64 * 8), 0, stream, a); break;
+                case 82: SVCMI_LAUNCH((attention_lds_kernel<D, 8, 2>), g, dim3(64 * 16), 0, stream, a); break;
+                default: return SVCMI_EINVAL;
+            }
             return SVCMI_LAST_ERROR();
         }
     }
@@ -1007,7 +1028,8 @@ extern "C" int svcmi_attn_tune_set(const char* name, int32_t value) {
     const char* k4 = "attn_lds";
     i = 0;
     while (k4[i] && name[i] == k4[i]) ++i;
-    if (k4[i] == 0 && name[i] == 0 && (value == 0 || value == 1)) { g_attn_lds = value; return 0; }
+    if (k4[i] == 0 && name[i] == 0 && (value == -1 || value == 0 || value == 1 || value == 21 || value == 22 || value == 24 || value == 41 || value == 42 ||
+                                       value == 44 || value == 81 || value == 82)) { g_attn_lds = value; return 0; }
     const char* k2 = "attn_q32";
     i = 0;
     while (k2[i] && name[i] == k2[i]) ++i;
