@@ -271,19 +271,10 @@ def roofline_pass(wl, fn):
     ops = wl.ops
     fn()
     torch.cuda.synchronize()
-    ops.timeline = []
     torch.cuda._sleep(int(2.0e8))        # ~0.1 s of device spin
+    ops.trace_begin()                    # HIP events around every launch, recorded by the C++ stage host on the launch stream
     fn()
-    torch.cuda.synchronize()
-    tl, ops.timeline = ops.timeline, None
-    agg = {}
-    for name, work, e0, e1 in tl:
-        a = agg.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
-        a["launches"] += 1
-        a["ms"] += e0.elapsed_time(e1)
-        a["flops"] += work.get("flops", 0.0)
-        a["bytes"] += work.get("bytes", 0.0)
-    return agg
+    return ops.trace_end()
 
 
 def measured_traffic(kernel="conv_gemm_kernel"):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SVCMI_ABI_VERSION 16
+#define SVCMI_ABI_VERSION 17
 
 enum svcmi_status { SVCMI_OK = 0, SVCMI_EINVAL = -1, SVCMI_EUNSUPPORTED = -2, SVCMI_EALIGN = -3 };
 
@@ -376,6 +376,168 @@ int svcmi_segment_mean_f32(const float* x, int32_t ldx, const int32_t* order, co
 
 /* int16 side output, vits_decoder/generator.py:167-173: clamp(32768*x, -32768, 32767) truncated to short. */
 int svcmi_source2wav_i16(const float* x, int16_t* y, int64_t n, void* stream);
+
+
+/* =============================================================================================
+ * Stage-level entry points: the composition of the kernels above into the
+ * reference's forward passes, done by a C++ host INSIDE this library -- no Python in the loop, so a
+ * non-Python caller can run a stage, and the Python facade (svcmi.SynthesizerInfer.inference,
+ * svcmi.whisper AudioEncoder) is one ctypes call per stage.
+ *
+ * Models are plain structs of DEVICE pointers to operands already in the packed layouts the kernels
+ * take (weight-norm folded, Conv1d [N,Cin,K] -> [N][K*Cin], ConvTranspose1d polyphase, q|k|v fused,
+ * Flip folded into permutations: svcmi/weights.py does this once at load; `python -m svcmi.tools
+ * pack` writes the same arena to a file a non-Python host can mmap / upload).  The structs are read
+ * on the host during the call only.
+ *
+ * Memory: every intermediate lives in ONE caller-owned device workspace; svcmi_*_workspace_bytes
+ * runs the same allocation plan without launching and returns the size needed for a shape.  Nothing
+ * is allocated, nothing synchronises, every launch goes to `stream`: a call can be captured into a
+ * hipGraph.  Return value as above (first failing launch aborts the stage).
+ */
+#define SVCMI_MAX_WHISPER_BLOCKS 32
+#define SVCMI_MAX_ENC_LAYERS 8
+#define SVCMI_MAX_FLOWS 8
+#define SVCMI_MAX_WN_LAYERS 8
+#define SVCMI_MAX_STAGES 6
+#define SVCMI_MAX_AMP_BLOCKS 3
+#define SVCMI_MAX_AMP_DILATIONS 3
+
+/* one packed GEMM operand: w [n][ldw] fp32 as svcmi_conv_gemm_f32 takes it; bias [n] or NULL; w16 = the svcmi_pack_weights_lp
+ * image for the model's `precision` (NULL = this layer always runs fp32), ldw16 its leading dimension */
+typedef struct svcmi_weight {
+    const float* w;
+    const float* bias;
+    const void* w16;
+    int32_t n, ldw, ldw16, reserved;
+} svcmi_weight;
+
+/* ---- Whisper audio encoder, truncated as whisper/inference.py:11-29 does (n_layers = the kept blocks) */
+typedef struct svcmi_whisper_block {
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;     /* attn_ln, mlp_ln (whisper/model.py:113-116) */
+    svcmi_weight qkv, o, m1, m2;                    /* q|k|v fused [3S][S] (key has no bias: zeros), out, mlp.0, mlp.2 */
+} svcmi_whisper_block;
+
+typedef struct svcmi_whisper_model {
+    int32_t n_state, n_heads, n_layers, n_mels, n_ctx;
+    int32_t precision;                              /* enum svcmi_precision of the linear layers (w16 images must match) */
+    svcmi_weight conv1, conv2;                      /* whisper/model.py:144-145 */
+    const float* pos;                               /* positional_embedding [n_ctx][n_state] */
+    const float *lnp_g, *lnp_b;                     /* ln_post */
+    svcmi_whisper_block blocks[SVCMI_MAX_WHISPER_BLOCKS];
+    /* tuning (0 = the library's table for MI355X): K slices of the two N = n_state projections and tile overrides (>> 8) for
+     * single windows (M <= small_m_rows rows); batched windows use the heuristic of svcmi_conv_gemm_f32 */
+    int32_t split_o, split_mlp, tile_qkv, tile_o, tile_mlp1, tile_mlp2, small_m_rows, reserved;
+    float lp_min_flops;                             /* launches below this stay fp32 in a 16-bit mode (0 = 1.5e9) */
+    int32_t reserved2;
+} svcmi_whisper_model;
+
+int64_t svcmi_whisper_workspace_bytes(const svcmi_whisper_model* m, int32_t batch, int32_t n_frames);
+/* AudioEncoder.forward, whisper/model.py:147-163, on mel [batch][n_mels][n_frames] (the reference's NCL layout) with the
+ * `mel + noise_scale * noise` of whisper/inference.py:46,58 fused into the layout change (noise: same layout, or NULL):
+ * conv1 + GELU, conv2 (stride 2) + GELU, + positional_embedding, n_layers x ResidualAttentionBlock (:118-129), ln_post.
+ * out: [batch][tw][n_state] time-major, tw = (n_frames - 1) / 2 + 1 <= n_ctx (else SVCMI_EINVAL: "incorrect audio shape", :156). */
+int svcmi_whisper_encoder_fwd(const svcmi_whisper_model* m, const float* mel, const float* noise, float noise_scale,
+                              int32_t batch, int32_t n_frames, float* out, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- SynthesizerInfer (vits/models.py:211-256) */
+typedef struct svcmi_enc_layer {                    /* attentions.Encoder layer i, vits/attentions.py:36-72 */
+    svcmi_weight qkv, o, f1, f2;                    /* conv_q|k|v fused, conv_o, FFN conv_1 / conv_2 */
+    const float *rel_k, *rel_v;                     /* emb_rel_k / emb_rel_v [2*window+1][H/heads] */
+    const float *g1, *b1, *g2, *b2;                 /* norm_layers_1 / _2 */
+} svcmi_enc_layer;
+
+typedef struct svcmi_wn_layer { svcmi_weight in, rs; } svcmi_wn_layer;   /* WN in_layers[l], res_skip_layers[l] (modules.py:148-176) */
+
+typedef struct svcmi_flow_layer {                   /* one ResidualCouplingLayer in EXECUTION order of reverse=True, Flip folded in */
+    int32_t x0_off, x1_off, n_wn, reserved;
+    svcmi_weight pre, post, snac;                   /* pre writes (h | skip) rows of 2H (upper H output channels zero) */
+    svcmi_wn_layer wn[SVCMI_MAX_WN_LAYERS];
+} svcmi_flow_layer;
+
+typedef struct svcmi_amp_block {                    /* AMPBlock, vits_decoder/bigv.py:22-58 */
+    int32_t k, n_dil;
+    int32_t dil[SVCMI_MAX_AMP_DILATIONS];
+    int32_t reserved;
+    svcmi_weight c1[SVCMI_MAX_AMP_DILATIONS], c2[SVCMI_MAX_AMP_DILATIONS];
+    const float *a1_alpha[SVCMI_MAX_AMP_DILATIONS], *a1_beta[SVCMI_MAX_AMP_DILATIONS];   /* activations[2q]   (log-scale alpha / beta) */
+    const float *a2_alpha[SVCMI_MAX_AMP_DILATIONS], *a2_beta[SVCMI_MAX_AMP_DILATIONS];   /* activations[2q+1] */
+} svcmi_amp_block;
+
+typedef struct svcmi_gen_stage {                    /* ups[i] + noise_convs[i] + resblocks[i*nk .. i*nk+nk) (generator.py:183-194) */
+    int32_t u, c, cp, up_taps, up_pad, nz_k, nz_stride, nz_pad, n_blocks, reserved;
+    svcmi_weight up, nz;                            /* polyphase ConvTranspose1d operand [u*cp][taps*cin_p]; noise conv [cp][>= nz_k] */
+    svcmi_amp_block blocks[SVCMI_MAX_AMP_BLOCKS];
+} svcmi_gen_stage;
+
+typedef struct svcmi_synth_model {
+    int32_t hidden, inter, n_heads, enc_window, enc_ffn_kernel, flow_kernel, n_enc, n_flow, n_stages;
+    int32_t ppg_dim, vec_dim, spk_dim, upsample_input, hop;
+    int32_t precision;                              /* enum svcmi_precision of prior encoder / flow / generator GEMMs */
+    float lp_min_flops;                             /* 0 = 1.5e9 */
+    float sampling_rate, merge_b;
+    svcmi_weight pre, hub, proj;                    /* enc_p.pre / hub / proj (vits/models.py:26-37) */
+    const float* pit_emb;                           /* enc_p.pit [256][hidden] */
+    svcmi_enc_layer enc[SVCMI_MAX_ENC_LAYERS];
+    svcmi_flow_layer flow[SVCMI_MAX_FLOWS];
+    svcmi_weight adapter, conv_pre, post;           /* SpeakerAdapter W_scale|W_bias fused [2U][spk]; conv_pre; conv_post (1 row, no bias) */
+    const float* merge_w;                           /* NSF merge weights [11] (nsf.py:378-381) */
+    const float* filt;                              /* the 12 Kaiser-sinc taps */
+    const float *post_alpha, *post_beta;            /* activation_post */
+    svcmi_gen_stage stages[SVCMI_MAX_STAGES];
+} svcmi_synth_model;
+
+enum svcmi_synth_stop { SVCMI_STOP_NONE = 0, SVCMI_STOP_PRIOR = 1, SVCMI_STOP_FLOW = 2, SVCMI_STOP_GEN_PRE = 3, SVCMI_STOP_STAGE0 = 4 /* + i */ };
+
+typedef struct svcmi_synth_io {
+    /* inputs, all device pointers */
+    const float* ppg;        /* [batch][t >> ppg_row_shift][ppg_dim] (+ ppg_bstride): shift 1 = the 50 fps Whisper output, x2 repeat fused */
+    const float* vec;        /* [batch][t][vec_dim] */
+    const float* pit;        /* [batch][t] Hz */
+    const float* spk;        /* [batch][spk_dim] */
+    const int32_t* lengths;  /* [batch] */
+    const float* source;     /* [batch][t*hop] harmonic source (svcmi_pitch2source_fwd) */
+    const float* noise;      /* [batch][inter][t]: the randn_like(m) of vits/models.py:51 in the reference's layout */
+    int64_t ppg_bstride;     /* floats; 0 = dense */
+    int32_t ppg_row_shift, batch, t;
+    int32_t stream_frames;   /* 0 = the generator sees the whole chunk; N = time tiles of N frames + 32-frame halos (bit-identical) */
+    int32_t stop_after;      /* enum svcmi_synth_stop: timing aid (scripts/stage_times.py): the pipeline stops there, `wave` is not written */
+    int32_t reserved;
+    /* outputs */
+    float* wave;             /* [batch][t*hop] */
+    float* z_p;              /* optional [batch][t][inter] time-major copies of the prior sample / flow output (NULL = skip) */
+    float* z;
+} svcmi_synth_io;
+
+int64_t svcmi_synth_workspace_bytes(const svcmi_synth_model* m, int32_t batch, int32_t t, int32_t stream_frames);
+/* Generator.pitch2source, vits_decoder/generator.py:160-165: svcmi_pitch_prefix_f64 + svcmi_pitch_source_f32.  workspace >= batch*t*11 doubles. */
+int svcmi_pitch2source_fwd(const svcmi_synth_model* m, const float* f0, const float* rand_ini, const float* noise, int32_t batch,
+                           int32_t t, float* source, void* workspace, int64_t workspace_bytes, void* stream);
+/* TextEncoder.forward (vits/models.py:39-52 + attentions.py:60-72): z_p [batch][t][inter] time-major */
+int svcmi_text_encoder_fwd(const svcmi_synth_model* m, const svcmi_synth_io* io, float* z_p, void* workspace, int64_t workspace_bytes, void* stream);
+/* ResidualCouplingBlock.forward(reverse=True) (vits/models.py:89-94): x [batch][t][inter] updated in place */
+int svcmi_flow_reverse_fwd(const svcmi_synth_model* m, const svcmi_synth_io* io, float* x, void* workspace, int64_t workspace_bytes, void* stream);
+/* Generator.inference (vits_decoder/generator.py:175-200) on z [batch][t][inter] time-major -> io->wave */
+int svcmi_generator_fwd(const svcmi_synth_model* m, const svcmi_synth_io* io, const float* z, void* workspace, int64_t workspace_bytes, void* stream);
+/* SynthesizerInfer.inference (vits/models.py:251-256): the three stages above on one workspace */
+int svcmi_synth_infer_fwd(const svcmi_synth_model* m, const svcmi_synth_io* io, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* y[r][0:cols] = x[r][0:cols] for `rows` rows of leading dimensions ldy / ldx (floats): the strided device copies of the host
+ * above (time tiles of the streaming decoder, optional z_p / z outputs) as a kernel, so that they are stream-ordered and graph-capturable. */
+int svcmi_copy2d_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, int64_t cols, void* stream);
+
+/* Per-launch timing of the stage entry points (bench.py's roofline leg): between svcmi_trace_begin and svcmi_trace_end every
+ * kernel launch the host makes on the calling thread is bracketed by HIP events on its stream.  svcmi_trace_end waits for the last one and
+ * fills `out` (up to `cap` records, in launch order); returns the number of launches seen.  Not for production use. */
+typedef struct svcmi_trace_record { int32_t op; float ms; double flops, bytes; } svcmi_trace_record;
+int svcmi_trace_begin(int32_t max_records);
+int svcmi_trace_end(svcmi_trace_record* out, int32_t cap);
+const char* svcmi_trace_op_name(int32_t op);
+
+/* Layout check for FFI bindings: out[i] = sizeof of svcmi_weight, svcmi_whisper_model, svcmi_synth_model, svcmi_synth_io,
+ * svcmi_trace_record, svcmi_conv_desc, svcmi_snake_conv_desc (in this order, up to `cap`); returns the count written.  A binding
+ * compares them with its own struct sizes before it trusts a filled struct (svcmi/_lib.py does at load). */
+int svcmi_struct_sizes(int64_t* out, int32_t cap);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,8 @@
 #!/usr/bin/env python
 """What does a kernel class cost under clips in flight?  Encoder-only lanes (1 / 2 / 4) with the attention or the split-K LayerNorm
-launches skipped (outputs left stale: timing only).  Tuning aid: python scripts/lanes_skip_probe.py"""
+launches skipped (outputs left stale: timing only).  Tuning aid of round 2: python scripts/lanes_skip_probe.py
+HISTORICAL: it patched the Python launch wrappers of the encoder; since round 3 the encoder is composed by the C++ stage host
+(svcmi_whisper_encoder_fwd), so this script no longer skips anything -- kept for the record of profiles/r02z_*."""
 import os
 import sys
 import time

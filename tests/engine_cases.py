@@ -70,10 +70,12 @@ def check_generator_widths_against_oracle(ops, device, T=5, B=2, tol=TIGHT, prec
         lens[-1] = max(1, T - 2)
     src = m.pitch2source(d["pit"], noise=(d["rand_ini"], d["src_noise"]))
     m.precision = precision
-    saved, launches = ops.lp_min_flops, ops.launches
+    saved = ops.lp_min_flops
     if precision is not None:
         ops.lp_min_flops = 0.0           # tiny shapes: force every eligible GEMM through the reduced-precision kernels
+    ops.trace_begin()
     wav = m.inference(d["ppg"], d["vec"], d["pit"], d["spk"], lens, src, noise=d["enc_noise"])
+    trace = ops.trace_end()
     ops.lp_min_flops = saved
     with torch.no_grad():
         o_src = O.pitch2source(sd, hp, d["pit"], d["rand_ini"], d["src_noise"])
@@ -84,9 +86,8 @@ def check_generator_widths_against_oracle(ops, device, T=5, B=2, tol=TIGHT, prec
         assert errs["source"] <= 5e-5 and errs["wave_vs_fp64"] <= WAVE_TOL and errs["wave"] <= WAVE_TOL, errs
         return errs
     if precision is not None:
-        w = m._weights()
-        assert getattr(w.pre_conv_w, "_svcmi_lp", None) and getattr(w.flow[0]["wn"][0]["in_w"], "_svcmi_lp", None) \
-            and getattr(w.stages[0]["blocks"][0]["c1"][0][0], "_svcmi_lp", None), "reduced-precision kernels did not run"
+        assert trace.get("svcmi_conv_gemm_lp", {}).get("launches", 0) >= 20 and trace.get("svcmi_conv_gemm_group_lp", {}).get("launches", 0) >= 6, \
+            f"reduced-precision kernels did not run: { {k: v['launches'] for k, v in trace.items()} }"
         assert errs["wave"] > 0.0
     assert errs["source"] <= 5e-5 and errs["wave"] <= min(tol * 5, WAVE_TOL), errs
     return errs
@@ -101,10 +102,12 @@ def check_whisper_golden(ops, device, tag, dims, tol=TIGHT, precision=None):
     saved = ops.lp_min_flops
     if precision is not None:
         ops.lp_min_flops = 0.0
+    ops.trace_begin()
     out = wm.encoder(_t(g["mel"]), _t(g["mel_noise"]), 0.1)
+    trace = ops.trace_end()
     ops.lp_min_flops = saved
     if precision is not None:
-        assert getattr(wm.weights.blocks[0]["qkv_w"], "_svcmi_lp", None), "reduced-precision kernels did not run"
+        assert trace.get("svcmi_conv_gemm_lp", {}).get("launches", 0) >= 4 * len(wm.weights.blocks), "reduced-precision kernels did not run"
     err = maxerr(out, _t(g["ppg"]))
     assert err <= tol * max(1.0, float(np.abs(g["ppg"]).max())), err
     return err

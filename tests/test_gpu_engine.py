@@ -373,16 +373,19 @@ def test_batch_folder_driver_single_rank(ops, tmp_path, monkeypatch):
     assert not [f for f in os.listdir("_svc_out") if f.startswith(".rank")]          # intermediates removed
 
 
-@pytest.mark.parametrize("streams", [False, True])
-def test_ungrouped_generator_paths_agree(ops, streams):
-    """The fallback structure (one launch per AMP block and step, serial or on forked streams) against the grouped launches."""
+def test_ungrouped_generator_paths_agree(ops):
+    """The fallback structure of the C++ stage host (one launch per AMP block and step, for stages the grouped scheme does not fit)
+    against the grouped launches."""
     hp = C.base_hp()
     m, _ = E.make_model(hp, ops, "cuda")
     d = I.synth_clip(T=60, hp=hp, seed=11, B=2)
     src = m.pitch2source(d["pit"], noise=(d["rand_ini"], d["src_noise"]))
     run = lambda: m.inference(d["ppg"], d["vec"], d["pit"], d["spk"], d["lengths"], src, noise=d["enc_noise"])
     want = run()
-    m.grouped_blocks, m.parallel_blocks = False, streams
-    got = run()
+    assert ops.lib.svcmi_tune_set(b"amp_grouped", 0) == 0
+    try:
+        got = run()
+    finally:
+        ops.lib.svcmi_tune_set(b"amp_grouped", 1)
     torch.cuda.synchronize()
     assert E.maxerr(got, want) <= 2e-5

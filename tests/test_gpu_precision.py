@@ -73,11 +73,10 @@ def clip10(ops, whisper):
 
 def _count_lp(ops, fn):
     """Run fn and return (result, number of reduced-precision GEMM launches it made)."""
-    ops.timeline = []
+    ops.trace_begin()
     out = fn()
-    torch.cuda.synchronize()
-    tl, ops.timeline = ops.timeline, None
-    return out, sum(1 for (name, _, _, _) in tl if name.endswith("_lp") and "pack" not in name)
+    trace = ops.trace_end()
+    return out, sum(v["launches"] for name, v in trace.items() if name.endswith("_lp") and "pack" not in name)
 
 
 @pytest.mark.parametrize("mode", MODES)

@@ -200,6 +200,23 @@ inline unsigned blocks_for(long long total) {
 
 inline bool mis16(const void* p) { return ((uintptr_t)p & 15) != 0; }
 
+// y[r][0:cols] = x[r][0:cols]: the strided device copies of the stage host (csrc/host_stages.hip) as a stream-ordered kernel
+__global__ __launch_bounds__(TPB) void copy2d_kernel(const float* x, long long ldx, float* y, long long ldy, long long rows, long long cols, int vec) {
+    if (vec) {
+        const long long c4 = cols >> 2, total = rows * c4;
+        for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+            const long long r = i / c4, c = (i - r * c4) * 4;
+            *reinterpret_cast<float4*>(y + r * ldy + c) = *reinterpret_cast<const float4*>(x + r * ldx + c);
+        }
+    } else {
+        const long long total = rows * cols;
+        for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+            const long long r = i / cols, c = i - r * cols;
+            y[r * ldy + c] = x[r * ldx + c];
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int svcmi_wn_gate_f32(const float* a, const float* bias, float* out, int32_t batch, int32_t t, int32_t h, int32_t lda,
@@ -268,5 +285,13 @@ extern "C" int svcmi_nlc_to_ncl_f32(const float* x, int32_t ldx, float* y, int32
     if (!x || !y || batch <= 0 || c <= 0 || t <= 0 || ldx < c) return SVCMI_EINVAL;
     if (batch > 65535) return SVCMI_EUNSUPPORTED;
     SVCMI_LAUNCH(nlc_to_ncl_kernel, dim3((t + 31) / 32, (c + 31) / 32, batch), dim3(TPB), 0, stream, x, ldx, y, c, t);
+    return SVCMI_LAST_ERROR();
+}
+
+extern "C" int svcmi_copy2d_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, int64_t cols, void* stream) {
+    if (!x || !y || rows <= 0 || cols <= 0 || ldx < cols || ldy < cols) return SVCMI_EINVAL;
+    const int vec = cols % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && !mis16(x) && !mis16(y);
+    SVCMI_LAUNCH(copy2d_kernel, dim3(blocks_for(vec ? rows * (cols / 4) : rows * cols)), dim3(TPB), 0, stream, x, (long long)ldx, y,
+                 (long long)ldy, (long long)rows, (long long)cols, vec);
     return SVCMI_LAST_ERROR();
 }

@@ -1,14 +1,14 @@
 """ctypes binding of libsvcmi.so (include/svcmi.h).  No fallback: a missing library raises."""
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(HERE, "libsvcmi.so")
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_MISH, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4, 5
 CONV_ACCUMULATE, CONV_MASK_IN, CONV_MASK_OUT, CONV_PARTIALS = 1, 2, 4, 8
-ABI_VERSION = 16
+ABI_VERSION = 17
 PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16 = 0, 1, 2, 3
 PRECISIONS = {None: 0, "f32": 0, "fp32": 0, "bf16x3": 1, "bf16": 2, "f16": 3, "fp16": 3}
 CONV_TILE_64x128 = 9
@@ -32,6 +32,80 @@ class ConvDesc(Structure):
         ("workspace", c_void_p), ("workspace_floats", c_int64),
         ("counters", c_void_p), ("counters_len", c_int64),
     ]
+
+
+# ---- stage-level entry points (include/svcmi.h "Stage-level entry points"): ctypes mirrors of the model / io structs
+MAX_WHISPER_BLOCKS, MAX_ENC_LAYERS, MAX_FLOWS, MAX_WN_LAYERS, MAX_STAGES, MAX_AMP_BLOCKS, MAX_AMP_DILATIONS = 32, 8, 8, 8, 6, 3, 3
+STOP_NONE, STOP_PRIOR, STOP_FLOW, STOP_GEN_PRE, STOP_STAGE0 = 0, 1, 2, 3, 4
+
+
+class Weight(Structure):
+    """svcmi_weight"""
+    _fields_ = [("w", c_void_p), ("bias", c_void_p), ("w16", c_void_p), ("n", c_int32), ("ldw", c_int32), ("ldw16", c_int32),
+                ("reserved", c_int32)]
+
+
+class WhisperBlock(Structure):
+    _fields_ = [("ln1_g", c_void_p), ("ln1_b", c_void_p), ("ln2_g", c_void_p), ("ln2_b", c_void_p),
+                ("qkv", Weight), ("o", Weight), ("m1", Weight), ("m2", Weight)]
+
+
+class WhisperModel(Structure):
+    _fields_ = [("n_state", c_int32), ("n_heads", c_int32), ("n_layers", c_int32), ("n_mels", c_int32), ("n_ctx", c_int32),
+                ("precision", c_int32), ("conv1", Weight), ("conv2", Weight), ("pos", c_void_p), ("lnp_g", c_void_p), ("lnp_b", c_void_p),
+                ("blocks", WhisperBlock * MAX_WHISPER_BLOCKS),
+                ("split_o", c_int32), ("split_mlp", c_int32), ("tile_qkv", c_int32), ("tile_o", c_int32), ("tile_mlp1", c_int32),
+                ("tile_mlp2", c_int32), ("small_m_rows", c_int32), ("reserved", c_int32), ("lp_min_flops", c_float), ("reserved2", c_int32)]
+
+
+class EncLayer(Structure):
+    _fields_ = [("qkv", Weight), ("o", Weight), ("f1", Weight), ("f2", Weight), ("rel_k", c_void_p), ("rel_v", c_void_p),
+                ("g1", c_void_p), ("b1", c_void_p), ("g2", c_void_p), ("b2", c_void_p)]
+
+
+class WnLayer(Structure):
+    _fields_ = [("in_", Weight), ("rs", Weight)]
+
+
+class FlowLayer(Structure):
+    _fields_ = [("x0_off", c_int32), ("x1_off", c_int32), ("n_wn", c_int32), ("reserved", c_int32),
+                ("pre", Weight), ("post", Weight), ("snac", Weight), ("wn", WnLayer * MAX_WN_LAYERS)]
+
+
+class AmpBlock(Structure):
+    _fields_ = [("k", c_int32), ("n_dil", c_int32), ("dil", c_int32 * MAX_AMP_DILATIONS), ("reserved", c_int32),
+                ("c1", Weight * MAX_AMP_DILATIONS), ("c2", Weight * MAX_AMP_DILATIONS),
+                ("a1_alpha", c_void_p * MAX_AMP_DILATIONS), ("a1_beta", c_void_p * MAX_AMP_DILATIONS),
+                ("a2_alpha", c_void_p * MAX_AMP_DILATIONS), ("a2_beta", c_void_p * MAX_AMP_DILATIONS)]
+
+
+class GenStage(Structure):
+    _fields_ = [("u", c_int32), ("c", c_int32), ("cp", c_int32), ("up_taps", c_int32), ("up_pad", c_int32), ("nz_k", c_int32),
+                ("nz_stride", c_int32), ("nz_pad", c_int32), ("n_blocks", c_int32), ("reserved", c_int32),
+                ("up", Weight), ("nz", Weight), ("blocks", AmpBlock * MAX_AMP_BLOCKS)]
+
+
+class SynthModel(Structure):
+    _fields_ = [("hidden", c_int32), ("inter", c_int32), ("n_heads", c_int32), ("enc_window", c_int32), ("enc_ffn_kernel", c_int32),
+                ("flow_kernel", c_int32), ("n_enc", c_int32), ("n_flow", c_int32), ("n_stages", c_int32),
+                ("ppg_dim", c_int32), ("vec_dim", c_int32), ("spk_dim", c_int32), ("upsample_input", c_int32), ("hop", c_int32),
+                ("precision", c_int32), ("lp_min_flops", c_float), ("sampling_rate", c_float), ("merge_b", c_float),
+                ("pre", Weight), ("hub", Weight), ("proj", Weight), ("pit_emb", c_void_p),
+                ("enc", EncLayer * MAX_ENC_LAYERS), ("flow", FlowLayer * MAX_FLOWS),
+                ("adapter", Weight), ("conv_pre", Weight), ("post", Weight),
+                ("merge_w", c_void_p), ("filt", c_void_p), ("post_alpha", c_void_p), ("post_beta", c_void_p),
+                ("stages", GenStage * MAX_STAGES)]
+
+
+class SynthIO(Structure):
+    _fields_ = [("ppg", c_void_p), ("vec", c_void_p), ("pit", c_void_p), ("spk", c_void_p), ("lengths", c_void_p), ("source", c_void_p),
+                ("noise", c_void_p), ("ppg_bstride", c_int64), ("ppg_row_shift", c_int32), ("batch", c_int32), ("t", c_int32),
+                ("stream_frames", c_int32), ("stop_after", c_int32), ("reserved", c_int32),
+                ("wave", c_void_p), ("z_p", c_void_p), ("z", c_void_p)]
+
+
+class TraceRecord(Structure):
+    _fields_ = [("op", c_int32), ("ms", c_float), ("flops", c_double), ("bytes", c_double)]
 
 
 _P, _I, _L, _F = c_void_p, c_int32, c_int64, c_float
@@ -81,6 +155,19 @@ SIGNATURES = {
     "svcmi_snake_alias_group_f32": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "svcmi_block_mean_f32": (c_int, [_P, _I, _P, _L, _P]),
     "svcmi_source2wav_i16": (c_int, [_P, _P, _L, _P]),
+    "svcmi_whisper_workspace_bytes": (c_int64, [POINTER(WhisperModel), _I, _I]),
+    "svcmi_whisper_encoder_fwd": (c_int, [POINTER(WhisperModel), _P, _P, _F, _I, _I, _P, _P, _L, _P]),
+    "svcmi_synth_workspace_bytes": (c_int64, [POINTER(SynthModel), _I, _I, _I]),
+    "svcmi_pitch2source_fwd": (c_int, [POINTER(SynthModel), _P, _P, _P, _I, _I, _P, _P, _L, _P]),
+    "svcmi_text_encoder_fwd": (c_int, [POINTER(SynthModel), POINTER(SynthIO), _P, _P, _L, _P]),
+    "svcmi_flow_reverse_fwd": (c_int, [POINTER(SynthModel), POINTER(SynthIO), _P, _P, _L, _P]),
+    "svcmi_generator_fwd": (c_int, [POINTER(SynthModel), POINTER(SynthIO), _P, _P, _L, _P]),
+    "svcmi_synth_infer_fwd": (c_int, [POINTER(SynthModel), POINTER(SynthIO), _P, _L, _P]),
+    "svcmi_copy2d_f32": (c_int, [_P, _L, _P, _L, _L, _L, _P]),
+    "svcmi_trace_begin": (c_int, [_I]),
+    "svcmi_trace_end": (c_int, [POINTER(TraceRecord), _I]),
+    "svcmi_trace_op_name": (c_char_p, [_I]),
+    "svcmi_struct_sizes": (c_int, [POINTER(c_int64), _I]),
 }
 
 
@@ -104,4 +191,10 @@ def load_library(path=None):
         fn.restype, fn.argtypes = res, args
     if lib.svcmi_abi_version() != ABI_VERSION:
         raise SvcmiError(f"ABI mismatch: library {lib.svcmi_abi_version()} vs binding {ABI_VERSION}")
+    import ctypes as _c
+    sizes = (c_int64 * 8)()
+    n = lib.svcmi_struct_sizes(sizes, 8)
+    mine = [_c.sizeof(t) for t in (Weight, WhisperModel, SynthModel, SynthIO, TraceRecord, ConvDesc, SnakeConvDesc)]
+    if list(sizes[:n]) != mine:
+        raise SvcmiError(f"struct layout mismatch: library {list(sizes[:n])} vs binding {mine}")
     return lib

@@ -12,7 +12,8 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_GELU, ACT_MISH, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, CONV_ACCUMULATE, CONV_MASK_IN,  # noqa: F401
-                   CONV_MASK_OUT, CONV_PARTIALS, PREC_BF16X3, PREC_F32, PRECISIONS, ConvDesc, SnakeConvDesc, SvcmiError)
+                   CONV_MASK_OUT, CONV_PARTIALS, PREC_BF16X3, PREC_F32, PRECISIONS, ConvDesc, SnakeConvDesc, SvcmiError, SynthIO,
+                   TraceRecord)
 
 
 def _ptr(t):
@@ -36,6 +37,7 @@ class Ops:
         self.launches = 0
         self.workspaces = {}     # split-K scratch, one per (device, stream): launches on parallel streams must not share it
         self.workspace_floats = 16 * 1024 * 1024
+        self._retired = []
         # split-K slices combined inside the GEMM launch by the last-arriving block of each tile.  Correct (bit-identical to
         # the two-kernel reduction, tests/test_gpu_kernels.py) but SLOWER on MI355X at these slab sizes (64-128 KB per tile):
         # 10 s step 15.8 ms (write-through slabs) / 16.1 ms (release fence per block) vs 12.6 ms -> off by default.
@@ -119,6 +121,113 @@ class Ops:
 
     def empty(self, *shape, like=None, dtype=torch.float32):
         return torch.empty(*shape, dtype=dtype, device=like.device if like is not None else ("cuda" if self.on_gpu else "cpu"))
+
+
+    # ------------------------------------------------------------------ stage-level entry points (csrc/host_stages.hip)
+    def stage_workspace(self, nbytes, device):
+        """The caller-owned workspace of the stage entry points: one buffer per (device, stream), grown on demand.  Stages issued on one
+        stream run one after the other, so they can share it; lanes / chunk streams each get their own."""
+        key = (device, self._stream(), "stage")
+        ws = self.workspaces.get(key)
+        if ws is None or ws.numel() < nbytes + 256:
+            if ws is not None:
+                self._retired.append(ws)       # a captured HIP graph may still point into it
+            ws = self.workspaces[key] = torch.empty(int(nbytes) + 512, dtype=torch.uint8, device=device)
+        base = (ws.data_ptr() + 255) & ~255            # the entry points want 256-byte alignment (CPU tensors of the emulator tests: 64)
+        return base, ws.numel() - (base - ws.data_ptr())
+
+    def _stage_call(self, name, *args):
+        rc = getattr(self.lib, name)(*args)
+        self.launches += 1
+        if rc != 0:
+            raise SvcmiError(f"{name} failed with code {rc}")
+
+    def whisper_encoder_fwd(self, cm, mel, noise, noise_scale):
+        """AudioEncoder.forward (whisper/model.py:147-163) as ONE call: mel [B, n_mels, n] (+ noise_scale * noise) -> [B, tw, n_state]."""
+        self._chk(mel, noise)
+        m = cm.struct
+        m.lp_min_flops = max(float(self.lp_min_flops), 1e-30)
+        B, _, n = mel.shape
+        need = self.lib.svcmi_whisper_workspace_bytes(ctypes.byref(m), B, n)
+        if need < 0:
+            if (n - 1) // 2 + 1 > m.n_ctx:
+                raise AssertionError("incorrect audio shape")                           # whisper/model.py:156
+            raise SvcmiError(f"svcmi_whisper_workspace_bytes failed with code {need}")
+        ws, ws_bytes = self.stage_workspace(need, mel.device)
+        out = torch.empty(B, (n - 1) // 2 + 1, m.n_state, dtype=torch.float32, device=mel.device)
+        self._stage_call("svcmi_whisper_encoder_fwd", ctypes.byref(m), _ptr(mel), _ptr(noise), float(noise_scale), B, n, _ptr(out), ws,
+                         ws_bytes, self._stream())
+        return out
+
+    def pitch2source_fwd(self, cm, f0, rand_ini, noise):
+        """Generator.pitch2source (vits_decoder/generator.py:160-165): f0 [B,T], rand_ini [B,11], noise [B,T*hop,11] -> [B, T*hop]."""
+        self._chk(f0, rand_ini, noise)
+        m = cm.struct
+        B, T = f0.shape
+        ws, ws_bytes = self.stage_workspace(B * T * 11 * 8 + 256, f0.device)
+        out = torch.empty(B, T * m.hop, dtype=torch.float32, device=f0.device)
+        self._stage_call("svcmi_pitch2source_fwd", ctypes.byref(m), _ptr(f0), _ptr(rand_ini), _ptr(noise), B, T, _ptr(out), ws,
+                         ws_bytes, self._stream())
+        return out
+
+    def synth_infer_fwd(self, cm, ppg, vec, pit, spk, lengths, source, noise, *, ppg_row_shift=0, stream_frames=0, stop_after=0,
+                        want_parts=False):
+        """SynthesizerInfer.inference (vits/models.py:251-256) as ONE call.  ppg [B, T >> shift, ppg_dim] (a batch-strided view is fine),
+        vec [B,T,vec_dim], pit [B,T], spk [B,spk_dim], lengths int32 [B], source [B, T*hop], noise [B, inter, T] -> wave [B, 1, T*hop]
+        (+ time-major z_p / z [B,T,inter] with ``want_parts``)."""
+        self._chk(ppg, vec, pit, spk, lengths, source, noise)
+        m = cm.struct
+        m.lp_min_flops = max(float(self.lp_min_flops), 1e-30)
+        B, T = pit.shape
+        if ppg.stride(2) != 1 or ppg.stride(1) != ppg.shape[2] or ppg.shape[1] != (T + (1 << ppg_row_shift) - 1) >> ppg_row_shift:
+            raise SvcmiError(f"ppg {tuple(ppg.shape)} / strides {ppg.stride()} do not fit {T} frames with row shift {ppg_row_shift}")
+        for t_, shape in ((vec, (B, T, m.vec_dim)), (spk, (B, m.spk_dim)), (source, (B, T * m.hop)), (noise, (B, m.inter, T))):
+            if tuple(t_.shape) != shape or not t_.is_contiguous():
+                raise SvcmiError(f"expected a contiguous tensor of shape {shape}, got {tuple(t_.shape)}")
+        need = self.lib.svcmi_synth_workspace_bytes(ctypes.byref(m), B, T, int(stream_frames))
+        if need < 0:
+            raise SvcmiError(f"svcmi_synth_workspace_bytes failed with code {need}")
+        ws, ws_bytes = self.stage_workspace(need, pit.device)
+        io = SynthIO()
+        io.ppg, io.vec, io.pit, io.spk, io.lengths, io.source, io.noise = (_ptr(t_) for t_ in (ppg, vec, pit, spk, lengths, source, noise))
+        io.ppg_bstride, io.ppg_row_shift, io.batch, io.t = ppg.stride(0), ppg_row_shift, B, T
+        io.stream_frames, io.stop_after = int(stream_frames), int(stop_after)
+        wave = torch.empty(B, 1, T * m.hop, dtype=torch.float32, device=pit.device)
+        parts = None
+        if want_parts:
+            parts = (torch.empty(B, T, m.inter, dtype=torch.float32, device=pit.device), torch.empty(B, T, m.inter, dtype=torch.float32, device=pit.device))
+            io.z_p, io.z = _ptr(parts[0]), _ptr(parts[1])
+        io.wave = _ptr(wave)
+        self._stage_call("svcmi_synth_infer_fwd", ctypes.byref(m), ctypes.byref(io), ws, ws_bytes, self._stream())
+        return (wave, parts) if want_parts else wave
+
+    def trace_begin(self, max_records=8192):
+        """Per-launch timing of everything launched from here on (stage entry points: HIP events inside the C host; single-op calls of
+        this class: torch events): bench.py's roofline leg."""
+        self.timeline = []
+        if self.lib.svcmi_trace_begin(max_records) != 0:
+            raise SvcmiError("svcmi_trace_begin failed")
+
+    def trace_end(self):
+        """-> {entry point: {launches, ms, flops, bytes}} since trace_begin (waits for the traced launches)."""
+        recs = (TraceRecord * 8192)()
+        n = min(self.lib.svcmi_trace_end(recs, 8192), 8192)
+        tl, self.timeline = self.timeline or [], None
+        agg = {}
+
+        def add(name, ms, flops, nbytes):
+            a = agg.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            a["launches"] += 1
+            a["ms"] += ms
+            a["flops"] += flops
+            a["bytes"] += nbytes
+        for i in range(n):
+            add(self.lib.svcmi_trace_op_name(recs[i].op).decode(), recs[i].ms, recs[i].flops, recs[i].bytes)
+        if tl and self.on_gpu:
+            torch.cuda.synchronize()
+        for name, work, e0, e1 in tl:
+            add(name, e0.elapsed_time(e1) if self.on_gpu else 0.0, work.get("flops", 0.0), work.get("bytes", 0.0))
+        return agg
 
     # ------------------------------------------------------------------ conv / linear
     def _conv_desc(self, x, w, bias=None, *, ksize=1, stride=1, dilation=1, pad=0, t_out=None, act=ACT_NONE,

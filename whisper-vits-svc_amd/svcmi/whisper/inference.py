@@ -9,76 +9,48 @@ SURVEY.md section 0).
 import numpy as np
 import torch
 
+from .. import _lib, cmodel
 from .. import weights as PW
-from ..ops import ACT_GELU, Ops
+from ..ops import Ops
 from ..vits import consts as K
 
 
 class AudioEncoder:
-    """whisper/model.py:132-163 (conv stem + pre-LN attention blocks + ln_post), time-major fp32."""
+    """whisper/model.py:132-163 (conv stem + pre-LN attention blocks + ln_post), time-major fp32.  The forward pass is composed by
+    the C++ host inside libsvcmi.so (csrc/host_stages.hip: svcmi_whisper_encoder_fwd); this object owns the weights, the tuning
+    table and makes ONE library call."""
 
     def __init__(self, w, ops):
         self.w, self.ops = w, ops
-        # Tuning table for the M = 500-row window GEMMs (scripts/microbench.py gemm / wp16, MI355X): K slices of the two
-        # N = n_state projections, and the 64x80 tile of the 16x16x4 policy where it balances the 256 CUs better than
-        # 64x64 (N = 5120 -> 8 x 64 = 512 blocks; N = 1280 with 2-4 K slices); the QKV projection stays on 64x64.
-        self.split_o, self.split_mlp = 2, 4
-        self.tile_qkv = 0                        # 0 = library heuristic (64x64 at M = 500)
-        self.tile_o = self.tile_mlp1 = self.tile_mlp2 = 6          # SVCMI_CONV_TILE_P16_64x80 >> 8
+        # Tuning table for the M = 500-row window GEMMs (0 = the library's own table, measured with scripts/microbench.py gemm / wp16
+        # / lp on MI355X: 2 / 4 K slices for the two N = n_state projections, the 64x80 tile of the 16x16x4 policy where it balances
+        # the 256 CUs better than 64x64; -1 = the tile heuristic of svcmi_conv_gemm_f32).  Fields of svcmi_whisper_model.
+        self.split_o = self.split_mlp = 0
+        self.tile_qkv = self.tile_o = self.tile_mlp1 = self.tile_mlp2 = 0
+        self.small_m_rows = 0                    # above this many GEMM rows (0 = 1024) the library's own tile heuristic takes over
         # GEMM operand precision of this encoder: None = fp32 (parity default); "bf16x3" / "bf16" / "f16" (the reference's
         # own accelerator path is fp16: whisper/inference.py:22-23,43-44) route the linear layers through
         # svcmi_conv_gemm_lp.  LayerNorm, softmax, GELU, residual stream and accumulation stay fp32 in every mode.
         self.precision = None
-        self.small_m_rows = 1024                 # above this many GEMM rows the library's own tile heuristic takes over
-        self.lp_split_o, self.lp_split_mlp = 2, 4
-        # measured (scripts/microbench.py lp, profiles/r02a_microbench_lp.log): the two N = n_state projections run best on 64x128
-        # tiles with 2 / 4 K slices (17 vs 22 us, 37 vs 38 us at Tw = 500); QKV / MLP-up follow the library heuristic
-        self.lp_tile_qkv = self.lp_tile_mlp1 = 0      # 0 = library heuristic
-        self.lp_tile_o = self.lp_tile_mlp2 = 9        # SVCMI_CONV_TILE_64x128 >> 8
+        self._cm = {}
+
+    def _cmodel(self):
+        prec = _lib.PRECISIONS.get(self.precision, self.precision)
+        cm = self._cm.get(prec)
+        if cm is None:
+            cm = self._cm[prec] = cmodel.whisper_cmodel(self.w, self.ops, prec)
+        m = cm.struct
+        m.split_o, m.split_mlp, m.small_m_rows = self.split_o, self.split_mlp, self.small_m_rows
+        m.tile_qkv, m.tile_o, m.tile_mlp1, m.tile_mlp2 = self.tile_qkv, self.tile_o, self.tile_mlp1, self.tile_mlp2
+        return cm
 
     @torch.no_grad()
     def __call__(self, mel, noise=None, noise_scale=0.1):
-        with self.ops.use_precision(self.precision):
-            return self._forward(mel, noise, noise_scale)
-
-    def _forward(self, mel, noise, noise_scale):
-        w, ops = self.w, self.ops
-        lp = ops.precision != 0
-        split_o, split_mlp = (self.lp_split_o, self.lp_split_mlp) if lp else (self.split_o, self.split_mlp)
-        tile_qkv, tile_o, tile_m1, tile_m2 = (self.lp_tile_qkv, self.lp_tile_o, self.lp_tile_mlp1, self.lp_tile_mlp2) if lp else \
-            (self.tile_qkv, self.tile_o, self.tile_mlp1, self.tile_mlp2)
-        if mel.shape[0] * ((mel.shape[2] + 1) // 2) > self.small_m_rows:
-            # batched windows (BASELINE.json configs[3] / [4]): M = B * Tw rows fill the chip with large tiles; the K slices and
-            # the 64x80 tiles above are a single-window (M = 500 .. 750) tuning
-            split_o = split_mlp = 1
-            tile_qkv = tile_o = tile_m1 = tile_m2 = 0
-        dev = w.lnp_g.device
+        dev = self.w.lnp_g.device
         mel = mel.to(dev, torch.float32).contiguous()
         if noise is not None:
             noise = noise.to(dev, torch.float32).contiguous()
-        x = ops.ncl_to_nlc(mel, noise, noise_scale if noise is not None else 0.0)          # [B, n, 80]
-        x = ops.conv(x, w.conv1_w, w.conv1_b, ksize=3, pad=1, act=ACT_GELU)               # model.py:150
-        n = x.shape[1]
-        tw = (n + 2 - 3) // 2 + 1
-        if tw > w.pos.shape[0]:
-            raise AssertionError("incorrect audio shape")                                   # model.py:156
-        x = ops.conv(x, w.conv2_w, w.conv2_b, ksize=3, stride=2, pad=1, act=ACT_GELU, res=w.pos[:tw])  # :151-158
-        scale = float(w.S // w.heads) ** -0.5          # (d^-0.25 on q) * (d^-0.25 on k), model.py:90-92
-        # model.py:118-129.  The two residual projections (attention out, MLP down: N = 1280 leaves most CUs idle) run
-        # split-K; their slabs are summed by the kernel that also applies the residual add and the NEXT LayerNorm
-        # (attn_ln -> mlp_ln -> next block's attn_ln -> ... -> ln_post), so a block is 6 launches.
-        nb = len(w.blocks)
-        h = ops.layernorm(x, w.blocks[0]["ln1_g"], w.blocks[0]["ln1_b"]) if nb else None
-        for i, blk in enumerate(w.blocks):
-            qkv = ops.conv(h, blk["qkv_w"], blk["qkv_b"], tile=tile_qkv)
-            a = ops.attention(qkv, w.heads, scale)
-            p = ops.conv(a, blk["o_w"], None, partials=True, split_k=max(1, min(split_o, blk["o_w"].shape[1] // 128)), tile=tile_o)
-            h = ops.splitk_layernorm(p, blk["o_b"], x, blk["ln2_g"], blk["ln2_b"], out=h)
-            m = ops.conv(h, blk["m1_w"], blk["m1_b"], act=ACT_GELU, tile=tile_m1, split_k=1)
-            p = ops.conv(m, blk["m2_w"], None, partials=True, split_k=max(1, min(split_mlp, blk["m2_w"].shape[1] // 128)), tile=tile_m2)
-            g, b = (w.blocks[i + 1]["ln1_g"], w.blocks[i + 1]["ln1_b"]) if i + 1 < nb else (w.lnp_g, w.lnp_b)
-            h = ops.splitk_layernorm(p, blk["m2_b"], x, g, b, out=h)
-        return h if nb else ops.layernorm(x, w.lnp_g, w.lnp_b)
+        return self.ops.whisper_encoder_fwd(self._cmodel(), mel, noise, noise_scale)
 
 
 class WhisperEncoderModel:
