@@ -415,19 +415,26 @@ def main():
     # the packed arena through one RCCL broadcast per model and only takes views of it
     t0 = time.perf_counter()
     wsd_cpu = vsd_cpu = vw = ww = None
+    t_make = 0.0
     if rank == 0:
+        # (making the seeded random-init checkpoints stands in for torch.load and dominates: ~6 s for the 1.9 GB Whisper state;
+        #  folding weight-norm + building the GEMM layouts + the upload is ~0.5 s)
         vsd_cpu = W.make_vits_state(hp, seed=1234)
-        vw = PW.VitsWeights(vsd_cpu, hp, device)
         if need_whisper:
             wsd_cpu = W.make_whisper_state(C.WHISPER_LARGE_V2)
+        t_make = time.perf_counter() - t0
+        vw = PW.VitsWeights(vsd_cpu, hp, device)
+        if need_whisper:
             ww = PW.WhisperWeights(wsd_cpu, device)
+        torch.cuda.synchronize()
     t1 = time.perf_counter()
     if world > 1:
         vw = D.broadcast_packed(vw, 0, device)
         if need_whisper:
             ww = D.broadcast_packed(ww, 0, device)
         torch.cuda.synchronize()
-    log(f"[rank {rank}] weights ready in {time.perf_counter() - t0:.1f}s (pack {t1 - t0:.1f}s on rank 0, broadcast {time.perf_counter() - t1:.1f}s)")
+    log(f"[rank {rank}] weights ready in {time.perf_counter() - t0:.1f}s (rank 0: synthetic checkpoint {t_make:.1f}s + fold / pack / upload "
+        f"{t1 - t0 - t_make:.1f}s; broadcast {time.perf_counter() - t1:.1f}s)")
     model = SynthesizerInfer(hp.data.filter_length // 2 + 1, hp.data.segment_size // hp.data.hop_length, hp, ops=ops).load_packed(vw, device)
     model.precision = norm(sprec)
     whisper = None
@@ -505,6 +512,8 @@ def main():
                              (f", {inflight} clips in flight (one lane = HIP stream + graph + static buffers each; GPU_MAX_HW_QUEUES="
                               f"{os.environ.get('GPU_MAX_HW_QUEUES')})" if inflight > 1 else ""),
                    "clips_in_flight": inflight,
+                   "world_size": world, "dist_backend": (dist.get_backend() if world > 1 else None),
+                   "weights": ("rank 0 packs, one broadcast of the packed arena per model (" + str(dist.get_backend()) + ")") if world > 1 else "packed on this rank",
                    "per_gpu_value": round(value / world, 2), "realtime_factor": round(value / world, 2)},
     }
     if single is not None:

@@ -7,6 +7,7 @@ launches one kernel on the current stream and returns its output tensor.
 import contextlib
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -49,7 +50,8 @@ class Ops:
         # on this chip (8-17 us whatever the operand type; measured: the 75 small prior / flow GEMMs of a 10 s clip cost the same
         # 1.35 ms through either kernel), so rounding its operands buys nothing and costs accuracy.  At batch 16 the same
         # layers are 16x the work and cross the threshold.
-        self.precision = PREC_F32
+        self._tls = threading.local()          # `precision` is per calling thread (worker threads of the folder driver share one Ops)
+        self._lock = threading.Lock()          # guards the lazily built per-tensor 16-bit weight images
         self.lp_min_flops = 1.5e9
 
     # ------------------------------------------------------------------ plumbing
@@ -78,6 +80,14 @@ class Ops:
             raise SvcmiError(f"{name} failed with code {rc}")
 
     # ------------------------------------------------------------------ reduced precision
+    @property
+    def precision(self):
+        return getattr(self._tls, "precision", PREC_F32)
+
+    @precision.setter
+    def precision(self, value):
+        self._tls.precision = value
+
     def set_precision(self, precision):
         if precision not in PRECISIONS and precision not in PRECISIONS.values():
             raise SvcmiError(f"unknown precision {precision!r}; one of {sorted(k for k in PRECISIONS if k)}")
@@ -99,11 +109,16 @@ class Ops:
         cache = w.__dict__.setdefault("_svcmi_lp", {})
         img = cache.get(prec)
         if img is None:
-            n, ldw = w.shape
-            ldw16 = (ldw + 31) // 32 * 32
-            img = torch.empty(n, (2 if prec == PREC_BF16X3 else 1) * ldw16, dtype=torch.int16, device=w.device)
-            self._call("svcmi_pack_weights_lp", _ptr(w), n, ldw, prec, _ptr(img), ldw16, self._stream())
-            cache[prec] = img
+            with self._lock:
+                img = cache.get(prec)
+                if img is None:
+                    n, ldw = w.shape
+                    ldw16 = (ldw + 31) // 32 * 32
+                    img = torch.empty(n, (2 if prec == PREC_BF16X3 else 1) * ldw16, dtype=torch.int16, device=w.device)
+                    self._call("svcmi_pack_weights_lp", _ptr(w), n, ldw, prec, _ptr(img), ldw16, self._stream())
+                    if self.on_gpu:            # packed on THIS thread's stream; other streams may read it right away
+                        torch.cuda.current_stream().synchronize()
+                    cache[prec] = img
         return img
 
     def _lp_eligible(self, d, w, work):

@@ -54,7 +54,10 @@ class ClipLanes:
         stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(stream):
             for k in INPUTS:
-                self.bufs[lane][k].copy_(inputs[k].to(self.bufs[lane][k].device, torch.float32), non_blocking=True)
+                src = inputs[k].to(self.bufs[lane][k].device, torch.float32)
+                self.bufs[lane][k].copy_(src, non_blocking=True)
+                if src.is_cuda:
+                    src.record_stream(stream)        # the caller may drop its tensor right after submit(): keep the block until the copy ran
             if lengths is not None:
                 self.bufs[lane]["lengths"].copy_(torch.as_tensor(lengths, dtype=torch.int32), non_blocking=True)
             if noise is not None:

@@ -63,6 +63,12 @@ class Converter:
         self.model.to(device)
         self.spk = torch.FloatTensor(np.load(args.spk))
         self.tmp = os.path.join(OUT_PATH, f".rank{rank}")
+        # everything lazily built (packed synthesizer weights, C model structs) is built HERE, on the constructing thread, and the device
+        # is drained: the worker threads of run_batch start on their own streams with all shared state complete and visible
+        self.model.warm()
+        self.whisper.encoder._cmodel()
+        if torch.device(device).type == "cuda":
+            torch.cuda.synchronize(device)
 
     def convert(self, wav_path):
         """One file through PPG / vec / F0 extraction and svc_infer; returns np.float32 audio at hp.data.sampling_rate."""

@@ -11,6 +11,7 @@ Internally everything is time-major ``[B, T, C]`` fp32.  The forward
 generator -- is composed by the C++ host inside libsvcmi.so (csrc/host_stages.hip: svcmi_synth_infer_fwd, svcmi_pitch2source_fwd):
 this class converts layouts at the API edge, owns the weights and makes ONE library call per stage.
 """
+import threading
 from collections import OrderedDict
 
 import torch
@@ -32,6 +33,7 @@ class SynthesizerInfer:
         self.training = False
         self._stop_after = None          # tuning aid (scripts/stage_times.py), never set in production
         self._cm = {}                    # C model structs (svcmi_synth_model), one per GEMM operand precision
+        self._lock = threading.RLock()   # lazy weight packing / struct building may be reached from several worker threads
         # GEMM operand precision of prior encoder / flow / generator: None = fp32 (parity default), "bf16x3" / "bf16" /
         # "f16" (Ops.use_precision).  Element-wise kernels, softmax, LayerNorm, SnakeAlias and accumulation stay fp32.
         self.precision = None
@@ -106,9 +108,13 @@ class SynthesizerInfer:
 
     def _weights(self):
         if self._w is None:
-            dev = self._device or torch.device("cuda" if self.ops.on_gpu else "cpu")
-            self._w = PW.VitsWeights(self.state_dict(), self.hp, dev)
-            self._device = dev
+            with self._lock:
+                if self._w is None:
+                    dev = self._device or torch.device("cuda" if self.ops.on_gpu else "cpu")
+                    w = PW.VitsWeights(self.state_dict(), self.hp, dev)
+                    if dev.type == "cuda":
+                        torch.cuda.synchronize(dev)      # uploaded on the packing thread's stream; every stream may use them from here on
+                    self._device, self._w = dev, w
         return self._w
 
     def _cmodel(self, precision=None):
@@ -118,8 +124,17 @@ class SynthesizerInfer:
         prec = _lib.PRECISIONS.get(p, p)
         cm = self._cm.get(prec)
         if cm is None:
-            cm = self._cm[prec] = cmodel.synth_cmodel(self._weights(), self.ops, prec)
+            with self._lock:
+                cm = self._cm.get(prec)
+                if cm is None:
+                    cm = self._cm[prec] = cmodel.synth_cmodel(self._weights(), self.ops, prec)
         return cm
+
+    def warm(self):
+        """Pack the weights and build the C model now (on the calling thread) instead of on first use: call before handing the model to
+        worker threads / lanes."""
+        self._cmodel()
+        return self
 
     # ------------------------------------------------------------------ reference methods
     STREAM_HALO = 32      # frames of halo per side of a streaming-decoder tile (csrc/host_stages.hip: the FIR chain's exact support is 30.9)

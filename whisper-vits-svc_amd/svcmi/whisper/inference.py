@@ -6,6 +6,8 @@ like whisper/inference.py:11-29, keeps only the audio encoder truncated to the f
 Arithmetic is fp32 (the reference runs fp16 on CUDA, fp32 on CPU -- :22-23; fp32 is the parity default,
 SURVEY.md section 0).
 """
+import threading
+
 import numpy as np
 import torch
 
@@ -33,12 +35,16 @@ class AudioEncoder:
         # svcmi_conv_gemm_lp.  LayerNorm, softmax, GELU, residual stream and accumulation stay fp32 in every mode.
         self.precision = None
         self._cm = {}
+        self._lock = threading.Lock()
 
     def _cmodel(self):
         prec = _lib.PRECISIONS.get(self.precision, self.precision)
         cm = self._cm.get(prec)
         if cm is None:
-            cm = self._cm[prec] = cmodel.whisper_cmodel(self.w, self.ops, prec)
+            with self._lock:
+                cm = self._cm.get(prec)
+                if cm is None:
+                    cm = self._cm[prec] = cmodel.whisper_cmodel(self.w, self.ops, prec)
         m = cm.struct
         m.split_o, m.split_mlp, m.small_m_rows = self.split_o, self.split_mlp, self.small_m_rows
         m.tile_qkv, m.tile_o, m.tile_mlp1, m.tile_mlp2 = self.tile_qkv, self.tile_o, self.tile_mlp1, self.tile_mlp2
