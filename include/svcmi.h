@@ -101,6 +101,10 @@ typedef struct svcmi_conv_desc {
     int32_t* counters;     /* optional: >= one int32 per output tile, ALL ZERO on entry (the library leaves them zero).  With it   */
     int64_t counters_len;  /* the slices are combined inside the GEMM launch by the last-arriving block of each tile (fixed slice */
                            /* order: still deterministic); without it a second kernel does the reduction.                         */
+    void* y16;             /* optional: a 16-bit copy of y (same values rounded to y16_format = SVCMI_PREC_BF16 | SVCMI_PREC_F16), element (b,t,n) */
+    int64_t y16_bstride;   /* at y16 + b*y16_bstride + t*ldy16 + n (in 16-bit elements): the A operand of a following _A16 launch, written by    */
+    int32_t ldy16;         /* THIS launch's epilogue instead of being rounded in that launch's registers.  Needs the float4 epilogue (n_out,    */
+    int32_t y16_format;    /* ldy % 4 == 0, aligned operands), no split-K.                                                                       */
 } svcmi_conv_desc;
 
 int svcmi_conv_gemm_f32(const svcmi_conv_desc* d, void* stream);
@@ -128,7 +132,13 @@ int svcmi_conv_gemm_group_f32(const svcmi_conv_desc* descs, int32_t count, void*
  * everything else (epilogue, masks, split-K, SVCMI_CONV_PARTIALS, grouping rules) is unchanged.  Activations are rounded in
  * registers inside the kernel, so no other kernel of the path changes.  Not supported (SVCMI_EUNSUPPORTED): per-element
  * gathers (c_in % 4 != 0 or unaligned x) and the in-launch split-K combine (`counters` is ignored). */
-enum svcmi_precision { SVCMI_PREC_F32 = 0, SVCMI_PREC_BF16X3 = 1, SVCMI_PREC_BF16 = 2, SVCMI_PREC_F16 = 3 };
+enum svcmi_precision { SVCMI_PREC_F32 = 0, SVCMI_PREC_BF16X3 = 1, SVCMI_PREC_BF16 = 2, SVCMI_PREC_F16 = 3,
+                       /* 16-bit ACTIVATIONS as well: d->x is a bf16 / fp16 tensor (ldx, x_bstride in 16-bit elements; c_in, ldx, x_bstride % 8 == 0, x 16-byte
+                        * aligned, no x_row_shift) that the producing kernel wrote (y16 of a convolution, svcmi_splitk_layernorm_f32, svcmi_layernorm_f32,
+                        * svcmi_attention_f32, svcmi_snake_alias_group_f32), so nothing is rounded in this launch's registers and the operand tile in LDS is
+                        * half the size.  Same products as SVCMI_PREC_BF16 / _F16 (the same fp32 values, rounded the same way); the weight image is packed
+                        * by svcmi_pack_weights_lp with the _A16 code (natural k order instead of the permuted order of the other modes). */
+                       SVCMI_PREC_BF16_A16 = 4, SVCMI_PREC_F16_A16 = 5 };
 int svcmi_pack_weights_lp(const float* w, int32_t n, int32_t ldw, int32_t precision, void* out, int32_t ldw16, void* stream);
 int svcmi_conv_gemm_lp(const svcmi_conv_desc* d, int32_t precision, void* stream);
 int svcmi_conv_gemm_group_lp(const svcmi_conv_desc* descs, int32_t count, int32_t precision, void* stream);
@@ -143,7 +153,10 @@ int svcmi_conv_gemm_group_lp(const svcmi_conv_desc* descs, int32_t count, int32_
  * c % 4 == 0, c <= 2048. */
 int svcmi_layernorm_f32(const float* x, const float* res, const float* gamma, const float* beta, float* y,
                         int32_t batch, int32_t rows_per_batch, int32_t c, int32_t ldx, int32_t ldr, int32_t ldy,
-                        int32_t gb_bstride, float eps, void* stream);
+                        int32_t gb_bstride, float eps, void* y16, int32_t ldy16, int32_t y16_format, void* stream);
+/* (y16 / ldy16 / y16_format here and below: an optional second output, the same rows rounded to bf16 / fp16 (SVCMI_PREC_BF16 |
+ * SVCMI_PREC_F16) with leading dimension ldy16 in 16-bit elements -- the A operand of a following SVCMI_PREC_*_A16 convolution.
+ * NULL = none.) */
 
 /* Per-channel normalisation over time + GELU: GroupNorm(num_groups = c, c) followed by exact-erf GELU, the first layer of
  * HuBERT's feature extractor (hubert/hubert_model.py:78,88): y[b,t,ch] = gelu((x[b,t,ch] - mean_t) / sqrt(var_t + eps) *
@@ -159,7 +172,7 @@ int svcmi_channel_norm_gelu_f32(const float* x, const float* gamma, const float*
  * rows r = b*rows_per_batch + t.  c % 4 == 0, c <= 2048. */
 int svcmi_splitk_layernorm_f32(const float* partials, int32_t split, const float* bias, float* x, const float* gamma,
                                const float* beta, float* y, int32_t batch, int32_t rows_per_batch, int32_t c,
-                               int32_t ldx, int32_t ldy, float eps, void* stream);
+                               int32_t ldx, int32_t ldy, float eps, void* y16, int32_t ldy16, int32_t y16_format, void* stream);
 
 /* Multi-head self-attention with exact (fp32, online) softmax.
  *   S[i,j] = scale * ( q_i . k_j  +  (|j-i| <= window ? q_i . rel_k[j-i+window] : 0) )
@@ -175,7 +188,7 @@ int svcmi_attention_f32(const float* q, const float* k, const float* v, float* o
                         int64_t q_bstride, int64_t k_bstride, int64_t v_bstride, int64_t o_bstride,
                         int32_t batch, int32_t t, int32_t heads, int32_t head_dim, float scale,
                         const float* rel_k, const float* rel_v, int32_t window,
-                        const int32_t* lengths, void* stream);
+                        const int32_t* lengths, void* o16, int32_t ldo16, int64_t o16_bstride, int32_t o16_format, void* stream);
 
 /* Anti-aliased SnakeBeta (vits_decoder/alias/act.py:124-129): 2x Kaiser-sinc polyphase upsample with
  * replicate padding (resample.py:25-33), x + sin^2(x*e^alpha)/(e^beta + 1e-9) (act.py:79-92), 12-tap
@@ -409,6 +422,7 @@ typedef struct svcmi_weight {
     const float* w;
     const float* bias;
     const void* w16;
+    const void* w16a;     /* the natural-k-order image of the SVCMI_PREC_*_A16 kernels (same ldw16), or NULL: 16-bit activations are not used here */
     int32_t n, ldw, ldw16, reserved;
 } svcmi_weight;
 

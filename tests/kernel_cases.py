@@ -8,6 +8,8 @@ import math
 
 import numpy as np
 import torch
+
+from svcmi._lib import PRECISIONS
 import torch.nn.functional as F
 
 from oracle import svc_oracle as O
@@ -71,6 +73,13 @@ CONV_CASES_LP_SMALL = [
     dict(id="lp_bf16_p16_n80_k3_acc", B=2, T=130, cin=80, n=80, k=3, pad=1, res=True, alpha=1.0 / 3.0, accumulate=True, prec="bf16", tile=6),
     dict(id="lp_f16_p16_n38_masks", B=2, T=150, cin=16, n=38, k=5, pad=2, lengths=[150, 111], mask_in=True, mask_out=True, prec="f16", tile=4),
     dict(id="lp_bf16x3_stride2", B=1, T=81, cin=32, n=40, k=3, stride=2, pad=1, act=ACT_GELU, prec="bf16x3"),
+    # 16-bit ACTIVATIONS (SVCMI_PREC_*_A16: x arrives as a bf16 / fp16 tensor, natural-order weight image) + the 16-bit output copy
+    dict(id="a16_f16_64x64_chunk_k1_out16", B=2, T=70, cin=64, n=72, k=1, prec="f16", a16=True, out16=True, act=ACT_GELU),
+    dict(id="a16_bf16_64x128_chunk_k3", B=1, T=90, cin=32, n=150, k=3, pad=1, prec="bf16", a16=True, tile=9, res=True),
+    dict(id="a16_f16_vec_c40_k11_d5_p16", B=1, T=300, cin=40, n=40, k=11, dil=5, pad=25, res=True, prec="f16", a16=True, tile=4),
+    dict(id="a16_bf16_vec_c24_masks_ktail", B=2, T=37, cin=24, n=20, k=5, pad=2, lengths=[37, 20], mask_in=True, mask_out=True, prec="bf16", a16=True),
+    dict(id="a16_f16_128x128_splitk_partials", B=1, T=150, cin=256, n=140, k=1, prec="f16", a16=True, tile=3),
+    dict(id="a16_f16_stride2_k3", B=1, T=81, cin=32, n=40, k=3, stride=2, pad=1, prec="f16", a16=True, out16=True),
 ]
 CONV_CASES_LP_LARGE = [
     dict(id="lp_whisper_qkv_bf16x3", B=1, T=750, cin=1280, n=3840, k=1, prec="bf16x3"),
@@ -79,6 +88,9 @@ CONV_CASES_LP_LARGE = [
     dict(id="lp_amp_k11_d5_bf16", B=1, T=5000, cin=160, n=160, k=11, dil=5, pad=25, res=True, prec="bf16"),
     dict(id="lp_auto_p16_big_bf16x3", B=2, T=20000, cin=80, n=80, k=7, pad=3, prec="bf16x3"),
     dict(id="lp_b16_wn_in_bf16x3", B=16, T=1000, cin=192, n=384, k=5, pad=2, prec="bf16x3"),
+    dict(id="a16_whisper_qkv_f16", B=1, T=750, cin=1280, n=3840, k=1, prec="f16", a16=True),
+    dict(id="a16_whisper_mlp1_gelu_out16_bf16", B=2, T=500, cin=1280, n=5120, k=1, prec="bf16", a16=True, out16=True, act=ACT_GELU),
+    dict(id="a16_whisper_mlp2_f16_splitk4", B=1, T=500, cin=5120, n=1280, k=1, res=True, prec="f16", a16=True, split_k=4),
 ]
 CONV_CASES_LARGE = [
     dict(id="whisper_qkv", B=1, T=500, cin=1280, n=3840, k=1),
@@ -139,15 +151,22 @@ def check_conv(ops, c, device):
         xd = xd.reshape(B, t_phys)      # a plain signal, ldx = 1
     launches, saved_min = ops.launches, ops.lp_min_flops
     ops.lp_min_flops = 0.0
+    dt16 = {"f16": torch.float16, "bf16": torch.bfloat16}.get(prec)
+    x16 = xd.to(dt16) if c.get("a16") else None          # what a producing kernel's 16-bit output holds: the same values, rounded
     with ops.use_precision(prec):
         y = ops.conv(xd, wp, dev(bias), ksize=k, stride=stride, dilation=dil, pad=pad, act=act, res=dev(res),
                      alpha=c.get("alpha", 1.0), accumulate=c.get("accumulate", False), lengths=dev(lengths),
                      mask_in=c.get("mask_in", False), mask_out=c.get("mask_out", False), out=out,
                      x_row_shift=1 if rep else 0, c_in=cin, ldx=cin, n_out=n, tile=c.get("tile", 0), split_k=c.get("split_k", 1),
-                     t_in=Tl, x_bstride=t_phys * cin)
+                     t_in=Tl, x_bstride=t_phys * cin, x16=x16, out16=dt16 if c.get("out16") else None)
     ops.lp_min_flops = saved_min
     if prec is not None:
         assert getattr(wp, "_svcmi_lp", None), f"{c['id']}: the reduced-precision kernel did not run"
+        if c.get("a16"):
+            assert wp._svcmi_lp.get(PRECISIONS[prec] + 2) is not None, f"{c['id']}: the 16-bit-activation kernel did not run"
+    if c.get("out16"):
+        y, y16 = y
+        assert torch.equal(y16.cpu(), y.cpu().to(dt16)), f"{c['id']}: the 16-bit output copy is not the rounded fp32 output"
     assert y.shape == ref.shape
     _close(y, ref, 2e-5 if cin * k < 4096 else 1e-4, c["id"])
 
@@ -699,3 +718,26 @@ def check_source2wav(ops, device):
     x = torch.cat([torch.randn(1000, generator=g) * 0.6, torch.tensor([1.0, -1.0, 0.99999, 2.0, -2.0, 0.0])])
     got = ops.source2wav(x.to(device)).cpu()
     assert torch.equal(got, torch.from_numpy(O.source2wav(x)))
+
+
+def check_outputs16(ops, device):
+    """The optional 16-bit output copies of LayerNorm / split-K LayerNorm / attention (the A operands of the _A16 GEMMs): exactly the fp32
+    output rounded to the requested type."""
+    g = _g(99)
+    B, T, c, H = 2, 37, 64, 2
+    x, r = torch.randn(B, T, c, generator=g), torch.randn(B, T, c, generator=g)
+    gamma, beta = torch.randn(c, generator=g), torch.randn(c, generator=g)
+    d = lambda t: t.to(device)
+    for dt in (torch.float16, torch.bfloat16):
+        y, y16 = ops.layernorm(d(x), d(gamma), d(beta), res=d(r), out16=dt)
+        assert y16.dtype == dt and torch.equal(y16.cpu(), y.cpu().to(dt))
+        part = torch.randn(B, 3, T, c, generator=g)
+        xs = d(x.clone())
+        y, y16 = ops.splitk_layernorm(d(part), d(beta), xs, d(gamma), d(beta), out16=dt)
+        assert torch.equal(y16.cpu(), y.cpu().to(dt))
+        qkv = torch.randn(B, 70, 3 * H * 32, generator=g)
+        o, o16 = ops.attention(d(qkv), H, 32 ** -0.5, out16=dt)
+        assert torch.equal(o16.cpu(), o.cpu().to(dt))
+        lens = torch.tensor([70, 41], dtype=torch.int32)
+        o, o16 = ops.attention(d(qkv), H, 32 ** -0.5, lengths=d(lens), out16=dt)            # (another kernel shape: masked)
+        assert torch.equal(o16.cpu(), o.cpu().to(dt))

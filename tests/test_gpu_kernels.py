@@ -168,3 +168,7 @@ def test_inlaunch_splitk_combine_is_bit_identical_under_load(ops):
         finally:
             ops.inlaunch_reduce = False
         torch.cuda.synchronize()
+
+
+def test_outputs16(ops):
+    K.check_outputs16(ops, "cuda")

@@ -157,3 +157,7 @@ def test_svc_train_retrieval_cli_writes_loadable_indexes(ops, tmp_path, monkeypa
     y = index.retriv(x)
     assert y.shape == x.shape and np.isfinite(y).all() and not np.allclose(y, x)
     assert TR.build_parser().parse_args([]).compress_features_after == 200_000
+
+
+def test_outputs16(ops):
+    K.check_outputs16(ops, "cpu")

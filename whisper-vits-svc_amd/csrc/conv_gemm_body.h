@@ -62,7 +62,11 @@ namespace {
 constexpr int BK = 32;
 enum { MODE_CHUNK = 0, MODE_VEC = 1, MODE_SCALAR = 2, MODE_CHUNK_RS = 3 };   // _RS: CHUNK with x_row_shift != 0
 
-enum { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_BF16 = 2, PREC_F16 = 3 };   // == enum svcmi_precision
+enum { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_BF16 = 2, PREC_F16 = 3, PREC_BF16_A16 = 4, PREC_F16_A16 = 5 };   // == enum svcmi_precision
+// _A16: the ACTIVATIONS arrive as a 16-bit tensor too (written by the producing kernel's epilogue): the A tile is [rows][64 B] like the
+// B tile, a lane's MFMA fragment is ONE ds_read_b128 of 8 consecutive k and nothing is rounded in registers; the weight image is in
+// natural k order for these modes (svcmi_pack_weights_lp with an _A16 precision).  Same products as the in-register rounding of the
+// plain modes (the same fp32 values rounded the same way), at half the LDS bytes per MFMA.
 
 struct ConvArgs {
     const float* x; const float* w; const float* bias; const float* res; float* y; const int32_t* lengths;
@@ -73,6 +77,9 @@ struct ConvArgs {
     int ksize, stride, dil, pad, rshift, act, flags;
     const unsigned short* w16;   // reduced precision: 16-bit weight image, row n = [hi: ldw16 values][lo: ldw16 values, bf16x3 only]
     int ldw16;
+    unsigned short* y16;         // optional 16-bit copy of the output (bf16 or f16, y16_f16), rows of ldy16 values: the next GEMM's A operand
+    long long y16_bs;
+    int ldy16, y16_f16;
     int vec;                     // 1: y / res / bias / workspace rows are 16-byte aligned multiples of 4 floats -> float4 epilogue
     int ktot;                    // ksize * c_in
     int split;                   // K slices (1 = none)
@@ -106,7 +113,8 @@ __device__ __forceinline__ float epilogue(const ConvArgs& p, float v, float bias
 
 // four consecutive output channels at once: the same arithmetic per component as `epilogue`, 16-byte accesses (the scalar loop
 // spent 5-9 us of a 53-73 us Whisper launch issuing 4-byte loads and stores: scripts/microbench.py ablation)
-__device__ __forceinline__ void epilogue4(const ConvArgs& p, float4 v, const float* bias_n, const float* res_n, float* dst, bool masked) {
+__device__ __forceinline__ void epilogue4(const ConvArgs& p, float4 v, const float* bias_n, const float* res_n, float* dst, bool masked,
+                                          unsigned short* dst16 = nullptr) {
     float o[4] = {v.x, v.y, v.z, v.w};
     float bv[4] = {0.f, 0.f, 0.f, 0.f}, rv[4] = {0.f, 0.f, 0.f, 0.f}, yo[4] = {0.f, 0.f, 0.f, 0.f};
     if (bias_n) { const float4 t = *reinterpret_cast<const float4*>(bias_n); bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w; }
@@ -121,6 +129,11 @@ __device__ __forceinline__ void epilogue4(const ConvArgs& p, float4 v, const flo
         o[e] = masked ? 0.f : q;
     }
     *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+    if (dst16) {
+        unsigned* h = reinterpret_cast<unsigned*>(dst16);          // 8-byte aligned: n % 4 == 0, ldy16 % 4 == 0
+        h[0] = p.y16_f16 ? svcmi_cvt_pk_f16(o[0], o[1]) : svcmi_cvt_pk_bf16(o[0], o[1]);
+        h[1] = p.y16_f16 ? svcmi_cvt_pk_f16(o[2], o[3]) : svcmi_cvt_pk_bf16(o[2], o[3]);
+    }
 }
 
 __device__ __forceinline__ int div_magic(int q, unsigned magic) {   // q / c_in, exact while q * c_in < 2^32
@@ -148,23 +161,26 @@ constexpr unsigned OOB = 0x40000000u;   // added to an offset that must read as 
 // `grid_blocks` / `block_id`: the launch geometry of THIS problem (a grouped launch runs several problems back to back in one grid).
 template <int WM, int WN, int MODE, bool P16, int NSTO = 0, int PREC = PREC_F32>
 __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid_blocks, const int block_id) {
-    constexpr bool LP = PREC != PREC_F32;             // 16-bit weight image(s), fp32 activations rounded in registers
+    constexpr bool LP = PREC != PREC_F32;             // 16-bit weight image(s); fp32 activations rounded in registers unless A16
+    constexpr bool A16 = PREC >= PREC_BF16_A16;       // 16-bit activations: A tile rows of 64 bytes, fragments straight from LDS
+    constexpr bool F16OP = PREC == PREC_F16 || PREC == PREC_F16_A16;
     constexpr int NB = PREC == PREC_BF16X3 ? 2 : 1;   // B images per stage (hi, lo)
     constexpr int BM = 64 * WM, BN = P16 ? 16 * WN : 64 * WN;
     constexpr int BROW = LP ? BK / 2 : BK;            // floats per B row in LDS (LP: 32 x 2 bytes)
     constexpr int BNL = LP ? (BN + 63) / 64 * 64 : (BN + 31) / 32 * 32;   // B rows held in LDS (whole 4-wave DMA rounds)
-    constexpr int A_PER = BM / 32, B_PER = LP ? BNL / 64 : BNL / 32;      // 1-KiB LDS-DMA pieces (8 x 128 B or 16 x 64 B rows) per wave per K-step (per image)
+    constexpr int AROW = A16 ? BK / 2 : BK;           // floats per A row in LDS
+    constexpr int A_PER = A16 ? BM / 64 : BM / 32, B_PER = LP ? BNL / 64 : BNL / 32;      // 1-KiB LDS-DMA pieces (8 x 128 B or 16 x 64 B rows) per wave per K-step (per image)
     constexpr int BTILE = BNL * BROW;                 // floats per B image per stage
     constexpr int CLD = BN;                           // epilogue staging tile [BM][BN] reuses the operand buffers
     // LDS ring of NST operand tiles (48 / 72 / 64 KiB per block): tile it+NST-1 is in flight while tile
     // `it` is consumed, so a K-step never waits a full HBM/L2 round trip -- what short K ranges (split-K slices,
     // the k=1 projections of the prior encoder / flow, k=3 convolutions) would otherwise pay on every step.
     constexpr int NST = NSTO ? NSTO : (LP ? 3 : (P16 ? ((BM + BNL) > 192 ? 2 : 3) : ((WM * WN == 1) ? 3 : (WM * WN == 2 ? 3 : 2))));
-    constexpr int RING = NST * (BM * BK + NB * BTILE);
+    constexpr int RING = NST * (BM * AROW + NB * BTILE);
     static_assert(LP || BM * CLD <= RING, "C tile must fit in the operand buffers");
     __shared__ __attribute__((aligned(16))) float smem[(RING > BM * CLD ? RING : BM * CLD) + 4];   // + the split-K ticket word
     float* const As0 = smem;                          // As[slot] = As0 + slot*BM*BK, rows of 32 floats, chunk-swizzled
-    float* const Bs0 = smem + NST * BM * BK;          // Bs[slot][image] = Bs0 + (slot*NB + image)*BTILE
+    float* const Bs0 = smem + NST * BM * AROW;        // Bs[slot][image] = Bs0 + (slot*NB + image)*BTILE
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = SVCMI_UNIFORM((int)(tid >> 6));
@@ -186,7 +202,8 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
     const int t_lim = (p.flags & SVCMI_CONV_MASK_IN) ? (len < p.t_in ? len : p.t_in) : p.t_in;
     // operand buffers: x of this batch item up to the first row that must read as zero; the whole weight matrix
     const int x_rows = (t_lim + (1 << p.rshift) - 1) >> p.rshift;
-    const svcmi_rsrc xr = svcmi_make_rsrc(p.x + (long long)b * p.x_bs, (unsigned)x_rows * (unsigned)p.ldx * 4u);
+    const svcmi_rsrc xr = A16 ? svcmi_make_rsrc(reinterpret_cast<const unsigned short*>(p.x) + (long long)b * p.x_bs, (unsigned)x_rows * (unsigned)p.ldx * 2u)
+                              : svcmi_make_rsrc(p.x + (long long)b * p.x_bs, (unsigned)x_rows * (unsigned)p.ldx * 4u);
     const svcmi_rsrc wr = LP ? svcmi_make_rsrc(p.w16, (unsigned)p.n_out * (unsigned)(NB * p.ldw16) * 2u)
                              : svcmi_make_rsrc(p.w, (unsigned)p.n_out * (unsigned)p.ldw * 4u);
 
@@ -205,9 +222,9 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
     unsigned b_row[B_PER];
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
-        const int t = m0 + (wave + 4 * i) * 8 + prow;
+        const int t = A16 ? m0 + (wave + 4 * i) * 16 + (lane >> 2) : m0 + (wave + 4 * i) * 8 + prow;   // A16: a piece is 16 rows of 64 bytes
         a_tb[i] = t * p.stride - p.pad;
-        a_row[i] = t < p.t_out ? (unsigned)a_tb[i] * (unsigned)p.ldx * 4u : OOB;
+        a_row[i] = t < p.t_out ? (unsigned)a_tb[i] * (unsigned)p.ldx * (A16 ? 2u : 4u) : OOB;
         if (t >= p.t_out) a_tb[i] = -0x40000000;
     }
 #pragma unroll
@@ -247,16 +264,18 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
         else b_koff = kk < p.ldw ? (unsigned)kk * 4u : OOB;
         if (MODE == MODE_CHUNK || MODE == MODE_CHUNK_RS) {
             tap_v = tap_u; ci_v = ci_u + lkq;
-            a_koff = (unsigned)(tap_u * p.dil * p.ldx + ci_u + lkq) * 4u;
+            if (A16) a_koff = (unsigned)(tap_u * p.dil * p.ldx + ci_u) * 2u + (unsigned)lkq16;
+            else a_koff = (unsigned)(tap_u * p.dil * p.ldx + ci_u + lkq) * 4u;
             ci_u += BK;
             if (ci_u >= p.c_in) { ci_u -= p.c_in; ++tap_u; }
         } else if (MODE == MODE_VEC) {
-            tap_v = div_magic(kk, p.magic); ci_v = kk - tap_v * p.c_in;
-            a_koff = kk < p.ktot ? (unsigned)(tap_v * p.dil * p.ldx + ci_v) * 4u : OOB;
+            const int kv = A16 ? it * BK + (lkq16 >> 1) : kk;      // A16: this lane's 16-byte chunk = 8 consecutive k (c_in % 8 == 0: inside one tap)
+            tap_v = div_magic(kv, p.magic); ci_v = kv - tap_v * p.c_in;
+            a_koff = kv < p.ktot ? (unsigned)(tap_v * p.dil * p.ldx + ci_v) * (A16 ? 2u : 4u) : OOB;
         }
     };
     auto stage_a = [&](int it, int buf, int i) {          // piece i of the A tile
-        const svcmi_ldsaddr dst = svcmi_lds_advance(lds_a, buf * BM * BK + 4 * i * 8 * BK);
+        const svcmi_ldsaddr dst = svcmi_lds_advance(lds_a, buf * BM * AROW + 4 * i * 8 * BK);      // (a piece is 1 KiB in either layout)
         if (MODE == MODE_SCALAR) {
             // 4-byte DMA: a wave-instruction fills 2 rows (64 floats); the piece needs 4 of them.
 #pragma unroll
@@ -288,7 +307,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
     // Either way the chunk sits at position chunk ^ swz(row), and both access patterns are bank-conflict free.
     constexpr int FR = P16 ? 16 : 32;                  // rows per MFMA tile
     const int frow = lane & (FR - 1), fhi = P16 ? (lane >> 4) : (lane >> 5);
-    const int a_off = (wm * FR * WM + frow) * BK, b_off = (wn * FR * WN + frow) * BROW;
+    const int a_off = (wm * FR * WM + frow) * AROW, b_off = (wn * FR * WN + frow) * BROW;
     // Fragment reads of sub-step s into (a4, b4).  `tie` is a register the MFMAs issued next consume.
     auto load_frags = [&](const float* Ab, const float* Bb, int s, svcmi_f32x4 (&a4)[WM], svcmi_f32x4 (&b4)[WN], svcmi_f32x4& tie) {
         const int pos = ((((P16 ? 4 : 2) * s + fhi) ^ swz(frow)) << 2);
@@ -315,8 +334,12 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
         const int pa = (q ^ swz(frow)) << 2, pb = (q ^ swz16(frow)) << 2;
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
-            svcmi_lds_read16(a8[i][0], Ab + i * FR * BK + pa, tie);
-            svcmi_lds_read16(a8[i][1], Ab + i * FR * BK + (pa ^ 16), tie);
+            if constexpr (A16) {
+                svcmi_lds_read16(a8[i][0], Ab + i * FR * AROW + pb, tie);      // 16-bit A row: same 64-byte layout and swizzle as a B row
+            } else {
+                svcmi_lds_read16(a8[i][0], Ab + i * FR * BK + pa, tie);
+                svcmi_lds_read16(a8[i][1], Ab + i * FR * BK + (pa ^ 16), tie);
+            }
         }
 #pragma unroll
         for (int h = 0; h < NB; ++h)
@@ -325,9 +348,9 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
     };
     auto frags_arrive_lp = [&](svcmi_f32x4 (&a8)[WM][2], svcmi_f32x4 (&b8)[NB][WN]) {
         svcmi_lds_arrive(a8[0][0]);
-        svcmi_lds_landed(a8[0][1]);
+        if constexpr (!A16) svcmi_lds_landed(a8[0][1]);
 #pragma unroll
-        for (int i = 1; i < WM; ++i) { svcmi_lds_landed(a8[i][0]); svcmi_lds_landed(a8[i][1]); }
+        for (int i = 1; i < WM; ++i) { svcmi_lds_landed(a8[i][0]); if constexpr (!A16) svcmi_lds_landed(a8[i][1]); }
 #pragma unroll
         for (int h = 0; h < NB; ++h)
 #pragma unroll
@@ -338,7 +361,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float x0 = r[e >> 1][2 * (e & 1)], x1 = r[e >> 1][2 * (e & 1) + 1];
-            if constexpr (PREC == PREC_F16) {
+            if constexpr (F16OP) {
                 hi[e] = svcmi_cvt_pk_f16(x0, x1);
             } else {
                 const unsigned h = svcmi_cvt_pk_bf16(x0, x1);
@@ -349,8 +372,8 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
         }
     };
     auto mma16 = [&](acc_t& c, svcmi_u32x4 a, svcmi_u32x4 b) {
-        if constexpr (P16) c = svcmi_mfma16_16x16x32<PREC == PREC_F16>(a, b, c);
-        else c = svcmi_mfma16_32x32x16<PREC == PREC_F16>(a, b, c);
+        if constexpr (P16) c = svcmi_mfma16_16x16x32<F16OP>(a, b, c);
+        else c = svcmi_mfma16_32x32x16<F16OP>(a, b, c);
     };
 
     // sub-steps per tile: fp32 4 x 8 k (32x32x2) or 2 x 16 k (16x16x4); 16-bit 2 x 16 k (32x32x16) or 1 x 32 k (16x16x32)
@@ -381,7 +404,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
         int nslot = slot + NST - 1;
         if (nslot >= NST) nslot -= NST;
         if (ISSUE) stage_prep(it + NST - 1);
-        const float* Ab = As0 + slot * BM * BK + a_off;
+        const float* Ab = As0 + slot * BM * AROW + a_off;
         const float* Bb = Bs0 + slot * NB * BTILE + b_off;
         svcmi_f32x4 tie0 = {0.f, 0.f, 0.f, 0.f};
         if constexpr (LP) {
@@ -400,7 +423,10 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
                 }
                 svcmi_u32x4 ahi[WM], alo[WM];
 #pragma unroll
-                for (int i = 0; i < WM; ++i) round_frag(a8[s & 1][i], ahi[i], alo[i]);
+                for (int i = 0; i < WM; ++i) {
+                    if constexpr (A16) ahi[i] = svcmi_as_u32x4(a8[s & 1][i][0]);
+                    else round_frag(a8[s & 1][i], ahi[i], alo[i]);
+                }
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -570,7 +596,8 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
             if (ml >= mvalid || nl >= nvalid) continue;
             const int t = m0 + ml, n = n0 + nl;
             epilogue4(p, *reinterpret_cast<const float4*>(Cs + ml * CLD + nl), p.bias ? p.bias + n : nullptr,
-                      rbp ? rbp + (long long)t * p.ldr + n : nullptr, yb + (long long)t * p.ldy + n, mask_out && t >= len);
+                      rbp ? rbp + (long long)t * p.ldr + n : nullptr, yb + (long long)t * p.ldy + n, mask_out && t >= len,
+                      p.y16 ? p.y16 + (long long)b * p.y16_bs + (long long)t * p.ldy16 + n : nullptr);
         }
         return;
     }
@@ -637,8 +664,10 @@ int launch(const ConvArgs& a_in, int batch, int mode, void* stream) {
     if (mode == MODE_CHUNK) SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_CHUNK, P16, PREC>), grid, dim3(256), 0, stream, a);
     else if (mode == MODE_VEC) SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_VEC, P16, PREC>), grid, dim3(256), 0, stream, a);
     else if constexpr (!P16) {
-        if (mode == MODE_CHUNK_RS) SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_CHUNK_RS, false, PREC>), grid, dim3(256), 0, stream, a);
-        else if constexpr (PREC == PREC_F32) SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_SCALAR, false>), grid, dim3(256), 0, stream, a);
+        if (mode == MODE_CHUNK_RS) {
+            if constexpr (PREC < PREC_BF16_A16) SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_CHUNK_RS, false, PREC>), grid, dim3(256), 0, stream, a);
+            else return SVCMI_EUNSUPPORTED;      // the fused row repeat reads fp32 rows only
+        } else if constexpr (PREC == PREC_F32) SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_SCALAR, false>), grid, dim3(256), 0, stream, a);
         else return SVCMI_EUNSUPPORTED;     // per-element gathers (c_in % 4 != 0) stay on the fp32 kernel
     } else {
         return SVCMI_EUNSUPPORTED;
@@ -693,8 +722,12 @@ int launch_group(GroupArgs& g, int count, int batch, int mode, void* stream) {
 // Validation + argument block + gather mode of one convolution (shared by the single and the grouped entry points).
 // lp: d->w is the 16-bit image of svcmi_pack_weights_lp and d->ldw its leading dimension in 16-bit values.
 int prepare(const svcmi_conv_desc* d, ConvArgs& a, int& mode, int prec = PREC_F32) {
-    const bool lp = prec != PREC_F32;
+    const bool lp = prec != PREC_F32, a16 = prec >= PREC_BF16_A16;
     if (!d || !d->x || !d->w || !d->y) return SVCMI_EINVAL;
+    if (a16 && (d->c_in % 8 || d->ldx % 8 || d->x_bstride % 8 || ((uintptr_t)d->x & 15) || d->x_row_shift)) return SVCMI_EUNSUPPORTED;
+    if (d->y16 && (d->ldy16 % 4 || d->ldy16 < d->n_out || d->y16_bstride % 4 || ((uintptr_t)d->y16 & 7) ||
+                   (d->y16_format != SVCMI_PREC_BF16 && d->y16_format != SVCMI_PREC_F16) || (d->flags & SVCMI_CONV_PARTIALS) || d->split_k > 1))
+        return SVCMI_EINVAL;
     /* 32-bit buffer offsets with a 2^30 out-of-range sentinel: each operand buffer stays below 2^29 bytes */
     if ((long long)d->t_in * d->ldx >= (1LL << 27) || (long long)d->n_out * d->ldw * (prec == PREC_BF16X3 ? 2 : 1) >= (1LL << (lp ? 28 : 27))) return SVCMI_EUNSUPPORTED;
     if (((long long)d->ksize * d->dilation + d->pad) * d->ldx >= (1LL << 27)) return SVCMI_EUNSUPPORTED;
@@ -711,6 +744,7 @@ int prepare(const svcmi_conv_desc* d, ConvArgs& a, int& mode, int prec = PREC_F3
 
     a.w16 = lp ? reinterpret_cast<const unsigned short*>(d->w) : nullptr;
     a.ldw16 = lp ? d->ldw : 0;
+    a.y16 = reinterpret_cast<unsigned short*>(d->y16); a.y16_bs = d->y16_bstride; a.ldy16 = d->ldy16; a.y16_f16 = d->y16_format == SVCMI_PREC_F16;
     a.x = d->x; a.w = d->w; a.bias = d->bias; a.res = d->res; a.y = d->y; a.lengths = d->lengths;
     a.ws = d->workspace;
     a.cnt = nullptr;
@@ -727,6 +761,7 @@ int prepare(const svcmi_conv_desc* d, ConvArgs& a, int& mode, int prec = PREC_F3
     }
     a.ktot = d->ksize * d->c_in;
     a.magic = d->c_in == 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d->c_in - 1) / (unsigned)d->c_in);
+    if (d->y16 && !a.vec) return SVCMI_EALIGN;      // the 16-bit copy is written by the float4 epilogue only
     const bool vec = (d->c_in % 4 == 0) && (d->ldx % 4 == 0) && (d->x_bstride % 4 == 0) && (((uintptr_t)d->x & 15) == 0);
     mode = !vec ? MODE_SCALAR : (d->c_in % BK == 0 ? MODE_CHUNK : MODE_VEC);
     if (d->x_row_shift) mode = mode == MODE_CHUNK ? MODE_CHUNK_RS : MODE_SCALAR;   // the fused row repeat: CHUNK_RS or per-element

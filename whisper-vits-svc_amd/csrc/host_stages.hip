@@ -112,14 +112,19 @@ struct CV {
     int tile = 0, tile_lp = -1;     // tile override (>> 8) on the fp32 / 16-bit kernels (-1: same as `tile`)
     int split_k = 0;                // 0 = library heuristic (shared scratch), 1 = off, n = exactly n with `slabs`
     float* slabs = nullptr;         // SVCMI_CONV_PARTIALS: raw slabs [B][split_k][t_out][n_out] land here
+    const void* x16 = nullptr;      // the same rows as `x` as a 16-bit tensor (same ldx / x_bs in elements), written by the producer: a
+                                    // launch that goes to the bf16 / f16 kernel then takes the _A16 instantiation (no in-register rounding)
+    void* y16 = nullptr;            // 16-bit copy of the output for the NEXT launch (written only in the bf16 / f16 modes)
 };
+
+bool mode16(int prec) { return prec == SVCMI_PREC_BF16 || prec == SVCMI_PREC_F16; }
 
 int conv_t_out(const CV& v) { return v.t_out >= 0 ? v.t_out : (v.t_in + 2 * v.pad - v.dil * (v.ksize - 1) - 1) / v.stride + 1; }
 
 bool lp_tile_ok(int tile) { return tile == 0 || tile == 1 || tile == 3 || tile == 4 || tile == 6 || tile == 9; }
 
-// fills the descriptor; returns whether the launch goes to the 16-bit kernel
-bool conv_desc(const Ctx& c, const CV& v, svcmi_conv_desc& d, double& flops, double& bytes, double lp_flops = -1.0) {
+// fills the descriptor; returns the precision code of the launch (SVCMI_PREC_F32 = the fp32 kernel)
+int conv_desc(const Ctx& c, const CV& v, svcmi_conv_desc& d, double& flops, double& bytes, double lp_flops = -1.0) {
     memset(&d, 0, sizeof(d));
     const int N = v.n_out ? v.n_out : v.w->n;
     const int t_out = conv_t_out(v);
@@ -148,20 +153,29 @@ bool conv_desc(const Ctx& c, const CV& v, svcmi_conv_desc& d, double& flops, dou
     } else {
         d.split_k = 1;
     }
-    if (lp) {
-        d.w = static_cast<const float*>(v.w->w16);
-        d.ldw = v.w->ldw16;
-        bytes += (double)N * v.ksize * v.c_in * ((c.prec == SVCMI_PREC_BF16X3 ? 4.0 : 2.0) - 4.0);
+    if (v.y16 && mode16(c.prec) && !partials && d.split_k == 1) {
+        d.y16 = v.y16; d.y16_bstride = d.y_bstride; d.ldy16 = d.ldy; d.y16_format = c.prec;
+        bytes += 2.0 * v.B * t_out * N;
     }
-    return lp;
+    if (!lp) return SVCMI_PREC_F32;
+    d.w = static_cast<const float*>(v.w->w16);
+    d.ldw = v.w->ldw16;
+    bytes += (double)N * v.ksize * v.c_in * ((c.prec == SVCMI_PREC_BF16X3 ? 4.0 : 2.0) - 4.0);
+    if (v.x16 && mode16(c.prec) && v.w->w16a && v.c_in % 8 == 0 && v.ldx % 8 == 0 && v.x_bs % 8 == 0 && !v.rshift) {
+        d.x = static_cast<const float*>(v.x16);
+        d.w = static_cast<const float*>(v.w->w16a);
+        bytes -= 2.0 * v.B * (double)v.t_in * v.c_in;
+        return c.prec + 2;          // SVCMI_PREC_BF16_A16 / _F16_A16
+    }
+    return c.prec;
 }
 
 void conv(Ctx& c, const CV& v) {
     if (!c.live()) return;
     svcmi_conv_desc d;
     double flops, bytes;
-    const bool lp = conv_desc(c, v, d, flops, bytes);
-    if (lp) run(c, OP_CONV_LP, flops, bytes, [&] { return svcmi_conv_gemm_lp(&d, c.prec, c.stream); });
+    const int prec = conv_desc(c, v, d, flops, bytes);
+    if (prec != SVCMI_PREC_F32) run(c, OP_CONV_LP, flops, bytes, [&] { return svcmi_conv_gemm_lp(&d, prec, c.stream); });
     else run(c, OP_CONV_F32, flops, bytes, [&] { return svcmi_conv_gemm_f32(&d, c.stream); });
 }
 
@@ -184,7 +198,9 @@ void conv_group(Ctx& c, const CV* vs, int count) {
         for (int i = 0; i < count && lp; ++i) {
             CV v = vs[i];
             v.split_k = 1;
-            lp = conv_desc(c, v, d[i], flops[i], bytes[i], total);
+            CV v2 = v;
+            v2.x16 = nullptr;            // (grouped launches: fp32 activations)
+            lp = conv_desc(c, v2, d[i], flops[i], bytes[i], total) != SVCMI_PREC_F32;
         }
         if (!lp)
             for (int i = 0; i < count; ++i) {      // back to fp32 descriptors: a group runs on ONE kernel
@@ -200,26 +216,30 @@ void conv_group(Ctx& c, const CV* vs, int count) {
     else run(c, OP_CONV_GROUP_F32, total, tb, [&] { return svcmi_conv_gemm_group_f32(d, count, c.stream); });
 }
 
+// (y16 / o16: optional 16-bit copies of the outputs, rows of C values, in the format of the bf16 / f16 mode; nullptr = none)
 void layernorm(Ctx& c, const float* x, const float* res, const float* g, const float* b, float* y, int B, int T, int C, int ldx, int ldr,
-               int ldy, int gb_bs) {
+               int ldy, int gb_bs, void* y16 = nullptr) {
+    if (!mode16(c.prec)) y16 = nullptr;
     run(c, OP_LAYERNORM, 0.0, 4.0 * B * T * C * (2 + (res != nullptr)), [&] {
-        return svcmi_layernorm_f32(x, res, g, b, y, B, T, C, ldx, ldr, ldy, gb_bs, 1e-5f, c.stream);
+        return svcmi_layernorm_f32(x, res, g, b, y, B, T, C, ldx, ldr, ldy, gb_bs, 1e-5f, y16, C, c.prec, c.stream);
     });
 }
 
 void splitk_layernorm(Ctx& c, const float* part, int split, const float* bias, float* x, const float* g, const float* b, float* y, int B,
-                      int T, int C) {
+                      int T, int C, void* y16 = nullptr) {
+    if (!mode16(c.prec)) y16 = nullptr;
     run(c, OP_SPLITK_LN, 0.0, 4.0 * B * T * C * (3 + split), [&] {
-        return svcmi_splitk_layernorm_f32(part, split, bias, x, g, b, y, B, T, C, C, C, 1e-5f, c.stream);
+        return svcmi_splitk_layernorm_f32(part, split, bias, x, g, b, y, B, T, C, C, C, 1e-5f, y16, C, c.prec, c.stream);
     });
 }
 
 void attention(Ctx& c, const float* qkv, float* o, int B, int T, int heads, int C, float scale, const float* rel_k, const float* rel_v,
-               int window, const int32_t* lengths) {
+               int window, const int32_t* lengths, void* o16 = nullptr) {
     const int64_t bs = (int64_t)T * 3 * C;
+    if (!mode16(c.prec)) o16 = nullptr;
     run(c, OP_ATTENTION, 4.0 * B * T * (double)T * C, 16.0 * B * T * C, [&] {
         return svcmi_attention_f32(qkv, qkv + C, qkv + 2 * C, o, 3 * C, 3 * C, 3 * C, C, bs, bs, bs, (int64_t)T * C, B, T, heads, C / heads,
-                                   scale, rel_k, rel_v, window, lengths, c.stream);
+                                   scale, rel_k, rel_v, window, lengths, o16, C, (int64_t)T * C, c.prec, c.stream);
     });
 }
 
@@ -284,33 +304,40 @@ void whisper_fwd(Ctx& c, const svcmi_whisper_model& m, const float* mel, const f
     const int so = split_o < m.blocks[0].o.ldw / 128 ? split_o : (m.blocks[0].o.ldw / 128 > 0 ? m.blocks[0].o.ldw / 128 : 1);
     const int sm = split_mlp < m.blocks[0].m2.ldw / 128 ? split_mlp : (m.blocks[0].m2.ldw / 128 > 0 ? m.blocks[0].m2.ldw / 128 : 1);
     float* slabs = c.ar.f((int64_t)B * (so > sm ? so : sm) * tw * S);
-    layernorm(c, x, nullptr, m.blocks[0].ln1_g, m.blocks[0].ln1_b, h, B, tw, S, S, 0, S, 0);
+    // bf16 / f16 modes: every GEMM's A operand is written as a 16-bit tensor by its producer (LayerNorm -> QKV and MLP-up, attention ->
+    // out-projection, MLP-up's GELU epilogue -> MLP-down), so the GEMMs take the _A16 kernels: half the LDS bytes per MFMA, no rounding
+    // in registers.  (The fp32 copies stay: LayerNorm output and residual stream are fp32 in every mode.)
+    const bool a16 = mode16(c.prec) && S % 8 == 0 && F % 8 == 0;
+    void* h16 = a16 ? c.ar.take((int64_t)B * tw * S * 2) : nullptr;
+    void* at16 = a16 ? c.ar.take((int64_t)B * tw * S * 2) : nullptr;
+    void* mm16 = a16 ? c.ar.take((int64_t)B * tw * F * 2) : nullptr;
+    layernorm(c, x, nullptr, m.blocks[0].ln1_g, m.blocks[0].ln1_b, h, B, tw, S, S, 0, S, 0, h16);
     for (int i = 0; i < nb; ++i) {
         const svcmi_whisper_block& blk = m.blocks[i];
         CV v; v.B = B; v.t_in = tw; v.c_in = v.ldx = S; v.x_bs = (int64_t)tw * S;
         {
-            CV q = v; q.x = h; q.w = &blk.qkv; q.y = qkv; q.y_bs = (int64_t)tw * 3 * S; q.ldy = 3 * S; q.tile = t_qkv; q.tile_lp = l_qkv;
+            CV q = v; q.x = h; q.x16 = h16; q.w = &blk.qkv; q.y = qkv; q.y_bs = (int64_t)tw * 3 * S; q.ldy = 3 * S; q.tile = t_qkv; q.tile_lp = l_qkv;
             conv(c, q);
         }
-        attention(c, qkv, a, B, tw, H, S, scale, nullptr, nullptr, 0, nullptr);
+        attention(c, qkv, a, B, tw, H, S, scale, nullptr, nullptr, 0, nullptr, at16);
         {
-            CV o = v; o.x = a; o.w = &blk.o; o.bias = false; o.slabs = slabs; o.split_k = so; o.tile = t_o; o.tile_lp = l_o;
+            CV o = v; o.x = a; o.x16 = at16; o.w = &blk.o; o.bias = false; o.slabs = slabs; o.split_k = so; o.tile = t_o; o.tile_lp = l_o;
             conv(c, o);
         }
-        splitk_layernorm(c, slabs, so, blk.o.bias, x, blk.ln2_g, blk.ln2_b, h, B, tw, S);
+        splitk_layernorm(c, slabs, so, blk.o.bias, x, blk.ln2_g, blk.ln2_b, h, B, tw, S, h16);
         {
-            CV u = v; u.x = h; u.w = &blk.m1; u.act = SVCMI_ACT_GELU; u.y = mm; u.y_bs = (int64_t)tw * F; u.ldy = F; u.split_k = 1;
-            u.tile = t_m1; u.tile_lp = l_m1;
+            CV u = v; u.x = h; u.x16 = h16; u.w = &blk.m1; u.act = SVCMI_ACT_GELU; u.y = mm; u.y_bs = (int64_t)tw * F; u.ldy = F; u.split_k = 1;
+            u.tile = t_m1; u.tile_lp = l_m1; u.y16 = mm16;
             conv(c, u);
         }
         {
-            CV dn = v; dn.x = mm; dn.c_in = dn.ldx = F; dn.x_bs = (int64_t)tw * F; dn.w = &blk.m2; dn.bias = false; dn.slabs = slabs;
+            CV dn = v; dn.x = mm; dn.x16 = mm16; dn.c_in = dn.ldx = F; dn.x_bs = (int64_t)tw * F; dn.w = &blk.m2; dn.bias = false; dn.slabs = slabs;
             dn.split_k = sm; dn.tile = t_m2; dn.tile_lp = l_m2;
             conv(c, dn);
         }
         const float* g = i + 1 < nb ? m.blocks[i + 1].ln1_g : m.lnp_g;
         const float* b = i + 1 < nb ? m.blocks[i + 1].ln1_b : m.lnp_b;
-        splitk_layernorm(c, slabs, sm, blk.m2.bias, x, g, b, h, B, tw, S);
+        splitk_layernorm(c, slabs, sm, blk.m2.bias, x, g, b, h, B, tw, S, h16);
     }
 }
 

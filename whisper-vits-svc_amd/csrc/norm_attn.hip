@@ -11,6 +11,13 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// 16-bit copy of four consecutive outputs (the A operand of a following SVCMI_PREC_*_A16 GEMM), 8-byte store
+__device__ __forceinline__ void store4_16(unsigned short* dst, float a, float b, float c, float d, int f16) {
+    unsigned* h = reinterpret_cast<unsigned*>(dst);
+    h[0] = f16 ? svcmi_cvt_pk_f16(a, b) : svcmi_cvt_pk_bf16(a, b);
+    h[1] = f16 ? svcmi_cvt_pk_f16(c, d) : svcmi_cvt_pk_bf16(c, d);
+}
+
 // ------------------------------------------------------------------------------------ LayerNorm
 // One wave per row; a lane owns float4 #(lane + 64*i).  Two-pass (mean, then centred variance) like
 // torch's CPU layer_norm so results track the oracle to rounding.
@@ -18,7 +25,8 @@ constexpr int LN_MAXV = 8;   // c <= 64*4*8 = 2048
 
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* res, const float* gamma,
                                                         const float* beta, float* y, int rows, int rows_per_batch,
-                                                        int c, int ldx, int ldr, int ldy, int gb_bs, float eps) {
+                                                        int c, int ldx, int ldr, int ldy, int gb_bs, float eps,
+                                                        unsigned short* y16, int ldy16, int f16) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;   // whole waves exit together; no block-level barrier below
@@ -67,6 +75,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
             o.z = (v[i].z - mean) * rstd * g.z + bb.z;
             o.w = (v[i].w - mean) * rstd * g.w + bb.w;
             *reinterpret_cast<float4*>(yr + 4 * q) = o;
+            if (y16) store4_16(y16 + (long long)row * ldy16 + 4 * q, o.x, o.y, o.z, o.w, f16);
         }
     }
 }
@@ -160,7 +169,8 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 
 __global__ __launch_bounds__(256) void splitk_layernorm_kernel(const float* part, int split, const float* bias, float* x,
                                                                const float* gamma, const float* beta, float* y,
-                                                               int rows_per_batch, int c, int ldx, int ldy, float eps) {
+                                                               int rows_per_batch, int c, int ldx, int ldy, float eps,
+                                                               unsigned short* y16, int ldy16, int f16) {
     __shared__ float red[4];
     const int row = blockIdx.x;
     const int nv = c >> 2;
@@ -214,6 +224,7 @@ __global__ __launch_bounds__(256) void splitk_layernorm_kernel(const float* part
             o.z = (v[i].z - mean) * rstd * g.z + bb.z;
             o.w = (v[i].w - mean) * rstd * g.w + bb.w;
             *reinterpret_cast<float4*>(yr + 4 * q) = o;
+            if (y16) store4_16(y16 + (long long)row * ldy16 + 4 * q, o.x, o.y, o.z, o.w, f16);
         }
     }
 }
@@ -244,6 +255,9 @@ struct AttnArgs {
     const float* rel_k; const float* rel_v;
     int window;
     const int32_t* lengths;
+    unsigned short* o16;       // optional 16-bit copy of o (rows of ldo16 values, batch stride o16_bs): the out-projection's A operand
+    long long o16_bs;
+    int ldo16, o16_f16;
 };
 
 constexpr int MAXW = 4;            // largest relative window
@@ -491,6 +505,7 @@ __global__ __launch_bounds__(64 * NS) void attention_kernel(AttnArgs p) {
         if (qrow < T) {
             const float inv = 1.0f / den;
             *reinterpret_cast<float4*>(ob + (long long)qrow * p.ldo + c4) = make_float4(num.x * inv, num.y * inv, num.z * inv, num.w * inv);
+            if (p.o16) store4_16(p.o16 + (long long)b * p.o16_bs + (long long)qrow * p.ldo16 + h * D + c4, num.x * inv, num.y * inv, num.z * inv, num.w * inv, p.o16_f16);
         }
     }
 }
@@ -663,6 +678,7 @@ __global__ __launch_bounds__(64 * NS) void attention_q32_kernel(AttnArgs p) {
         if (qrow < T) {
             const float inv = 1.0f / den;
             *reinterpret_cast<float4*>(ob + (long long)qrow * p.ldo + c4) = make_float4(num.x * inv, num.y * inv, num.z * inv, num.w * inv);
+            if (p.o16) store4_16(p.o16 + (long long)b * p.o16_bs + (long long)qrow * p.ldo16 + h * D + c4, num.x * inv, num.y * inv, num.z * inv, num.w * inv, p.o16_f16);
         }
     }
 }
@@ -862,6 +878,7 @@ __global__ __launch_bounds__(64 * QT * KS) void attention_lds_kernel(AttnArgs p)
         if (qrow < T) {
             const float inv = 1.0f / den;
             *reinterpret_cast<float4*>(ob + (long long)qrow * p.ldo + c4) = make_float4(num.x * inv, num.y * inv, num.z * inv, num.w * inv);
+            if (p.o16) store4_16(p.o16 + (long long)b * p.o16_bs + (long long)qrow * p.ldo16 + h * D + c4, num.x * inv, num.y * inv, num.z * inv, num.w * inv, p.o16_f16);
         }
     }
 }
@@ -944,8 +961,9 @@ int launch_attn(const AttnArgs& a_in, int batch, void* stream) {
 
 extern "C" int svcmi_layernorm_f32(const float* x, const float* res, const float* gamma, const float* beta, float* y,
                                    int32_t batch, int32_t rows_per_batch, int32_t c, int32_t ldx, int32_t ldr,
-                                   int32_t ldy, int32_t gb_bstride, float eps, void* stream) {
+                                   int32_t ldy, int32_t gb_bstride, float eps, void* y16, int32_t ldy16, int32_t y16_format, void* stream) {
     if (!x || !y || batch <= 0 || rows_per_batch <= 0 || c <= 0) return SVCMI_EINVAL;
+    if (y16 && (ldy16 % 4 || ldy16 < c || ((uintptr_t)y16 & 7) || (y16_format != SVCMI_PREC_BF16 && y16_format != SVCMI_PREC_F16))) return SVCMI_EINVAL;
     if (c % 4 != 0 || c > 64 * 4 * LN_MAXV) return SVCMI_EUNSUPPORTED;
     if (ldx % 4 || ldy % 4 || (res && ldr % 4) || gb_bstride % 4) return SVCMI_EALIGN;
     if (((uintptr_t)x & 15) || ((uintptr_t)y & 15) || ((uintptr_t)res & 15) || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15))
@@ -953,7 +971,8 @@ extern "C" int svcmi_layernorm_f32(const float* x, const float* res, const float
     const long long rows = (long long)batch * rows_per_batch;
     if (rows > 0x7fffffffLL) return SVCMI_EUNSUPPORTED;
     SVCMI_LAUNCH(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, res, gamma, beta, y,
-                 (int)rows, rows_per_batch, c, ldx, ldr, ldy, gb_bstride, eps);
+                 (int)rows, rows_per_batch, c, ldx, ldr, ldy, gb_bstride, eps, static_cast<unsigned short*>(y16), ldy16,
+                 (int)(y16_format == SVCMI_PREC_F16));
     return SVCMI_LAST_ERROR();
 }
 
@@ -980,8 +999,9 @@ extern "C" int svcmi_channel_norm_gelu_f32(const float* x, const float* gamma, c
 
 extern "C" int svcmi_splitk_layernorm_f32(const float* partials, int32_t split, const float* bias, float* x, const float* gamma,
                                           const float* beta, float* y, int32_t batch, int32_t rows_per_batch, int32_t c,
-                                          int32_t ldx, int32_t ldy, float eps, void* stream) {
+                                          int32_t ldx, int32_t ldy, float eps, void* y16, int32_t ldy16, int32_t y16_format, void* stream) {
     if (!partials || !x || !y || split < 1 || batch <= 0 || rows_per_batch <= 0 || c <= 0) return SVCMI_EINVAL;
+    if (y16 && (ldy16 % 4 || ldy16 < c || ((uintptr_t)y16 & 7) || (y16_format != SVCMI_PREC_BF16 && y16_format != SVCMI_PREC_F16))) return SVCMI_EINVAL;
     if (c % 4 != 0 || c > 256 * 4 * SKV) return SVCMI_EUNSUPPORTED;
     if (ldx % 4 || ldy % 4) return SVCMI_EALIGN;
     if (((uintptr_t)partials & 15) || ((uintptr_t)x & 15) || ((uintptr_t)y & 15) || ((uintptr_t)bias & 15) ||
@@ -989,7 +1009,7 @@ extern "C" int svcmi_splitk_layernorm_f32(const float* partials, int32_t split, 
     const long long rows = (long long)batch * rows_per_batch;
     if (rows > 0x7fffffffLL) return SVCMI_EUNSUPPORTED;
     SVCMI_LAUNCH(splitk_layernorm_kernel, dim3((unsigned)rows), dim3(256), 0, stream, partials, split, bias, x, gamma,
-                 beta, y, rows_per_batch, c, ldx, ldy, eps);
+                 beta, y, rows_per_batch, c, ldx, ldy, eps, static_cast<unsigned short*>(y16), ldy16, (int)(y16_format == SVCMI_PREC_F16));
     return SVCMI_LAST_ERROR();
 }
 
@@ -998,8 +1018,10 @@ extern "C" int svcmi_attention_f32(const float* q, const float* k, const float* 
                                    int64_t q_bstride, int64_t k_bstride, int64_t v_bstride, int64_t o_bstride,
                                    int32_t batch, int32_t t, int32_t heads, int32_t head_dim, float scale,
                                    const float* rel_k, const float* rel_v, int32_t window,
-                                   const int32_t* lengths, void* stream) {
+                                   const int32_t* lengths, void* o16, int32_t ldo16, int64_t o16_bstride, int32_t o16_format, void* stream) {
     if (!q || !k || !v || !o || batch <= 0 || t <= 0 || heads <= 0) return SVCMI_EINVAL;
+    if (o16 && (ldo16 % 4 || ldo16 < heads * head_dim || o16_bstride % 4 || ((uintptr_t)o16 & 7) ||
+                (o16_format != SVCMI_PREC_BF16 && o16_format != SVCMI_PREC_F16))) return SVCMI_EINVAL;
     if ((rel_k == nullptr) != (rel_v == nullptr)) return SVCMI_EINVAL;
     if (rel_k && (window < 0 || window > MAXW)) return SVCMI_EUNSUPPORTED;
     if (ldq % 4 || ldk % 4 || ldv % 4 || ldo % 4 || q_bstride % 4 || k_bstride % 4 || v_bstride % 4 || o_bstride % 4)
@@ -1010,6 +1032,7 @@ extern "C" int svcmi_attention_f32(const float* q, const float* k, const float* 
     a.q = q; a.k = k; a.v = v; a.o = o; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
     a.q_bs = q_bstride; a.k_bs = k_bstride; a.v_bs = v_bstride; a.o_bs = o_bstride;
     a.t = t; a.heads = heads; a.nq = (t + 15) / 16; a.scale = scale; a.rel_k = rel_k; a.rel_v = rel_v; a.window = window; a.lengths = lengths;
+    a.o16 = static_cast<unsigned short*>(o16); a.ldo16 = ldo16; a.o16_bs = o16_bstride; a.o16_f16 = o16_format == SVCMI_PREC_F16;
     switch (head_dim) {
         case 16: return launch_attn<16>(a, batch, stream);
         case 32: return launch_attn<32>(a, batch, stream);

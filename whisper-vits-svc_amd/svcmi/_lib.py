@@ -9,7 +9,7 @@ DEFAULT_LIB = os.path.join(HERE, "libsvcmi.so")
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_MISH, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4, 5
 CONV_ACCUMULATE, CONV_MASK_IN, CONV_MASK_OUT, CONV_PARTIALS = 1, 2, 4, 8
 ABI_VERSION = 17
-PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16 = 0, 1, 2, 3
+PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16, PREC_BF16_A16, PREC_F16_A16 = 0, 1, 2, 3, 4, 5
 PRECISIONS = {None: 0, "f32": 0, "fp32": 0, "bf16x3": 1, "bf16": 2, "f16": 3, "fp16": 3}
 CONV_TILE_64x128 = 9
 
@@ -31,6 +31,7 @@ class ConvDesc(Structure):
         ("act", c_int32), ("flags", c_int32), ("alpha", c_float), ("split_k", c_int32),
         ("workspace", c_void_p), ("workspace_floats", c_int64),
         ("counters", c_void_p), ("counters_len", c_int64),
+        ("y16", c_void_p), ("y16_bstride", c_int64), ("ldy16", c_int32), ("y16_format", c_int32),
     ]
 
 
@@ -41,8 +42,8 @@ STOP_NONE, STOP_PRIOR, STOP_FLOW, STOP_GEN_PRE, STOP_STAGE0 = 0, 1, 2, 3, 4
 
 class Weight(Structure):
     """svcmi_weight"""
-    _fields_ = [("w", c_void_p), ("bias", c_void_p), ("w16", c_void_p), ("n", c_int32), ("ldw", c_int32), ("ldw16", c_int32),
-                ("reserved", c_int32)]
+    _fields_ = [("w", c_void_p), ("bias", c_void_p), ("w16", c_void_p), ("w16a", c_void_p), ("n", c_int32), ("ldw", c_int32),
+                ("ldw16", c_int32), ("reserved", c_int32)]
 
 
 class WhisperBlock(Structure):
@@ -116,10 +117,10 @@ SIGNATURES = {
     "svcmi_pack_weights_lp": (c_int, [_P, _I, _I, _I, _P, _I, _P]),
     "svcmi_conv_gemm_lp": (c_int, [POINTER(ConvDesc), _I, _P]),
     "svcmi_conv_gemm_group_lp": (c_int, [_P, _I, _I, _P]),
-    "svcmi_layernorm_f32": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "svcmi_layernorm_f32": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _I, _I, _P]),
     "svcmi_channel_norm_gelu_f32": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
-    "svcmi_splitk_layernorm_f32": (c_int, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
-    "svcmi_attention_f32": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _I, _I, _I, _I, _F, _P, _P, _I, _P, _P]),
+    "svcmi_splitk_layernorm_f32": (c_int, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _I, _I, _P]),
+    "svcmi_attention_f32": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _I, _I, _I, _I, _F, _P, _P, _I, _P, _P, _I, _L, _I, _P]),
     "svcmi_snake_alias_f32": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "svcmi_snake_conv_supported": (c_int, [_I, _I, _I, _I]),
     "svcmi_snake_conv_preferred": (c_int, [_I, _I, _I, _I]),

@@ -3,7 +3,7 @@ svcmi_synth_model).  The structs only carry device pointers and dimensions: the 
 ``WhisperWeights`` object (and the 16-bit images by the per-tensor cache of ``Ops.lp_weight``), which the returned handle keeps
 alive."""
 from . import _lib
-from ._lib import PREC_BF16X3, PREC_F32
+from ._lib import PREC_BF16, PREC_BF16X3, PREC_F16, PREC_F32
 from .vits import consts as K
 
 
@@ -14,14 +14,19 @@ class CModel:
         self.struct, self.keep = struct, keep
 
 
-def _weight(cw, ops, w, bias, prec, keep):
+def _weight(cw, ops, w, bias, prec, keep, a16=False):
+    """``a16``: also pack the natural-order image of the 16-bit-activation kernels (bf16 / f16 modes only)."""
     cw.w, cw.bias = w.data_ptr(), (0 if bias is None else bias.data_ptr())
     cw.n, cw.ldw = int(w.shape[0]), int(w.shape[1])
-    cw.w16, cw.ldw16 = 0, 0
+    cw.w16, cw.w16a, cw.ldw16 = 0, 0, 0
     if prec != PREC_F32 and w.dim() == 2 and w.is_contiguous():
         img = ops.lp_weight(w, prec)
         cw.w16, cw.ldw16 = img.data_ptr(), img.shape[1] // (2 if prec == PREC_BF16X3 else 1)
         keep.append(img)
+        if a16 and prec in (PREC_BF16, PREC_F16):
+            img_a = ops.lp_weight(w, prec + 2)          # PREC_BF16_A16 / PREC_F16_A16
+            cw.w16a = img_a.data_ptr()
+            keep.append(img_a)
     keep.append(w)
     keep.append(bias)
 
@@ -39,10 +44,10 @@ def whisper_cmodel(w, ops, prec=PREC_F32):
     for i, b in enumerate(w.blocks):
         cb = m.blocks[i]
         cb.ln1_g, cb.ln1_b, cb.ln2_g, cb.ln2_b = (b[k].data_ptr() for k in ("ln1_g", "ln1_b", "ln2_g", "ln2_b"))
-        _weight(cb.qkv, ops, b["qkv_w"], b["qkv_b"], prec, keep)
-        _weight(cb.o, ops, b["o_w"], b["o_b"], prec, keep)
-        _weight(cb.m1, ops, b["m1_w"], b["m1_b"], prec, keep)
-        _weight(cb.m2, ops, b["m2_w"], b["m2_b"], prec, keep)
+        _weight(cb.qkv, ops, b["qkv_w"], b["qkv_b"], prec, keep, a16=True)
+        _weight(cb.o, ops, b["o_w"], b["o_b"], prec, keep, a16=True)
+        _weight(cb.m1, ops, b["m1_w"], b["m1_b"], prec, keep, a16=True)
+        _weight(cb.m2, ops, b["m2_w"], b["m2_b"], prec, keep, a16=True)
     return CModel(m, keep)
 
 

@@ -13,8 +13,13 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_GELU, ACT_MISH, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, CONV_ACCUMULATE, CONV_MASK_IN,  # noqa: F401
-                   CONV_MASK_OUT, CONV_PARTIALS, PREC_BF16X3, PREC_F32, PRECISIONS, ConvDesc, SnakeConvDesc, SvcmiError, SynthIO,
-                   TraceRecord)
+                   CONV_MASK_OUT, CONV_PARTIALS, PREC_BF16, PREC_BF16X3, PREC_F16, PREC_F32, PRECISIONS, ConvDesc, SnakeConvDesc, SvcmiError,
+                   SynthIO, TraceRecord)
+
+
+def _fmt16(dtype):
+    """torch.bfloat16 / torch.float16 -> the svcmi_precision code of a 16-bit output copy."""
+    return {torch.bfloat16: PREC_BF16, torch.float16: PREC_F16}[dtype]
 
 
 def _ptr(t):
@@ -293,18 +298,29 @@ class Ops:
         nbytes = 4.0 * (B * (t_in >> x_row_shift) * c_in + N * ksize * c_in + B * t_out * N * (1 + (res is not None) + bool(accumulate)))
         return d, out, (ws if (split_k != 1 or partials) else None), B, t_out, N, {"flops": 2.0 * B * t_out * N * ksize * c_in, "bytes": nbytes}
 
-    def conv(self, x, w, bias=None, **kw):
+    def conv(self, x, w, bias=None, *, x16=None, out16=None, **kw):
         """y[b,t,n] = epilogue(sum_k sum_ci x[b, t*stride + k*dilation - pad, ci] * w[n, k*c_in + ci]).
-        ``x`` is [B, T, C]; ``w`` is [N, ldw] packed (weights.pack_conv).  Keywords: see ``_conv_desc``."""
+        ``x`` is [B, T, C]; ``w`` is [N, ldw] packed (weights.pack_conv).  Keywords: see ``_conv_desc``.
+        ``x16``: the same activations as a bf16 / float16 tensor written by the producing kernel -- in the matching 16-bit mode the launch
+        then takes the _A16 kernel (no in-register rounding).  ``out16`` = torch.bfloat16 | torch.float16: also return that copy of y."""
         d, out, ws, B, t_out, N, work = self._conv_desc(x, w, bias, **kw)
+        y16 = None
+        if out16 is not None:
+            y16 = torch.empty(out.shape, dtype=out16, device=out.device)
+            d.y16, d.y16_bstride, d.ldy16, d.y16_format = y16.data_ptr(), y16.stride(0), y16.stride(1), _fmt16(out16)
         if self._lp_eligible(d, w, work):
             prec = self._to_lp(d, w, work)
+            if x16 is not None and prec == _fmt16(x16.dtype):
+                self._chk(x16)
+                prec += 2                                      # SVCMI_PREC_BF16_A16 / _F16_A16: natural-order weight image
+                img = self.lp_weight(w, prec)
+                d.x, d.w = x16.data_ptr(), img.data_ptr()
             self._call("svcmi_conv_gemm_lp", ctypes.byref(d), prec, self._stream(), work=work)
         else:
             self._call("svcmi_conv_gemm_f32", ctypes.byref(d), self._stream(), work=work)
         if kw.get("partials"):      # [B, split, t_out, N] view of this stream's workspace; valid until the next split-K launch on it
             return ws[0][:B * d.split_k * t_out * N].view(B, d.split_k, t_out, N)
-        return out
+        return out if out16 is None else (out, y16)
 
     def conv_group(self, problems):
         """Up to 3 convolutions of one geometry in one launch (svcmi_conv_gemm_group_f32).  ``problems``: dicts of ``conv``
@@ -333,15 +349,18 @@ class Ops:
         return outs
 
     # ------------------------------------------------------------------ norm / attention
-    def layernorm(self, x, gamma=None, beta=None, *, res=None, eps=1e-5, per_batch_affine=False, out=None):
+    def layernorm(self, x, gamma=None, beta=None, *, res=None, eps=1e-5, per_batch_affine=False, out=None, out16=None):
+        """``out16`` = torch.bfloat16 | torch.float16: also return the rows rounded to that type (a following GEMM's 16-bit A operand)."""
         self._chk(x, gamma, beta, res, out)
         B, T, Cc = x.shape
         if out is None:
             out = torch.empty_like(x)
+        y16 = torch.empty(B, T, Cc, dtype=out16, device=x.device) if out16 is not None else None
         self._call("svcmi_layernorm_f32", _ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(out), B, T, Cc,
                    x.stride(1), res.stride(1) if res is not None else 0, out.stride(1),
-                   (gamma.stride(0) if gamma is not None else beta.stride(0)) if per_batch_affine else 0, eps, self._stream())
-        return out
+                   (gamma.stride(0) if gamma is not None else beta.stride(0)) if per_batch_affine else 0, eps,
+                   _ptr(y16), Cc, _fmt16(out16) if out16 is not None else 0, self._stream())
+        return out if out16 is None else (out, y16)
 
     def channel_norm_gelu(self, x, gamma, beta, eps=1e-5, out=None):
         """GroupNorm(C, C) over time + GELU on time-major x [B, T, C] (hubert/hubert_model.py:78,88)."""
@@ -354,18 +373,19 @@ class Ops:
                    x.stride(1), out.stride(1), eps, self._stream())
         return out
 
-    def splitk_layernorm(self, partials, bias, x, gamma, beta, *, eps=1e-5, out=None):
+    def splitk_layernorm(self, partials, bias, x, gamma, beta, *, eps=1e-5, out=None, out16=None):
         """x += bias + sum_s partials[:, s]  (in place);  returns LayerNorm(x) * gamma + beta.  partials: [B, S, T, C]."""
         self._chk(partials, bias, x, gamma, beta, out)
         B, S, T, Cc = partials.shape
         if out is None:
             out = torch.empty_like(x)
+        y16 = torch.empty(B, T, Cc, dtype=out16, device=x.device) if out16 is not None else None
         self._call("svcmi_splitk_layernorm_f32", _ptr(partials), S, _ptr(bias), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(out),
-                   B, T, Cc, x.stride(1), out.stride(1), eps, self._stream())
-        return out
+                   B, T, Cc, x.stride(1), out.stride(1), eps, _ptr(y16), Cc, _fmt16(out16) if out16 is not None else 0, self._stream())
+        return out if out16 is None else (out, y16)
 
-    def attention(self, qkv, heads, scale, *, rel_k=None, rel_v=None, window=0, lengths=None, out=None):
-        """qkv: [B, T, 3*C] fused projection (q | k | v).  Returns [B, T, C]."""
+    def attention(self, qkv, heads, scale, *, rel_k=None, rel_v=None, window=0, lengths=None, out=None, out16=None):
+        """qkv: [B, T, 3*C] fused projection (q | k | v).  Returns [B, T, C] (+ its bf16 / float16 copy with ``out16``)."""
         self._chk(qkv, rel_k, rel_v, lengths, out)
         B, T, C3 = qkv.shape
         Cc = C3 // 3
@@ -373,10 +393,12 @@ class Ops:
             out = torch.empty(B, T, Cc, dtype=torch.float32, device=qkv.device)
         base = qkv.data_ptr()
         bs = qkv.stride(0)
+        o16 = torch.empty(B, T, Cc, dtype=out16, device=qkv.device) if out16 is not None else None
         self._call("svcmi_attention_f32", base, base + 4 * Cc, base + 8 * Cc, _ptr(out), C3, C3, C3, out.stride(1),
                    bs, bs, bs, out.stride(0), B, T, heads, Cc // heads, scale, _ptr(rel_k), _ptr(rel_v), window,
-                   _ptr(lengths), self._stream(), work={"flops": 4.0 * B * T * T * Cc})
-        return out
+                   _ptr(lengths), _ptr(o16), Cc, T * Cc, _fmt16(out16) if out16 is not None else 0, self._stream(),
+                   work={"flops": 4.0 * B * T * T * Cc})
+        return out if out16 is None else (out, o16)
 
     # ------------------------------------------------------------------ generator pieces
     def snake_alias(self, x, alpha_log, beta_log, filt, out=None):
