@@ -200,7 +200,9 @@ int svcmi_snake_alias_f32(const float* x, float* y, const float* alpha_log, cons
  * blocks of a generator stage at the same step.  The pointer arrays are host arrays read during the call. */
 int svcmi_snake_alias_group_f32(const float* const* x, float* const* y, const float* const* alpha_log,
                                 const float* const* beta_log, const float* filt, int32_t count, int32_t batch,
-                                int32_t len, int32_t c, int32_t ld, void* stream);
+                                int32_t len, int32_t c, int32_t ld, void* const* y16, int32_t y16_format, void* stream);
+/* (y16 != NULL: tensor i is written as bf16 / fp16 rows (y16_format, same ld) to y16[i] INSTEAD of fp32 to y[i] -- the activation only
+ * feeds the following convolution, which then runs as an SVCMI_PREC_*_A16 launch; y / y[i] may be NULL then.) */
 /* y[i] = ((xs[0][i] + xs[1][i]) + xs[2][i]) / count, count <= 3: the `xs / num_kernels` of vits_decoder/generator.py:188-194
  * when the AMP blocks ran side by side in grouped launches.  n % 4 == 0, 16-byte aligned pointers; y may alias xs[0]. */
 int svcmi_block_mean_f32(const float* const* xs, int32_t count, float* y, int64_t n, void* stream);

@@ -29,7 +29,7 @@ def timeit(fn, iters=30, warm=5):
     return e0.elapsed_time(e1) * 1e3 / iters      # us
 
 
-def gemm(ops, tag, T, cin, n, k=1, dil=1, res=False, tiles=(0, 1, 2, 3), splits=(1, 0), B=1, prec=None, partials=False):
+def gemm(ops, tag, T, cin, n, k=1, dil=1, res=False, tiles=(0, 1, 2, 3), splits=(1, 0), B=1, prec=None, partials=False, a16=False):
     g = torch.Generator().manual_seed(0)
     x = torch.randn(B, T, cin, generator=g).cuda()
     w = PW.pack_conv(torch.randn(n, cin, k, generator=g) / math.sqrt(cin * k)).cuda()
@@ -37,15 +37,16 @@ def gemm(ops, tag, T, cin, n, k=1, dil=1, res=False, tiles=(0, 1, 2, 3), splits=
     r = torch.randn(B, T, n, generator=g).cuda() if res else None
     out = torch.empty(B, T, n, device="cuda")
     fl = 2.0 * B * T * n * k * cin
+    x16 = x.to({"f16": torch.float16, "bf16": torch.bfloat16}[prec]) if a16 else None      # the producer's 16-bit copy: _A16 kernels
     for tile in tiles:
         for sk in splits:
             try:
                 with ops.use_precision(prec):
                     if partials and sk >= 1:
-                        us = timeit(lambda: ops.conv(x, w, None, ksize=k, dilation=dil, pad=(k - 1) * dil // 2, tile=tile, split_k=sk, partials=True))
+                        us = timeit(lambda: ops.conv(x, w, None, ksize=k, dilation=dil, pad=(k - 1) * dil // 2, tile=tile, split_k=sk, partials=True, x16=x16))
                     else:
-                        us = timeit(lambda: ops.conv(x, w, bias, ksize=k, dilation=dil, pad=(k - 1) * dil // 2, res=r, out=out, tile=tile, split_k=sk, n_out=n))
-                print(f"gemm {tag:18s} {prec or 'f32':6s} B={B} T={T} cin={cin} n={n} k={k} d={dil} tile={tile} split={sk}{' partials' if partials else ''}: {us:8.1f} us  {fl / us / 1e6:7.1f} TF/s", flush=True)
+                        us = timeit(lambda: ops.conv(x, w, bias, ksize=k, dilation=dil, pad=(k - 1) * dil // 2, res=r, out=out, tile=tile, split_k=sk, n_out=n, x16=x16))
+                print(f"gemm {tag:18s} {(prec or 'f32') + ('+a16' if a16 else ''):8s} B={B} T={T} cin={cin} n={n} k={k} d={dil} tile={tile} split={sk}{' partials' if partials else ''}: {us:8.1f} us  {fl / us / 1e6:7.1f} TF/s", flush=True)
             except Exception as e:      # noqa: BLE001
                 print(f"gemm {tag} tile={tile} split={sk}: {e}")
 
@@ -77,6 +78,17 @@ def main():
             gemm(ops, "stage0_C160_B16", 5000, 160, 160, k=7, dil=3, res=True, tiles=(0,), splits=(1,), B=16, prec=prec)
             gemm(ops, "stage1_C80_B16", 20000, 80, 80, k=7, dil=3, res=True, tiles=(0,), splits=(1,), B=16, prec=prec)
             gemm(ops, "stage2_C40_B4", 80000, 40, 40, k=7, dil=3, res=True, tiles=(0,), splits=(1,), B=4, prec=prec)
+    if "a16" in what:         # 16-bit activations (K-step 64) against the in-register rounding kernels on the Whisper window shapes
+        for T in (500, 750, 1500):
+            for a16 in (False, True):
+                gemm(ops, "whisper_qkv", T, 1280, 3840, tiles=(1, 9, 3), splits=(1,), prec="f16", a16=a16)
+                gemm(ops, "whisper_mlp1", T, 1280, 5120, tiles=(1, 9, 3), splits=(1,), prec="f16", a16=a16)
+                gemm(ops, "whisper_o", T, 1280, 1280, tiles=(1, 9), splits=(1, 2, 4), prec="f16", partials=True, a16=a16)
+                gemm(ops, "whisper_mlp2", T, 5120, 1280, tiles=(1, 9), splits=(1, 2, 4, 8), prec="f16", partials=True, a16=a16)
+        for a16 in (False, True):
+            gemm(ops, "square4096", 4096, 4096, 4096, tiles=(9, 3), splits=(1,), prec="bf16", a16=a16)
+            gemm(ops, "stage1_C80_B16", 20000, 80, 80, k=7, dil=3, res=True, tiles=(0,), splits=(1,), B=16, prec="bf16", a16=a16)
+            gemm(ops, "stage0_C160_B16", 5000, 160, 160, k=7, dil=3, res=True, tiles=(0,), splits=(1,), B=16, prec="bf16", a16=a16)
     if "gemmpmc" in what:     # few launches, for counter collection
         global timeit
         _t = timeit

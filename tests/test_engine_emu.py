@@ -48,6 +48,12 @@ def test_generator_base_widths_bf16x3_within_parity_bar(ops):
     print(E.check_generator_widths_against_oracle(ops, "cpu", T=3, B=2, tol=2e-4, precision="bf16x3"))
 
 
+def test_generator_base_widths_f16_with_16bit_activations(ops):
+    """fp16 mode: on the wide stages SnakeAlias writes 16-bit rows and the grouped GEMMs run the _A16 kernels (K-step 64) -- error in
+    the fp16 class against the fp32 oracle."""
+    print(E.check_generator_widths_against_oracle(ops, "cpu", T=3, B=1, tol=4e-3, precision="f16"))
+
+
 def test_whisper_tiny_f16_operands(ops):
     """fp16 operands (what the reference's `.half()` accelerator path uses, whisper/inference.py:22-23) on the tiny encoder:
     error in the fp16 class, far from fp32's 1e-6 but bounded."""

@@ -63,10 +63,12 @@ constexpr int BK = 32;
 enum { MODE_CHUNK = 0, MODE_VEC = 1, MODE_SCALAR = 2, MODE_CHUNK_RS = 3 };   // _RS: CHUNK with x_row_shift != 0
 
 enum { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_BF16 = 2, PREC_F16 = 3, PREC_BF16_A16 = 4, PREC_F16_A16 = 5 };   // == enum svcmi_precision
-// _A16: the ACTIVATIONS arrive as a 16-bit tensor too (written by the producing kernel's epilogue): the A tile is [rows][64 B] like the
-// B tile, a lane's MFMA fragment is ONE ds_read_b128 of 8 consecutive k and nothing is rounded in registers; the weight image is in
-// natural k order for these modes (svcmi_pack_weights_lp with an _A16 precision).  Same products as the in-register rounding of the
-// plain modes (the same fp32 values rounded the same way), at half the LDS bytes per MFMA.
+// _A16: the ACTIVATIONS arrive as a 16-bit tensor too (written by the producing kernel's epilogue) and the weight image is in natural
+// k order (svcmi_pack_weights_lp with an _A16 precision).  Both tiles then use the fp32 kernel's data movement unchanged -- rows of 128
+// bytes, eight 16-byte chunks XOR-swizzled by swz(row), 8 rows per 1-KiB DMA piece -- on 16-bit data: a K-step covers 64 k instead of
+// 32, a lane's ds_read_b128 fragment (8 consecutive k) feeds ONE 16-bit MFMA where the fp32 kernel issues four, and nothing is rounded
+// in registers.  Half the barriers / DMA issues / LDS bytes per FLOP of the plain 16-bit modes, and the same products (the same fp32
+// values rounded the same way by the producer).
 
 struct ConvArgs {
     const float* x; const float* w; const float* bias; const float* res; float* y; const int32_t* lengths;
@@ -161,26 +163,27 @@ constexpr unsigned OOB = 0x40000000u;   // added to an offset that must read as 
 // `grid_blocks` / `block_id`: the launch geometry of THIS problem (a grouped launch runs several problems back to back in one grid).
 template <int WM, int WN, int MODE, bool P16, int NSTO = 0, int PREC = PREC_F32>
 __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid_blocks, const int block_id) {
-    constexpr bool LP = PREC != PREC_F32;             // 16-bit weight image(s); fp32 activations rounded in registers unless A16
-    constexpr bool A16 = PREC >= PREC_BF16_A16;       // 16-bit activations: A tile rows of 64 bytes, fragments straight from LDS
+    constexpr bool A16 = PREC >= PREC_BF16_A16;       // 16-bit activations AND weights in the fp32 kernel's tile geometry, K-step 64
+    constexpr bool LP = PREC != PREC_F32 && !A16;     // 16-bit weight image(s) in 64-byte rows, fp32 activations rounded in registers
+    constexpr int KS = A16 ? 2 * BK : BK;             // k per K-step
+    constexpr unsigned ESZ = A16 ? 2u : 4u;           // bytes per activation element
     constexpr bool F16OP = PREC == PREC_F16 || PREC == PREC_F16_A16;
     constexpr int NB = PREC == PREC_BF16X3 ? 2 : 1;   // B images per stage (hi, lo)
     constexpr int BM = 64 * WM, BN = P16 ? 16 * WN : 64 * WN;
     constexpr int BROW = LP ? BK / 2 : BK;            // floats per B row in LDS (LP: 32 x 2 bytes)
     constexpr int BNL = LP ? (BN + 63) / 64 * 64 : (BN + 31) / 32 * 32;   // B rows held in LDS (whole 4-wave DMA rounds)
-    constexpr int AROW = A16 ? BK / 2 : BK;           // floats per A row in LDS
-    constexpr int A_PER = A16 ? BM / 64 : BM / 32, B_PER = LP ? BNL / 64 : BNL / 32;      // 1-KiB LDS-DMA pieces (8 x 128 B or 16 x 64 B rows) per wave per K-step (per image)
+    constexpr int A_PER = BM / 32, B_PER = LP ? BNL / 64 : BNL / 32;      // 1-KiB LDS-DMA pieces (8 x 128 B or 16 x 64 B rows) per wave per K-step (per image)
     constexpr int BTILE = BNL * BROW;                 // floats per B image per stage
     constexpr int CLD = BN;                           // epilogue staging tile [BM][BN] reuses the operand buffers
     // LDS ring of NST operand tiles (48 / 72 / 64 KiB per block): tile it+NST-1 is in flight while tile
     // `it` is consumed, so a K-step never waits a full HBM/L2 round trip -- what short K ranges (split-K slices,
     // the k=1 projections of the prior encoder / flow, k=3 convolutions) would otherwise pay on every step.
     constexpr int NST = NSTO ? NSTO : (LP ? 3 : (P16 ? ((BM + BNL) > 192 ? 2 : 3) : ((WM * WN == 1) ? 3 : (WM * WN == 2 ? 3 : 2))));
-    constexpr int RING = NST * (BM * AROW + NB * BTILE);
-    static_assert(LP || BM * CLD <= RING, "C tile must fit in the operand buffers");
+    constexpr int RING = NST * (BM * BK + NB * BTILE);
+    static_assert(LP || A16 || BM * CLD <= RING, "C tile must fit in the operand buffers");
     __shared__ __attribute__((aligned(16))) float smem[(RING > BM * CLD ? RING : BM * CLD) + 4];   // + the split-K ticket word
     float* const As0 = smem;                          // As[slot] = As0 + slot*BM*BK, rows of 32 floats, chunk-swizzled
-    float* const Bs0 = smem + NST * BM * AROW;        // Bs[slot][image] = Bs0 + (slot*NB + image)*BTILE
+    float* const Bs0 = smem + NST * BM * BK;          // Bs[slot][image] = Bs0 + (slot*NB + image)*BTILE
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = SVCMI_UNIFORM((int)(tid >> 6));
@@ -204,10 +207,10 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
     const int x_rows = (t_lim + (1 << p.rshift) - 1) >> p.rshift;
     const svcmi_rsrc xr = A16 ? svcmi_make_rsrc(reinterpret_cast<const unsigned short*>(p.x) + (long long)b * p.x_bs, (unsigned)x_rows * (unsigned)p.ldx * 2u)
                               : svcmi_make_rsrc(p.x + (long long)b * p.x_bs, (unsigned)x_rows * (unsigned)p.ldx * 4u);
-    const svcmi_rsrc wr = LP ? svcmi_make_rsrc(p.w16, (unsigned)p.n_out * (unsigned)(NB * p.ldw16) * 2u)
+    const svcmi_rsrc wr = (LP || A16) ? svcmi_make_rsrc(p.w16, (unsigned)p.n_out * (unsigned)(NB * p.ldw16) * 2u)
                              : svcmi_make_rsrc(p.w, (unsigned)p.n_out * (unsigned)p.ldw * 4u);
 
-    const int nk_all = (p.ktot + BK - 1) / BK;
+    const int nk_all = (p.ktot + KS - 1) / KS;
     const int it_beg = (int)((long long)nk_all * slice / p.split);
     const int it_end = (int)((long long)nk_all * (slice + 1) / p.split);
 
@@ -222,22 +225,22 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
     unsigned b_row[B_PER];
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
-        const int t = A16 ? m0 + (wave + 4 * i) * 16 + (lane >> 2) : m0 + (wave + 4 * i) * 8 + prow;   // A16: a piece is 16 rows of 64 bytes
+        const int t = m0 + (wave + 4 * i) * 8 + prow;
         a_tb[i] = t * p.stride - p.pad;
-        a_row[i] = t < p.t_out ? (unsigned)a_tb[i] * (unsigned)p.ldx * (A16 ? 2u : 4u) : OOB;
+        a_row[i] = t < p.t_out ? (unsigned)a_tb[i] * (unsigned)p.ldx * ESZ : OOB;
         if (t >= p.t_out) a_tb[i] = -0x40000000;
     }
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
         // LP: a piece is 16 rows of 64 bytes, lane l -> row l>>2, position l&3
         const int n = n0 + (wave + 4 * i) * (LP ? 16 : 8) + (LP ? (lane >> 2) : prow);
-        b_row[i] = n < p.n_out ? (LP ? (unsigned)(n * NB * p.ldw16) * 2u : (unsigned)(n * p.ldw) * 4u) : OOB;
+        b_row[i] = n < p.n_out ? ((LP || A16) ? (unsigned)(n * NB * p.ldw16) * 2u : (unsigned)(n * p.ldw) * 4u) : OOB;
     }
     const int lkq16 = ((lane & 3) ^ swz16(lane >> 2)) * 16;    // LP: this lane's byte offset within the 64-byte K-step of a B row
     // CHUNK mode: wave-uniform (tap, first channel) of the K-step, advanced incrementally
     int tap_u = 0, ci_u = 0;
     if (MODE == MODE_CHUNK || MODE == MODE_CHUNK_RS) {
-        const int k0 = it_beg * BK;
+        const int k0 = it_beg * KS;
         tap_u = k0 / p.c_in;
         ci_u = k0 - tap_u * p.c_in;
     }
@@ -259,23 +262,23 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
     unsigned a_koff = 0, b_koff = 0;     // K part of this lane's byte offset (or OOB), valid between prep and issue
     int tap_v = 0, ci_v = 0;             // x_row_shift path: this K-step's (tap, channel)
     auto stage_prep = [&](int it) {
-        const int kk = it * BK + lkq;
+        const int lkk = A16 ? 2 * lkq : lkq;         // this lane's k offset within the K-step (a 16-byte chunk = 4 fp32 or 8 16-bit values)
+        const int kk = it * KS + lkk;
         if (LP) b_koff = (it * BK * 2 + lkq16) < p.ldw16 * 2 ? (unsigned)(it * BK * 2 + lkq16) : OOB;
+        else if (A16) b_koff = kk < p.ldw16 ? (unsigned)kk * 2u : OOB;
         else b_koff = kk < p.ldw ? (unsigned)kk * 4u : OOB;
         if (MODE == MODE_CHUNK || MODE == MODE_CHUNK_RS) {
-            tap_v = tap_u; ci_v = ci_u + lkq;
-            if (A16) a_koff = (unsigned)(tap_u * p.dil * p.ldx + ci_u) * 2u + (unsigned)lkq16;
-            else a_koff = (unsigned)(tap_u * p.dil * p.ldx + ci_u + lkq) * 4u;
-            ci_u += BK;
+            tap_v = tap_u; ci_v = ci_u + lkk;
+            a_koff = (unsigned)(tap_u * p.dil * p.ldx + ci_u + lkk) * ESZ;
+            ci_u += KS;
             if (ci_u >= p.c_in) { ci_u -= p.c_in; ++tap_u; }
-        } else if (MODE == MODE_VEC) {
-            const int kv = A16 ? it * BK + (lkq16 >> 1) : kk;      // A16: this lane's 16-byte chunk = 8 consecutive k (c_in % 8 == 0: inside one tap)
-            tap_v = div_magic(kv, p.magic); ci_v = kv - tap_v * p.c_in;
-            a_koff = kv < p.ktot ? (unsigned)(tap_v * p.dil * p.ldx + ci_v) * (A16 ? 2u : 4u) : OOB;
+        } else if (MODE == MODE_VEC) {      // (A16: c_in % 8 == 0, so a lane's 8 consecutive k lie inside one tap)
+            tap_v = div_magic(kk, p.magic); ci_v = kk - tap_v * p.c_in;
+            a_koff = kk < p.ktot ? (unsigned)(tap_v * p.dil * p.ldx + ci_v) * ESZ : OOB;
         }
     };
     auto stage_a = [&](int it, int buf, int i) {          // piece i of the A tile
-        const svcmi_ldsaddr dst = svcmi_lds_advance(lds_a, buf * BM * AROW + 4 * i * 8 * BK);      // (a piece is 1 KiB in either layout)
+        const svcmi_ldsaddr dst = svcmi_lds_advance(lds_a, buf * BM * BK + 4 * i * 8 * BK);
         if (MODE == MODE_SCALAR) {
             // 4-byte DMA: a wave-instruction fills 2 rows (64 floats); the piece needs 4 of them.
 #pragma unroll
@@ -307,7 +310,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
     // Either way the chunk sits at position chunk ^ swz(row), and both access patterns are bank-conflict free.
     constexpr int FR = P16 ? 16 : 32;                  // rows per MFMA tile
     const int frow = lane & (FR - 1), fhi = P16 ? (lane >> 4) : (lane >> 5);
-    const int a_off = (wm * FR * WM + frow) * AROW, b_off = (wn * FR * WN + frow) * BROW;
+    const int a_off = (wm * FR * WM + frow) * BK, b_off = (wn * FR * WN + frow) * BROW;
     // Fragment reads of sub-step s into (a4, b4).  `tie` is a register the MFMAs issued next consume.
     auto load_frags = [&](const float* Ab, const float* Bb, int s, svcmi_f32x4 (&a4)[WM], svcmi_f32x4 (&b4)[WN], svcmi_f32x4& tie) {
         const int pos = ((((P16 ? 4 : 2) * s + fhi) ^ swz(frow)) << 2);
@@ -334,12 +337,8 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
         const int pa = (q ^ swz(frow)) << 2, pb = (q ^ swz16(frow)) << 2;
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
-            if constexpr (A16) {
-                svcmi_lds_read16(a8[i][0], Ab + i * FR * AROW + pb, tie);      // 16-bit A row: same 64-byte layout and swizzle as a B row
-            } else {
-                svcmi_lds_read16(a8[i][0], Ab + i * FR * BK + pa, tie);
-                svcmi_lds_read16(a8[i][1], Ab + i * FR * BK + (pa ^ 16), tie);
-            }
+            svcmi_lds_read16(a8[i][0], Ab + i * FR * BK + pa, tie);
+            svcmi_lds_read16(a8[i][1], Ab + i * FR * BK + (pa ^ 16), tie);
         }
 #pragma unroll
         for (int h = 0; h < NB; ++h)
@@ -348,9 +347,9 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
     };
     auto frags_arrive_lp = [&](svcmi_f32x4 (&a8)[WM][2], svcmi_f32x4 (&b8)[NB][WN]) {
         svcmi_lds_arrive(a8[0][0]);
-        if constexpr (!A16) svcmi_lds_landed(a8[0][1]);
+        svcmi_lds_landed(a8[0][1]);
 #pragma unroll
-        for (int i = 1; i < WM; ++i) { svcmi_lds_landed(a8[i][0]); if constexpr (!A16) svcmi_lds_landed(a8[i][1]); }
+        for (int i = 1; i < WM; ++i) { svcmi_lds_landed(a8[i][0]); svcmi_lds_landed(a8[i][1]); }
 #pragma unroll
         for (int h = 0; h < NB; ++h)
 #pragma unroll
@@ -404,7 +403,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
         int nslot = slot + NST - 1;
         if (nslot >= NST) nslot -= NST;
         if (ISSUE) stage_prep(it + NST - 1);
-        const float* Ab = As0 + slot * BM * AROW + a_off;
+        const float* Ab = As0 + slot * BM * BK + a_off;
         const float* Bb = Bs0 + slot * NB * BTILE + b_off;
         svcmi_f32x4 tie0 = {0.f, 0.f, 0.f, 0.f};
         if constexpr (LP) {
@@ -423,10 +422,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
                 }
                 svcmi_u32x4 ahi[WM], alo[WM];
 #pragma unroll
-                for (int i = 0; i < WM; ++i) {
-                    if constexpr (A16) ahi[i] = svcmi_as_u32x4(a8[s & 1][i][0]);
-                    else round_frag(a8[s & 1][i], ahi[i], alo[i]);
-                }
+                for (int i = 0; i < WM; ++i) round_frag(a8[s & 1][i], ahi[i], alo[i]);
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -467,22 +463,29 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
                     else stage_b(nslot, q - A_PER);
                 }
             }
+            if constexpr (A16) {         // the fragment's 16 bytes are 8 consecutive 16-bit k: one MFMA per (i, j)
 #pragma unroll
-            for (int i = 0; i < WM; ++i)
+                for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int j = 0; j < WN; ++j) mma(acc[i][j], af[i][0], bf[j][0]);
+                    for (int j = 0; j < WN; ++j) mma16(acc[i][j], svcmi_as_u32x4(af[i]), svcmi_as_u32x4(bf[j]));
+            } else {
 #pragma unroll
-            for (int i = 0; i < WM; ++i)
+                for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int j = 0; j < WN; ++j) mma(acc[i][j], af[i][1], bf[j][1]);
+                    for (int j = 0; j < WN; ++j) mma(acc[i][j], af[i][0], bf[j][0]);
 #pragma unroll
-            for (int i = 0; i < WM; ++i)
+                for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int j = 0; j < WN; ++j) mma(acc[i][j], af[i][2], bf[j][2]);
+                    for (int j = 0; j < WN; ++j) mma(acc[i][j], af[i][1], bf[j][1]);
 #pragma unroll
-            for (int i = 0; i < WM; ++i)
+                for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int j = 0; j < WN; ++j) mma(acc[i][j], af[i][3], bf[j][3]);
+                    for (int j = 0; j < WN; ++j) mma(acc[i][j], af[i][2], bf[j][2]);
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) mma(acc[i][j], af[i][3], bf[j][3]);
+            }
             // ... and waited for after them (the pins keep this sub-step's MFMAs above the wait)
             if (s + 1 < NSUB) {
 #pragma unroll
@@ -763,7 +766,7 @@ int prepare(const svcmi_conv_desc* d, ConvArgs& a, int& mode, int prec = PREC_F3
     a.magic = d->c_in == 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d->c_in - 1) / (unsigned)d->c_in);
     if (d->y16 && !a.vec) return SVCMI_EALIGN;      // the 16-bit copy is written by the float4 epilogue only
     const bool vec = (d->c_in % 4 == 0) && (d->ldx % 4 == 0) && (d->x_bstride % 4 == 0) && (((uintptr_t)d->x & 15) == 0);
-    mode = !vec ? MODE_SCALAR : (d->c_in % BK == 0 ? MODE_CHUNK : MODE_VEC);
+    mode = !vec ? MODE_SCALAR : (d->c_in % (a16 ? 2 * BK : BK) == 0 ? MODE_CHUNK : MODE_VEC);      // CHUNK: a K-step (32 k; _A16: 64 k) lies inside one tap
     if (d->x_row_shift) mode = mode == MODE_CHUNK ? MODE_CHUNK_RS : MODE_SCALAR;   // the fused row repeat: CHUNK_RS or per-element
     return SVCMI_OK;
 }

@@ -96,7 +96,8 @@ extern "C" int svcmi_conv_gemm_lp(const svcmi_conv_desc* d, int32_t precision, v
     const long long blocks = (long long)((d->t_out + bm - 1) / bm) * ((d->n_out + bn - 1) / bn) * d->batch;
     // Split-K as in the fp32 entry point: raw slabs for a consumer kernel (PARTIALS), or slices summed by the reduce kernel
     a.split = 1;
-    const int nk = (a.ktot + BK - 1) / BK;
+    const int kstep = precision >= SVCMI_PREC_BF16_A16 ? 2 * BK : BK;
+    const int nk = (a.ktot + kstep - 1) / kstep;
     if (d->flags & SVCMI_CONV_PARTIALS) {
         if (!d->workspace || d->split_k < 1 || d->split_k > nk) return SVCMI_EINVAL;
         if ((long long)d->batch * d->split_k * d->t_out * d->n_out > d->workspace_floats) return SVCMI_EINVAL;

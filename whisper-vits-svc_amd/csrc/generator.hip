@@ -21,6 +21,8 @@ struct SnakeArgs {
     const float* x[SNAKE_GROUP]; float* y[SNAKE_GROUP]; const float* alpha_log[SNAKE_GROUP]; const float* beta_log[SNAKE_GROUP];
     const float* filt;
     int n, c, ld;
+    unsigned short* y16[SNAKE_GROUP];      // when set: the output goes out as bf16 / fp16 rows INSTEAD of fp32 (a following _A16 GEMM's A operand)
+    int f16;
 };
 
 __global__ __launch_bounds__(TPB) void snake_alias_kernel(SnakeArgs p) {
@@ -36,7 +38,8 @@ __global__ __launch_bounds__(TPB) void snake_alias_kernel(SnakeArgs p) {
     const float a = expf(p.alpha_log[gi][ch]);
     const float inv_b = 1.0f / (expf(p.beta_log[gi][ch]) + 1e-9f);
     const float* xc = p.x[gi] + (long long)b * n * ld + ch;
-    float* yc = p.y[gi] + (long long)b * n * ld + ch;
+    float* yc = p.y[gi] ? p.y[gi] + (long long)b * n * ld + ch : nullptr;
+    unsigned short* yh = p.y16[gi] ? p.y16[gi] + (long long)b * n * ld + ch : nullptr;
 
     float f[12];
 #pragma unroll
@@ -49,7 +52,10 @@ __global__ __launch_bounds__(TPB) void snake_alias_kernel(SnakeArgs p) {
     snake_run<RT>(xw, f, a, inv_b, xc, ld, n, t0, out);
 #pragma unroll
     for (int r = 0; r < RT; ++r)
-        if (t0 + r < n) yc[(long long)(t0 + r) * ld] = out[r];
+        if (t0 + r < n) {
+            if (yh) yh[(long long)(t0 + r) * ld] = (unsigned short)((p.f16 ? svcmi_cvt_pk_f16(out[r], 0.f) : svcmi_cvt_pk_bf16(out[r], 0.f)) & 0xffffu);
+            else yc[(long long)(t0 + r) * ld] = out[r];
+        }
 }
 
 // y = ((x0 + x1) + x2) / count -- `xs = xs + resblock(x)` ... `x = xs / num_kernels` (vits_decoder/generator.py:188-194), float4 stream
@@ -154,18 +160,21 @@ __global__ __launch_bounds__(TPB) void source2wav_kernel(const float* x, int16_t
 
 extern "C" int svcmi_snake_alias_group_f32(const float* const* x, float* const* y, const float* const* alpha_log,
                                            const float* const* beta_log, const float* filt, int32_t count, int32_t batch,
-                                           int32_t len, int32_t c, int32_t ld, void* stream) {
-    if (!x || !y || !alpha_log || !beta_log || !filt || count < 1 || count > SNAKE_GROUP) return SVCMI_EINVAL;
+                                           int32_t len, int32_t c, int32_t ld, void* const* y16, int32_t y16_format, void* stream) {
+    if (!x || (!y && !y16) || !alpha_log || !beta_log || !filt || count < 1 || count > SNAKE_GROUP) return SVCMI_EINVAL;
+    if (y16 && y16_format != SVCMI_PREC_BF16 && y16_format != SVCMI_PREC_F16) return SVCMI_EINVAL;
     if (batch <= 0 || len <= 0 || c <= 0 || ld < c) return SVCMI_EINVAL;
     if (batch > 65535) return SVCMI_EUNSUPPORTED;
     SnakeArgs a;
     for (int i = 0; i < SNAKE_GROUP; ++i) {
         const int j = i < count ? i : 0;
-        if (!x[j] || !y[j] || !alpha_log[j] || !beta_log[j]) return SVCMI_EINVAL;
-        if (x[j] == y[j]) return SVCMI_EINVAL;            // halo reads: not an in-place op
-        a.x[i] = x[j]; a.y[i] = y[j]; a.alpha_log[i] = alpha_log[j]; a.beta_log[i] = beta_log[j];
+        float* yj = y ? y[j] : nullptr;
+        unsigned short* hj = y16 ? static_cast<unsigned short*>(y16[j]) : nullptr;
+        if (!x[j] || (!yj && !hj) || !alpha_log[j] || !beta_log[j]) return SVCMI_EINVAL;
+        if (x[j] == yj) return SVCMI_EINVAL;              // halo reads: not an in-place op
+        a.x[i] = x[j]; a.y[i] = yj; a.y16[i] = hj; a.alpha_log[i] = alpha_log[j]; a.beta_log[i] = beta_log[j];
     }
-    a.filt = filt; a.n = len; a.c = c; a.ld = ld;
+    a.filt = filt; a.n = len; a.c = c; a.ld = ld; a.f16 = y16_format == SVCMI_PREC_F16;
     const long long runs = ((long long)len + RT - 1) / RT;
     const long long threads = runs * c;
     SVCMI_LAUNCH(snake_alias_kernel, dim3((unsigned)((threads + TPB - 1) / TPB), batch, count), dim3(TPB), 0, stream, a);
@@ -174,7 +183,7 @@ extern "C" int svcmi_snake_alias_group_f32(const float* const* x, float* const* 
 
 extern "C" int svcmi_snake_alias_f32(const float* x, float* y, const float* alpha_log, const float* beta_log,
                                      const float* filt, int32_t batch, int32_t len, int32_t c, int32_t ld, void* stream) {
-    return svcmi_snake_alias_group_f32(&x, &y, &alpha_log, &beta_log, filt, 1, batch, len, c, ld, stream);
+    return svcmi_snake_alias_group_f32(&x, &y, &alpha_log, &beta_log, filt, 1, batch, len, c, ld, nullptr, 0, stream);
 }
 
 extern "C" int svcmi_block_mean_f32(const float* const* xs, int32_t count, float* y, int64_t n, void* stream) {

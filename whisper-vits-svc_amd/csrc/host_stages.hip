@@ -179,9 +179,10 @@ void conv(Ctx& c, const CV& v) {
     else run(c, OP_CONV_F32, flops, bytes, [&] { return svcmi_conv_gemm_f32(&d, c.stream); });
 }
 
-// up to 3 convolutions of one geometry in one launch (Ops.conv_group): no split-K; 16-bit only if every problem qualifies
-void conv_group(Ctx& c, const CV* vs, int count) {
-    if (!c.live()) return;
+// up to 3 convolutions of one geometry in one launch (Ops.conv_group): no split-K; 16-bit only if every problem qualifies, 16-bit
+// activations (x16) only if every problem can take them.  `dry`: decide the kernel only; returns its precision code.
+int conv_group(Ctx& c, const CV* vs, int count, bool dry = false) {
+    if (!c.live() && !dry) return SVCMI_PREC_F32;
     svcmi_conv_desc d[3];
     double flops[3], bytes[3], total = 0.0;
     for (int i = 0; i < count; ++i) {
@@ -194,14 +195,24 @@ void conv_group(Ctx& c, const CV* vs, int count) {
     const int tile0 = vs[0].tile_lp >= 0 ? vs[0].tile_lp : vs[0].tile;
     if (lp && !(tile0 == 0 || tile0 == 1 || tile0 == 4 || tile0 == 6)) lp = false;
     double tb = 0.0;
+    int prec = SVCMI_PREC_F32;
     if (lp) {
+        bool a16 = true;
         for (int i = 0; i < count && lp; ++i) {
             CV v = vs[i];
             v.split_k = 1;
-            CV v2 = v;
-            v2.x16 = nullptr;            // (grouped launches: fp32 activations)
-            lp = conv_desc(c, v2, d[i], flops[i], bytes[i], total) != SVCMI_PREC_F32;
+            const int pi = conv_desc(c, v, d[i], flops[i], bytes[i], total);
+            lp = pi != SVCMI_PREC_F32;
+            a16 = a16 && pi >= SVCMI_PREC_BF16_A16;
         }
+        if (lp && !a16)
+            for (int i = 0; i < count; ++i) {      // mixed: everyone rounds in registers
+                CV v = vs[i];
+                v.split_k = 1;
+                v.x16 = nullptr;
+                conv_desc(c, v, d[i], flops[i], bytes[i], total);
+            }
+        if (lp) prec = a16 ? c.prec + 2 : c.prec;
         if (!lp)
             for (int i = 0; i < count; ++i) {      // back to fp32 descriptors: a group runs on ONE kernel
                 CV v = vs[i];
@@ -212,8 +223,10 @@ void conv_group(Ctx& c, const CV* vs, int count) {
             }
     }
     for (int i = 0; i < count; ++i) tb += bytes[i];
-    if (lp) run(c, OP_CONV_GROUP_LP, total, tb, [&] { return svcmi_conv_gemm_group_lp(d, count, c.prec, c.stream); });
+    if (dry) return prec;
+    if (lp) run(c, OP_CONV_GROUP_LP, total, tb, [&] { return svcmi_conv_gemm_group_lp(d, count, prec, c.stream); });
     else run(c, OP_CONV_GROUP_F32, total, tb, [&] { return svcmi_conv_gemm_group_f32(d, count, c.stream); });
+    return prec;
 }
 
 // (y16 / o16: optional 16-bit copies of the outputs, rows of C values, in the format of the bf16 / f16 mode; nullptr = none)
@@ -539,9 +552,14 @@ bool amp_stage_grouped(Ctx& c, const svcmi_synth_model& m, const svcmi_gen_stage
     const bool fused = nf == nall;
     const int64_t n = (int64_t)B * L * cp, bs = L * cp;
     float *xj[3], *t1[3], *t2[3];
+    void* t1h[3] = {nullptr, nullptr, nullptr};
     for (int j = 0; j < nb; ++j) xj[j] = c.ar.f(n);
     for (int j = 0; j < nb; ++j) t1[j] = c.ar.f(n);
     for (int j = 0; j < nb; ++j) t2[j] = c.ar.f(n);
+    // bf16 / f16 modes, wide stages: SnakeAlias writes its output as 16-bit rows ONLY (it feeds nothing but the convolution) and
+    // the grouped GEMM takes the _A16 kernel -- a quarter less activation traffic per half-step, half the operand bytes through LDS
+    if (!fused && mode16(c.prec) && cp % 8 == 0)
+        for (int j = 0; j < nb; ++j) t1h[j] = c.ar.take(n * 2);
     const float* xc[3] = {y, y, y};
     for (int q = 0; q < nd; ++q) {
         float** outs = q == nd - 1 ? t2 : xj;
@@ -565,26 +583,36 @@ bool amp_stage_grouped(Ctx& c, const svcmi_synth_model& m, const svcmi_gen_stage
                 [&] { return svcmi_snake_conv_group_f32(d, nb, m.filt, B, (int32_t)L, st.c, cp, c.stream); });
         } else {
             const float* px[3]; float* py[3]; const float *pa[3], *pb[3];
-            for (int j = 0; j < nb; ++j) { px[j] = xc[j]; py[j] = t1[j]; pa[j] = st.blocks[j].a1_alpha[q]; pb[j] = st.blocks[j].a1_beta[q]; }
-            run(c, OP_SNAKE_ALIAS_GROUP, 0.0, 8.0 * nb * B * L * cp,
-                [&] { return svcmi_snake_alias_group_f32(px, py, pa, pb, m.filt, nb, B, (int32_t)L, cp, cp, c.stream); });
             CV vs[3];
+            // activation -> 16-bit rows when the convolution that reads them will run on the _A16 kernel (decided from the same descriptors)
+            auto snake = [&](bool second) {
+                const bool h16 = t1h[0] && conv_group(c, vs, nb, true) >= SVCMI_PREC_BF16_A16;
+                for (int j = 0; j < nb; ++j) {
+                    px[j] = second ? t2[j] : xc[j]; py[j] = t1[j];
+                    pa[j] = second ? st.blocks[j].a2_alpha[q] : st.blocks[j].a1_alpha[q];
+                    pb[j] = second ? st.blocks[j].a2_beta[q] : st.blocks[j].a1_beta[q];
+                    if (!h16) vs[j].x16 = nullptr;
+                }
+                run(c, OP_SNAKE_ALIAS_GROUP, 0.0, (h16 ? 6.0 : 8.0) * nb * B * L * cp, [&] {
+                    return svcmi_snake_alias_group_f32(px, h16 ? nullptr : py, pa, pb, m.filt, nb, B, (int32_t)L, cp, cp, h16 ? t1h : nullptr, c.prec,
+                                                       c.stream);
+                });
+            };
             for (int j = 0; j < nb; ++j) {
                 const svcmi_amp_block& b = st.blocks[j];
                 CV& v = vs[j]; v = CV();
-                v.x = t1[j]; v.x_bs = bs; v.B = B; v.t_in = (int)L; v.c_in = v.ldx = cp; v.w = &b.c1[q]; v.ksize = b.k; v.dil = b.dil[q];
+                v.x = t1[j]; v.x16 = t1h[j]; v.x_bs = bs; v.B = B; v.t_in = (int)L; v.c_in = v.ldx = cp; v.w = &b.c1[q]; v.ksize = b.k; v.dil = b.dil[q];
                 v.pad = (b.k * b.dil[q] - b.dil[q]) / 2; v.y = t2[j]; v.y_bs = bs; v.ldy = cp;
             }
+            snake(false);
             conv_group(c, vs, nb);
-            for (int j = 0; j < nb; ++j) { px[j] = t2[j]; py[j] = t1[j]; pa[j] = st.blocks[j].a2_alpha[q]; pb[j] = st.blocks[j].a2_beta[q]; }
-            run(c, OP_SNAKE_ALIAS_GROUP, 0.0, 8.0 * nb * B * L * cp,
-                [&] { return svcmi_snake_alias_group_f32(px, py, pa, pb, m.filt, nb, B, (int32_t)L, cp, cp, c.stream); });
             for (int j = 0; j < nb; ++j) {          // t2 is free again once the second activation has read it
                 const svcmi_amp_block& b = st.blocks[j];
                 CV& v = vs[j]; v = CV();
-                v.x = t1[j]; v.x_bs = bs; v.B = B; v.t_in = (int)L; v.c_in = v.ldx = cp; v.w = &b.c2[q]; v.ksize = b.k; v.pad = (b.k - 1) / 2;
+                v.x = t1[j]; v.x16 = t1h[j]; v.x_bs = bs; v.B = B; v.t_in = (int)L; v.c_in = v.ldx = cp; v.w = &b.c2[q]; v.ksize = b.k; v.pad = (b.k - 1) / 2;
                 v.res = xc[j]; v.res_bs = bs; v.ldr = cp; v.y = outs[j]; v.y_bs = bs; v.ldy = cp;
             }
+            snake(true);
             conv_group(c, vs, nb);
         }
         for (int j = 0; j < nb; ++j) xc[j] = outs[j];

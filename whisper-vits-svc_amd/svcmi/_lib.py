@@ -153,7 +153,7 @@ SIGNATURES = {
     "svcmi_snake_post_f32": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "svcmi_conv_gemm_group_f32": (c_int, [_P, _I, _P]),
     "svcmi_snake_conv_group_f32": (c_int, [_P, _I, _P, _I, _I, _I, _I, _P]),
-    "svcmi_snake_alias_group_f32": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "svcmi_snake_alias_group_f32": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P]),
     "svcmi_block_mean_f32": (c_int, [_P, _I, _P, _L, _P]),
     "svcmi_source2wav_i16": (c_int, [_P, _P, _L, _P]),
     "svcmi_whisper_workspace_bytes": (c_int64, [POINTER(WhisperModel), _I, _I]),

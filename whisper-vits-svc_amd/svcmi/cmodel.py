@@ -64,7 +64,7 @@ def synth_cmodel(w, ops, prec=PREC_F32):
     m.upsample_input, m.hop = w.U, w.hop
     m.precision, m.lp_min_flops = prec, 0.0
     m.sampling_rate, m.merge_b = float(hp.data.sampling_rate), float(w.merge_b)
-    W = lambda cw, wt, b=None: _weight(cw, ops, wt, b, prec, keep)
+    W = lambda cw, wt, b=None, a16=False: _weight(cw, ops, wt, b, prec, keep, a16=a16)
     W(m.pre, w.pre_w, w.pre_b)
     W(m.hub, w.hub_w, w.hub_b)
     W(m.proj, w.proj_w, w.proj_b)
@@ -108,8 +108,8 @@ def synth_cmodel(w, ops, prec=PREC_F32):
             b.k, b.n_dil = blk["k"], len(blk["d"])
             for q, d in enumerate(blk["d"]):
                 b.dil[q] = d
-                W(b.c1[q], blk["c1"][q][0], blk["c1"][q][1])
-                W(b.c2[q], blk["c2"][q][0], blk["c2"][q][1])
+                W(b.c1[q], blk["c1"][q][0], blk["c1"][q][1], a16=st["cp"] % 8 == 0)      # wide stages: SnakeAlias hands 16-bit rows to the GEMM
+                W(b.c2[q], blk["c2"][q][0], blk["c2"][q][1], a16=st["cp"] % 8 == 0)
                 b.a1_alpha[q], b.a1_beta[q] = blk["a1"][q][0].data_ptr(), blk["a1"][q][1].data_ptr()
                 b.a2_alpha[q], b.a2_beta[q] = blk["a2"][q][0].data_ptr(), blk["a2"][q][1].data_ptr()
     return CModel(m, keep)

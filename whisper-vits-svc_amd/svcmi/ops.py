@@ -416,8 +416,12 @@ class Ops:
         n = len(xs)
         B, L, Cc = xs[0].shape
         arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+        if outs[0].dtype != torch.float32:      # bf16 / float16 outputs: the 16-bit rows a following _A16 GEMM reads
+            self._call("svcmi_snake_alias_group_f32", arr(xs), None, arr(alpha_logs), arr(beta_logs), _ptr(filt), n,
+                       B, L, Cc, xs[0].stride(1), arr(outs), _fmt16(outs[0].dtype), self._stream(), work={"bytes": 6.0 * n * B * L * Cc})
+            return outs
         self._call("svcmi_snake_alias_group_f32", arr(xs), arr(outs), arr(alpha_logs), arr(beta_logs), _ptr(filt), n,
-                   B, L, Cc, xs[0].stride(1), self._stream(), work={"bytes": 8.0 * n * B * L * Cc})
+                   B, L, Cc, xs[0].stride(1), None, 0, self._stream(), work={"bytes": 8.0 * n * B * L * Cc})
         return outs
 
     def block_mean(self, xs, out=None):
