@@ -113,7 +113,8 @@ def units_windowed(model, audio, max_batch=8):
         j = i + 1
         while j < len(plan) and j - i < max_batch and plan[j][1] - plan[j][0] == plan[i][1] - plan[i][0]:
             j += 1
-        wav = torch.stack([torch.from_numpy(audio[s:e]) for (s, e) in plan[i:j]]).unsqueeze(1)
+        # (numpy, not torch, on the host: a torch CPU op on a many-core box wakes its whole intra-op thread pool -- milliseconds per call)
+        wav = torch.from_numpy(np.ascontiguousarray(np.stack([audio[s:e] for (s, e) in plan[i:j]])[:, None, :]))
         out.extend(model.units(wav))
         i = j
     return torch.cat(out, 0)

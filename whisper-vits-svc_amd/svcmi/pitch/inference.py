@@ -157,6 +157,14 @@ def compute_f0_sing(filename, device, model=None, noise=None, dither=None, decod
     """pitch/inference.py:74-99.  ``filename``: wav path or a 16 kHz float waveform [n]; ``model``: a ``Crepe`` (the
     reference loads crepe/assets/full.pth on first use).  ``noise`` [n] ~ N(0,1) pins the 1e-3 input noise (:77),
     ``dither`` [frames] pins convert.py:58-64.  Returns np.float32 Hz [2 * (1 + n // 320)]."""
+    return compute_f0_sing_begin(filename, device, model=model, noise=noise, decoder=decoder)(dither)
+
+
+@torch.no_grad()
+def compute_f0_sing_begin(filename, device, model=None, noise=None, decoder="viterbi"):
+    """The device half of ``compute_f0_sing``: everything up to the decoded bins is ENQUEUED on the current stream and nothing waits for
+    it; returns ``finish(dither=None) -> np.float32 Hz`` which does the device -> host copy and the host-side tail.  Lets a caller put
+    other work (the other two extractors, svc_inference.extract_features) in flight before it blocks on the F0 track."""
     if model is None:
         raise ValueError("pass model=load_crepe(<crepe full.pth>, device)")
     if isinstance(filename, str):
@@ -170,18 +178,23 @@ def compute_f0_sing(filename, device, model=None, noise=None, dither=None, decod
     nz = torch.randn_like(audio) if noise is None else torch.as_tensor(noise, dtype=torch.float32).to(model.device)
     audio = audio + nz * 0.001
     prob = model.probabilities(audio, hop=320, batch_size=512)
-    if decoder == "viterbi" and model.ops.on_gpu:      # the DP on the device (one block per 512-frame decoding batch)
+    on_device = decoder == "viterbi" and model.ops.on_gpu
+    if on_device:      # the DP on the device (one block per 512-frame decoding batch)
         lt, band = _viterbi_constants(prob.device)
         bins = model.ops.viterbi_decode(prob, lt, 512, _frequency_to_bins(50.0), _frequency_to_bins(1000.0, ceil=True), band=band)
-        pitch = bins_to_hz(bins, dither)[None].float()
-    else:
-        prob, out = prob.cpu(), []
-        for i in range(0, prob.shape[0], 512):         # crepe/core.py:683-686: decoding restarts with every batch
-            d = None if dither is None else np.asarray(dither)[i:i + 512]
-            out.append(decode(prob[i:i + 512], 50.0, 1000.0, decoder, d))
-        pitch = torch.cat(out)[None].float()
-    pitch = np.repeat(pitch.numpy(), 2, -1)                           # 320 -> 160 * 2 (:95)
-    return _mean_filter_np(pitch[0], 5)
+
+    def finish(dither=None):
+        if on_device:
+            pitch = bins_to_hz(bins, dither)[None].float()
+        else:
+            p, out = prob.cpu(), []
+            for i in range(0, p.shape[0], 512):         # crepe/core.py:683-686: decoding restarts with every batch
+                d = None if dither is None else np.asarray(dither)[i:i + 512]
+                out.append(decode(p[i:i + 512], 50.0, 1000.0, decoder, d))
+            pitch = torch.cat(out)[None].float()
+        pitch = np.repeat(pitch.numpy(), 2, -1)                           # 320 -> 160 * 2 (:95)
+        return _mean_filter_np(pitch[0], 5)
+    return finish
 
 
 _VITERBI_CONSTANTS = {}

@@ -140,6 +140,39 @@ def svc_infer(model, retrieval, spk, pit, ppg, vec, hp, device, noise=None, writ
     return out if return_tensor else out.cpu().numpy()
 
 
+@torch.no_grad()
+def extract_features(audio, whisper, hubert, crepe, device, in_flight=True):
+    """The three extractors of svc_inference.py:138-154 on ONE 16 kHz waveform (numpy float32 [n]), in process and in flight together:
+    the reference runs them as three child processes one after the other; they are independent, so here the Whisper PPG, the HuBERT
+    units and the CREPE F0 track are issued on three HIP streams (clips-in-flight idea of svcmi/lanes.py: one network's launch gaps
+    are filled by another's kernels).  Returns (ppg [T50, ppg_dim] device, vec [T50, vec_dim] device, f0 np.float32 [2 * (1 + n // 320)])
+    -- the contents of svc_tmp.ppg.npy / svc_tmp.vec.npy / svc_tmp.pit.csv (before the CSV's int() quantisation)."""
+    from .hubert import inference as hubert_inf
+    from .pitch import inference as pitch_inf
+    from .whisper import inference as whisper_inf
+    dev = torch.device(device)
+    if dev.type != "cuda" or not in_flight:
+        return (whisper_inf.ppg_from_audio(whisper, audio), hubert_inf.units_windowed(hubert, audio),
+                pitch_inf.compute_f0_sing(audio, dev, model=crepe))
+    cur = torch.cuda.current_stream(dev)
+    pool = whisper.__dict__.setdefault("_svcmi_extract_streams", {})          # per calling thread (folder driver workers)
+    side = pool.setdefault(threading.get_ident(), [])
+    while len(side) < 2:
+        side.append(torch.cuda.Stream(device=dev))
+    for s in side:
+        s.wait_stream(cur)
+    f0_finish = pitch_inf.compute_f0_sing_begin(audio, dev, model=crepe)       # the longest of the three first, on the current stream
+    with torch.cuda.stream(side[0]):
+        ppg = whisper_inf.ppg_from_audio(whisper, audio)
+    with torch.cuda.stream(side[1]):
+        vec = hubert_inf.units_windowed(hubert, audio)
+    f0 = f0_finish()                                                          # D2H copy of the decoded track + host tail
+    for s, t in zip(side, (ppg, vec)):
+        cur.wait_stream(s)
+        t.record_stream(cur)
+    return ppg, vec, f0
+
+
 # ------------------------------------------------------------------------------------------------ CLI (svc_inference.py:137-239)
 class _Hp(dict):
     """Attribute-style view of the YAML config, like the OmegaConf object the reference passes around
@@ -182,6 +215,19 @@ def main(args):
     from .vits.models import SynthesizerInfer
     from .whisper import inference as whisper_inf
     device = "cuda"
+    f0_prec = None if getattr(args, "f0_precision", "bf16x3") == "f32" else getattr(args, "f0_precision", "bf16x3")
+    if args.ppg is None and args.vec is None and args.pit is None:
+        # all three features from the wav: the extractors run in flight together (extract_features); the intermediate files keep
+        # their names and formats
+        from .whisper.audio import load_audio
+        crepe = pitch_inf.load_crepe(args.crepe, device)
+        crepe.precision = f0_prec
+        ppg_d, vec_d, f0 = extract_features(load_audio(args.wave), whisper_inf.load_model(args.whisper, device),
+                                            hubert_inf.load_model(args.hubert, device), crepe, device)
+        args.ppg, args.vec, args.pit = "svc_tmp.ppg.npy", "svc_tmp.vec.npy", "svc_tmp.pit.csv"
+        np.save(args.ppg, ppg_d.cpu().numpy(), allow_pickle=False)
+        np.save(args.vec, vec_d.cpu().numpy(), allow_pickle=False)
+        pitch_inf.save_csv_pitch(f0, args.pit)
     if args.ppg is None:
         args.ppg = "svc_tmp.ppg.npy"
         whisper_inf.pred_ppg(whisper_inf.load_model(args.whisper, device), args.wave, args.ppg, device)
@@ -190,7 +236,9 @@ def main(args):
         hubert_inf.pred_vec(hubert_inf.load_model(args.hubert, device), args.wave, args.vec, device)
     if args.pit is None:
         args.pit = "svc_tmp.pit.csv"
-        pitch_inf.save_csv_pitch(pitch_inf.compute_f0_sing(args.wave, device, model=pitch_inf.load_crepe(args.crepe, device)), args.pit)
+        crepe = pitch_inf.load_crepe(args.crepe, device)
+        crepe.precision = f0_prec
+        pitch_inf.save_csv_pitch(pitch_inf.compute_f0_sing(args.wave, device, model=crepe), args.pit)
     hp = load_config(args.config)
     model = SynthesizerInfer(hp.data.filter_length // 2 + 1, hp.data.segment_size // hp.data.hop_length, hp)
     load_svc_model(args.model, model)
@@ -231,6 +279,9 @@ def build_parser():
     p.add_argument("--hubert", type=str, default=os.path.join("hubert_pretrain", "hubert-soft-0d54a1f4.pt"))
     p.add_argument("--crepe", type=str, default=os.path.join("crepe", "assets", "full.pth"))
     p.add_argument("--debug", action="store_true")
+    p.add_argument("--f0-precision", default="bf16x3", choices=["f32", "bf16x3"],
+                   help="GEMM operand precision of the CREPE F0 extractor: bf16x3 = split-bf16 operands, fp32 accumulate (posteriors within 1e-5 "
+                        "of fp32, decoded track identical on the golden clip: tests/test_gpu_engine.py), 2x faster; f32 = exact-fp32 matrix cores")
     return p
 
 

@@ -50,6 +50,7 @@ class Converter:
         self.whisper = whisper_inf.load_model({"dims": dims[0], "model_state_dict": bc(wck["model_state_dict"] if rank == 0 else None)}, device)
         self.hubert = hubert_inf.load_model(bc(_load_on_rank0(args.hubert, rank)), device)
         self.crepe = pitch_inf.load_crepe(bc(_load_on_rank0(args.crepe, rank)), device)
+        self.crepe.precision = None if getattr(args, "f0_precision", "bf16x3") == "f32" else getattr(args, "f0_precision", "bf16x3")
         ck = _load_on_rank0(args.model, rank)
         self.model = SynthesizerInfer(self.hp.data.filter_length // 2 + 1, self.hp.data.segment_size // self.hp.data.hop_length, self.hp)
         want = self.model.state_dict()
@@ -76,17 +77,14 @@ class Converter:
         from .pitch import inference as pitch_inf
         from .svc_inference import DummyRetrieval, shift_pitch, svc_infer
         from .whisper import inference as whisper_inf
-        tmp = f"{self.tmp}.{threading.get_ident()}"          # one set of intermediates per worker thread
-        ppg_p, vec_p = tmp + ".ppg.npy", tmp + ".vec.npy"
-        whisper_inf.pred_ppg(self.whisper, wav_path, ppg_p, self.device)
-        hubert_inf.pred_vec(self.hubert, wav_path, vec_p, self.device)
-        pit = pitch_inf.compute_f0_sing(wav_path, self.device, model=self.crepe)
-        ppg = torch.FloatTensor(np.repeat(np.load(ppg_p), 2, 0))
-        vec = torch.FloatTensor(np.repeat(np.load(vec_p), 2, 0))
-        # the reference hands F0 to the synthesizer through the pitch CSV (svc_inference.py:150-154,183): int() per frame
+        from .svc_inference import extract_features
+        from .whisper.audio import load_audio
+        # the three extractors in flight together, features kept on the device (the reference's per-file .npy / .csv intermediates
+        # carry the same values: float32 arrays and the int()-quantised F0 of the pitch CSV, svc_inference.py:150-154,183)
+        ppg, vec, pit = extract_features(load_audio(wav_path), self.whisper, self.hubert, self.crepe, self.device)
+        ppg = torch.repeat_interleave(ppg, 2, 0)              # np.repeat(ppg, 2, 0), svc_inference.py:175-182
+        vec = torch.repeat_interleave(vec, 2, 0)
         pit = torch.FloatTensor(shift_pitch(pitch_inf.quantize_pitch_like_csv(pit), self.args.shift))
-        os.remove(ppg_p)
-        os.remove(vec_p)
         return svc_infer(self.model, DummyRetrieval(), self.spk, pit, ppg, vec, self.hp, self.device, write_pit_wav=False)
 
 
@@ -158,6 +156,7 @@ def build_parser():
     p.add_argument("--whisper", type=str, default=os.path.join("whisper_pretrain", "large-v2.pt"))
     p.add_argument("--hubert", type=str, default=os.path.join("hubert_pretrain", "hubert-soft-0d54a1f4.pt"))
     p.add_argument("--crepe", type=str, default=os.path.join("crepe", "assets", "full.pth"))
+    p.add_argument("--f0-precision", default="bf16x3", choices=["f32", "bf16x3"], help="GEMM operand precision of the CREPE F0 extractor (see svc_inference)")
     p.add_argument("--workers", type=int, default=3,
                    help="files in flight per GPU: worker threads, each converting its files on its own HIP stream (1 = the reference's order)")
     return p

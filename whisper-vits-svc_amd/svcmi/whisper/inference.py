@@ -120,12 +120,18 @@ def window_plan(n_samples, sr=16000, window_s=K.WHISPER_WINDOW_S):
     return plan
 
 
+@torch.no_grad()
+def ppg_from_audio(whisper, wav):
+    """whisper/inference.py:32-62 on a 16 kHz float waveform (numpy [n]): log-mel front-end on the GPU, 15 s windows, encoder, kept
+    frames -> device tensor [T50, n_state].  Nothing here waits for the device."""
+    from . import audio
+    plan = window_plan(wav.shape[0])
+    mels = [audio.log_mel_spectrogram(torch.from_numpy(wav[s:e]), ops=whisper.ops, device=whisper.device) for (s, e, _) in plan]
+    return pred_ppg_from_mel(whisper, mels, [k for (_, _, k) in plan])
+
+
 def pred_ppg(whisper, wavPath, ppgPath, device):
     """whisper/inference.py:32-62 with the 16 kHz loader + GPU log-mel front-end of svcmi.whisper.audio (row N2 of
     SURVEY.md 8f); writes the same float32 [T50, 1280] .npy."""
     from . import audio
-    wav = audio.load_audio(wavPath)
-    plan = window_plan(wav.shape[0])
-    mels = [audio.log_mel_spectrogram(torch.from_numpy(wav[s:e]), ops=whisper.ops, device=whisper.device) for (s, e, _) in plan]
-    ppg = pred_ppg_from_mel(whisper, mels, [k for (_, _, k) in plan])
-    np.save(ppgPath, ppg.cpu().numpy(), allow_pickle=False)
+    np.save(ppgPath, ppg_from_audio(whisper, audio.load_audio(wavPath)).cpu().numpy(), allow_pickle=False)
