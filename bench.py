@@ -277,6 +277,25 @@ def roofline_pass(wl, fn):
     return ops.trace_end()
 
 
+def measured_precision_error(config, wprec, sprec):
+    """Waveform max-abs error of a reduced-precision mode against the fp32 oracle, from the newest committed report of
+    tests/test_gpu_precision.py (profiles/r*_precision_report.json).  The north_star tolerance is 1e-3; bf16 (what BASELINE.json names for
+    configs[2]) is outside it, bf16x3 and f16 are inside -- the line says which it is instead of leaving it implicit."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_precision_report.json")))
+    mode = sprec if sprec not in (None, "f32") else wprec
+    if not files or mode in (None, "f32"):
+        return None
+    try:
+        rep = json.load(open(files[-1]))
+        key = {1: "configs1_", 2: "configs2_", 3: "configs1_", 4: "configs1_"}[config] + mode
+        e = rep[key]
+        err = e.get("wave_max_abs_err", e.get("item0_vs_oracle"))
+        return {"mode": mode, "waveform_max_abs_err_vs_fp32_oracle": err, "within_1e-3": bool(err <= 1e-3),
+                "measured_on": key.split("_")[0], "source": os.path.relpath(files[-1], ROOT)}
+    except Exception:       # noqa: BLE001
+        return None
+
+
 def measured_traffic(kernel="conv_gemm_kernel"):
     """HBM bytes per launch of the dominant kernel from the newest committed PMC summary (profiles/r*_traffic.json,
     made by scripts/pmc_traffic.sh + scripts/traffic_summary.py: rocprofv3 cannot be driven from inside this
@@ -518,6 +537,9 @@ def main():
     }
     if single is not None:
         out["config"]["single_stream"] = single
+    perr = measured_precision_error(args.config, wprec, sprec)
+    if perr is not None:
+        out["config"]["precision_error"] = perr
     if rank == 0 and not args.no_roofline:
         fn = wl.one_batch if args.config == 3 else wl.step
         agg = roofline_pass(wl, fn)

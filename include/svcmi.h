@@ -550,6 +550,15 @@ int svcmi_trace_begin(int32_t max_records);
 int svcmi_trace_end(svcmi_trace_record* out, int32_t cap);
 const char* svcmi_trace_op_name(int32_t op);
 
+/* Packed-model files: a whole model for a host without Python.  `python -m svcmi.tools pack --config cfg.yaml --model sovits5.0.pth
+ * --out synth.svcmi` (or --whisper large-v2.pt) writes header + relocation table + the model struct with every pointer stored as
+ * (byte offset into the arena + 1; 0 = NULL) + the flat fp32 weight arena in the packed layouts.  The host reads / mmaps the file,
+ * asks svcmi_packed_model_info where the arena lies (kind: 1 = svcmi_synth_model, 2 = svcmi_whisper_model), uploads those
+ * arena_bytes to device memory (256-byte aligned) and calls svcmi_packed_model_bind, which fills `model_out` (model_bytes = sizeof of the
+ * struct of that kind) with device pointers.  examples/stage_host.cpp does exactly this and runs svcmi_synth_infer_fwd. */
+int svcmi_packed_model_info(const void* file, int64_t file_bytes, int32_t* kind, int64_t* arena_offset, int64_t* arena_bytes);
+int svcmi_packed_model_bind(const void* file, int64_t file_bytes, const void* device_arena, void* model_out, int64_t model_bytes);
+
 /* Layout check for FFI bindings: out[i] = sizeof of svcmi_weight, svcmi_whisper_model, svcmi_synth_model, svcmi_synth_io,
  * svcmi_trace_record, svcmi_conv_desc, svcmi_snake_conv_desc (in this order, up to `cap`); returns the count written.  A binding
  * compares them with its own struct sizes before it trusts a filled struct (svcmi/_lib.py does at load). */

@@ -50,7 +50,20 @@ def build_hip(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    build_example(hipcc, verbose)
     return OUT
+
+
+def build_example(hipcc, verbose=False):
+    """examples/stage_host: the C++ host without Python (packed model -> svcmi_synth_infer_fwd), linked against the in-tree library."""
+    src = os.path.join(HERE, "examples", "stage_host.cpp")
+    exe = os.path.join(HERE, "examples", "stage_host")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", src, "-o", exe, "-L", os.path.dirname(OUT), "-lsvcmi",
+           "-Wl,-rpath,$ORIGIN/../svcmi"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return exe
 
 
 if __name__ == "__main__":

@@ -888,3 +888,56 @@ extern "C" int svcmi_host_tune_set(const char* name, int32_t value) {
     if (strcmp(name, "amp_grouped") == 0 && (value == 0 || value == 1)) { g_amp_grouped = value; return 0; }
     return SVCMI_EINVAL;
 }
+
+// ------------------------------------------------------------------------------------------------ packed-model files
+// A model for a host that has no Python: `python -m svcmi.tools pack` (svcmi/packed.py) writes ONE file = header + relocation table +
+// the model struct with every pointer replaced by (byte offset into the arena + 1, 0 = NULL) + the flat weight arena (fp32, packed
+// layouts, 256-byte aligned tensors).  The host reads the file, uploads the arena bytes to the device and calls
+// svcmi_packed_model_bind, which copies the struct image and turns the offsets into device pointers.  Nothing else to parse.
+namespace {
+struct PackedHeader {
+    char magic[8];              // "SVCMIPK1"
+    uint32_t kind, abi;         // 1 = svcmi_synth_model, 2 = svcmi_whisper_model; SVCMI_ABI_VERSION of the writer
+    uint64_t struct_bytes, n_reloc, arena_offset, arena_bytes;
+};
+const PackedHeader* packed_header(const void* file, int64_t file_bytes) {
+    if (!file || file_bytes < (int64_t)sizeof(PackedHeader)) return nullptr;
+    const PackedHeader* h = static_cast<const PackedHeader*>(file);
+    if (memcmp(h->magic, "SVCMIPK1", 8) != 0 || h->abi != SVCMI_ABI_VERSION) return nullptr;
+    const uint64_t want = h->kind == 1 ? sizeof(svcmi_synth_model) : (h->kind == 2 ? sizeof(svcmi_whisper_model) : 0);
+    if (!want || h->struct_bytes != want) return nullptr;
+    if (sizeof(PackedHeader) + 8 * h->n_reloc + h->struct_bytes > h->arena_offset || h->arena_offset + h->arena_bytes > (uint64_t)file_bytes) return nullptr;
+    return h;
+}
+}  // namespace
+
+extern "C" int svcmi_packed_model_info(const void* file, int64_t file_bytes, int32_t* kind, int64_t* arena_offset, int64_t* arena_bytes) {
+    const PackedHeader* h = packed_header(file, file_bytes);
+    if (!h) return SVCMI_EINVAL;
+    if (kind) *kind = (int32_t)h->kind;
+    if (arena_offset) *arena_offset = (int64_t)h->arena_offset;
+    if (arena_bytes) *arena_bytes = (int64_t)h->arena_bytes;
+    return 0;
+}
+
+extern "C" int svcmi_packed_model_bind(const void* file, int64_t file_bytes, const void* device_arena, void* model_out, int64_t model_bytes) {
+    const PackedHeader* h = packed_header(file, file_bytes);
+    if (!h || !device_arena || !model_out || (uint64_t)model_bytes != h->struct_bytes || ((uintptr_t)device_arena & 255)) return SVCMI_EINVAL;
+    const char* p = static_cast<const char*>(file) + sizeof(PackedHeader);
+    const uint64_t* reloc = reinterpret_cast<const uint64_t*>(p);
+    const char* image = p + 8 * h->n_reloc;
+    char* out = static_cast<char*>(model_out);
+    memcpy(out, image, h->struct_bytes);
+    for (uint64_t i = 0; i < h->n_reloc; ++i) {
+        if (reloc[i] + sizeof(void*) > h->struct_bytes) return SVCMI_EINVAL;
+        uint64_t v;
+        memcpy(&v, out + reloc[i], 8);
+        const void* ptr = nullptr;
+        if (v) {
+            if (v - 1 >= h->arena_bytes) return SVCMI_EINVAL;
+            ptr = static_cast<const char*>(device_arena) + (v - 1);
+        }
+        memcpy(out + reloc[i], &ptr, sizeof(void*));
+    }
+    return 0;
+}

@@ -169,6 +169,8 @@ SIGNATURES = {
     "svcmi_trace_end": (c_int, [POINTER(TraceRecord), _I]),
     "svcmi_trace_op_name": (c_char_p, [_I]),
     "svcmi_struct_sizes": (c_int, [POINTER(c_int64), _I]),
+    "svcmi_packed_model_info": (c_int, [_P, _L, POINTER(c_int32), POINTER(c_int64), POINTER(c_int64)]),
+    "svcmi_packed_model_bind": (c_int, [_P, _L, _P, _P, _L]),
 }
 
 

@@ -92,7 +92,28 @@ def _main_merge(argv=None):
     save_model_g(merge_model(load_model_g(a.model1), load_model_g(a.model2), a.rate), "sovits5.0_merge.pth")
 
 
+def _main_pack(argv=None):
+    """Kernel-ready weights of one model as a packed-model file for hosts without Python (svcmi/packed.py, include/svcmi.h)."""
+    import argparse
+    from . import packed, weights as PW
+    from .svc_inference import load_config
+    p = argparse.ArgumentParser(description="pack a checkpoint into a .svcmi file (svcmi_packed_model_bind)")
+    p.add_argument("--config", type=str, help="yaml config of the synthesizer (with --model)")
+    p.add_argument("--model", type=str, help="sovits5.0.pth: {'model_g': SynthesizerInfer.state_dict()}")
+    p.add_argument("--whisper", type=str, help="OpenAI Whisper checkpoint {'dims', 'model_state_dict'}")
+    p.add_argument("--out", type=str, required=True)
+    a = p.parse_args(argv)
+    if bool(a.model) == bool(a.whisper) or (a.model and not a.config):
+        p.error("give either --config + --model or --whisper")
+    if a.model:
+        w = PW.VitsWeights(load_model_g(a.model), load_config(a.config), "cpu")
+    else:
+        w = PW.WhisperWeights(torch.load(a.whisper, map_location="cpu"), "cpu")
+    with open(a.out, "wb") as f:
+        f.write(packed.pack_model(w))
+
+
 if __name__ == "__main__":
     import sys
     cmd, rest = (sys.argv[1], sys.argv[2:]) if len(sys.argv) > 1 else ("", [])
-    {"export": _main_export, "merge": _main_merge}.get(cmd, lambda _: sys.exit("usage: python -m svcmi.tools export|merge ..."))(rest)
+    {"export": _main_export, "merge": _main_merge, "pack": _main_pack}.get(cmd, lambda _: sys.exit("usage: python -m svcmi.tools export|merge|pack ..."))(rest)
