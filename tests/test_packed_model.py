@@ -60,3 +60,25 @@ def test_packed_synthesizer_runs_like_the_facade(ops):
     assert torch.equal(src2.view(-1), src.view(-1))
     got = ops.synth_infer_fwd(cm, d["ppg"], d["vec"], d["pit"], d["spk"], d["lengths"].to(torch.int32), src2, d["enc_noise"])
     assert torch.equal(got, want)
+
+
+def test_per_stage_entry_points_compose_to_the_whole(ops):
+    """svcmi_text_encoder_fwd -> svcmi_flow_reverse_fwd -> svcmi_generator_fwd == svcmi_synth_infer_fwd, and the intermediate tensors are
+    the ones `return_parts` hands out."""
+    hp = C.tiny_hp()
+    m, _ = E.make_model(hp, ops, "cpu")
+    d = I.synth_clip(T=5, hp=hp, seed=4, B=2)
+    lens = d["lengths"].clone()
+    lens[-1] = 3
+    src = m.pitch2source(d["pit"], noise=(d["rand_ini"], d["src_noise"]))
+    want, parts = m.inference(d["ppg"], d["vec"], d["pit"], d["spk"], lens, src, noise=d["enc_noise"], return_parts=True)
+    wave, z_p, z = ops.synth_stages_fwd(m._cmodel(), d["ppg"], d["vec"], d["pit"], d["spk"], lens.to(torch.int32), src.view(2, -1), d["enc_noise"])
+    assert torch.equal(wave, want)
+    assert torch.equal(z_p.transpose(1, 2), parts["z_p"]) and torch.equal(z.transpose(1, 2), parts["z"])
+    # a workspace smaller than svcmi_synth_workspace_bytes says is refused before anything is launched
+    cm = m._cmodel()
+    io = _lib.SynthIO()
+    io.batch, io.t = 2, 5
+    small = torch.empty(4096, dtype=torch.uint8)
+    base = (small.data_ptr() + 255) & ~255
+    assert ops.lib.svcmi_flow_reverse_fwd(ctypes.byref(cm.struct), ctypes.byref(io), z.data_ptr(), base, 1024, 0) == -1

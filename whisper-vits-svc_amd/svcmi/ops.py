@@ -221,6 +221,30 @@ class Ops:
         self._stage_call("svcmi_synth_infer_fwd", ctypes.byref(m), ctypes.byref(io), ws, ws_bytes, self._stream())
         return (wave, parts) if want_parts else wave
 
+    def synth_stages_fwd(self, cm, ppg, vec, pit, spk, lengths, source, noise, *, ppg_row_shift=0, stream_frames=0):
+        """The same forward pass as ``synth_infer_fwd`` through the three per-stage entry points (svcmi_text_encoder_fwd ->
+        svcmi_flow_reverse_fwd -> svcmi_generator_fwd), for callers that want the intermediate tensors.  Returns (wave, z_p, z);
+        z_p / z time-major [B, T, inter]."""
+        self._chk(ppg, vec, pit, spk, lengths, source, noise)
+        m = cm.struct
+        m.lp_min_flops = max(float(self.lp_min_flops), 1e-30)
+        B, T = pit.shape
+        need = self.lib.svcmi_synth_workspace_bytes(ctypes.byref(m), B, T, int(stream_frames))
+        if need < 0:
+            raise SvcmiError(f"svcmi_synth_workspace_bytes failed with code {need}")
+        ws, ws_bytes = self.stage_workspace(need, pit.device)
+        io = SynthIO()
+        io.ppg, io.vec, io.pit, io.spk, io.lengths, io.source, io.noise = (_ptr(t_) for t_ in (ppg, vec, pit, spk, lengths, source, noise))
+        io.ppg_bstride, io.ppg_row_shift, io.batch, io.t, io.stream_frames = ppg.stride(0), ppg_row_shift, B, T, int(stream_frames)
+        wave = torch.empty(B, 1, T * m.hop, dtype=torch.float32, device=pit.device)
+        io.wave = _ptr(wave)
+        z_p = torch.empty(B, T, m.inter, dtype=torch.float32, device=pit.device)
+        self._stage_call("svcmi_text_encoder_fwd", ctypes.byref(m), ctypes.byref(io), _ptr(z_p), ws, ws_bytes, self._stream())
+        z = z_p.clone()
+        self._stage_call("svcmi_flow_reverse_fwd", ctypes.byref(m), ctypes.byref(io), _ptr(z), ws, ws_bytes, self._stream())
+        self._stage_call("svcmi_generator_fwd", ctypes.byref(m), ctypes.byref(io), _ptr(z), ws, ws_bytes, self._stream())
+        return wave, z_p, z
+
     def trace_begin(self, max_records=8192):
         """Per-launch timing of everything launched from here on (stage entry points: HIP events inside the C host; single-op calls of
         this class: torch events): bench.py's roofline leg."""
