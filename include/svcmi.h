@@ -261,6 +261,8 @@ int svcmi_snake_post_f32(const float* x, const float* w, float* y, const float* 
 
 /* Development knobs for the tuning scripts (kernel SHAPE choices only: results never depend on them beyond fp32 re-association):
  *   "amp_tt"   {0 = default, 1, 2, 4}   time steps per thread of svcmi_snake_conv_f32
+ *   "amp_u"    {0 = measured choice, -1 = never, 1 = wherever it exists}  grouped fused narrow-stage kernel with the up-sampled activation tile in LDS
+ *   "amp_grouped" {1 = default, 0}      0 forces the one-launch-per-AMP-block fallback of the generator stages (stage host)
  *   "group_nst" {0 = default, 2, 3}     LDS ring depth of the grouped implicit-GEMM launches
  *   "attn_ns"  {0 = heuristic, 1, 2, 4, 8}  key-split waves per block of svcmi_attention_f32
  *   "attn_q32" {-1 = heuristic, 0, 1}   two query tiles per wave (band-free attention, head_dim <= 64)

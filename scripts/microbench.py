@@ -159,6 +159,16 @@ def main():
                     assert ops.lib.svcmi_tune_set(b"amp_tt", tt) == 0
                     us = timeit(lambda: ops.snake_conv_group(probs, filt, c=C))
                     print(f"ampgroup C={C} n={n} d={d} tt={tt}: {us:8.1f} us  {fl / us / 1e6:6.1f} TF/s", flush=True)
+                ops.lib.svcmi_tune_set(b"amp_tt", 0)
+                assert ops.lib.svcmi_tune_set(b"amp_u", 1) == 0      # up-sampled activation tile in LDS (default tile of the width)
+                for B in (1, 4):
+                    pb = [dict(pr, x=pr["x"].expand(B, -1, -1).contiguous(), res=pr["res"].expand(B, -1, -1).contiguous(),
+                               out=torch.empty(B, n, ld, device="cuda")) for pr in probs]
+                    for u in (-1, 1):
+                        ops.lib.svcmi_tune_set(b"amp_u", u)
+                        us = timeit(lambda: ops.snake_conv_group(pb, filt, c=C))
+                        print(f"ampgroup C={C} n={n} d={d} B={B} amp_u={u}: {us:8.1f} us  {B * fl / us / 1e6:6.1f} TF/s", flush=True)
+                ops.lib.svcmi_tune_set(b"amp_u", 0)
         ops.lib.svcmi_tune_set(b"amp_tt", 0)
     if "small" in what:       # the short-K / few-tile GEMMs of the prior encoder, flow and widest decoder stage
         sp = (1, 0, 2, 3, 4)

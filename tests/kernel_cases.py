@@ -600,12 +600,17 @@ def check_snake_conv_group(ops, device, c=20, ld=20, B=2, n=300):
                   res=res.to(device), alpha=0.5)
         want.append(ops.snake_conv(pr["x"], pr["alpha_log"], pr["beta_log"], filt, w, bias, c=c, ksize=k, dilation=d, res=pr["res"], alpha=0.5))
         probs.append(dict(pr, out=torch.full((B, n, ld), 7.0).to(device)))
-    for n_prob in (1, 2, 3):
-        for pr in probs:
-            pr["out"].fill_(7.0)
-        got = ops.snake_conv_group(probs[:n_prob], filt, c=c)
-        for j in range(n_prob):
-            assert torch.equal(got[j], want[j]), (n_prob, j, float((got[j] - want[j]).abs().max()))
+    for amp_u in ((-1, 1) if c <= 20 else (0,)):     # 1: the variant that keeps the up-sampled activation tile in LDS (snake_tile_u), -1: never; same bits
+        assert ops.lib.svcmi_tune_set(b"amp_u", amp_u) == 0
+        try:
+            for n_prob in (1, 2, 3):
+                for pr in probs:
+                    pr["out"].fill_(7.0)
+                got = ops.snake_conv_group(probs[:n_prob], filt, c=c)
+                for j in range(n_prob):
+                    assert torch.equal(got[j], want[j]), (amp_u, n_prob, j, float((got[j] - want[j]).abs().max()))
+        finally:
+            ops.lib.svcmi_tune_set(b"amp_u", 0)
 
 
 def check_snake_post(ops, device, B=2, n=700):

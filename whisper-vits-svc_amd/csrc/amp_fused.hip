@@ -75,6 +75,89 @@ __device__ __forceinline__ void snake_tile(float* S, const float* xb, const floa
         }
 }
 
+// The same tile with every up-sampled SnakeBeta value computed ONCE (round 3): step 1 fills U[m][ch] = the pair (s_up[2(t_lo + m) - 5],
+// s_up[.. + 1]) for all rows + 5 pairs of the tile (work items = channel x run of RT pairs, 13 x loads per 8 pairs instead of 18 per 8
+// outputs); step 2 runs the 12-tap decimating FIR from LDS (13 ds_read_b64 per 8 outputs), keeps its outputs in registers across a
+// barrier and writes S over the SAME memory -- 20 + 9 instead of 42 VALU instructions per output for ~2.2x the LDS footprint of S alone.
+// Bit-identical to snake_tile (same operation sequence per value).  LU = pair-row stride in floats (even; 8 * LU mod 64 spread).
+template <int CP>
+struct UTile {
+    static constexpr int LU = 2 * CP + 2;
+};
+
+template <int CP, int CR, int LS, int MAXI>
+__device__ __forceinline__ void snake_tile_u(float* smem, const float* xb, const float* alpha_log, const float* beta_log,
+                                             const float* filt, int n, int ld, int t_blk, int halo, int rows, int tid) {
+    constexpr int LU = UTile<CP>::LU;
+    float f[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) f[k] = filt[k];
+    const int t_lo = t_blk - halo;                    // time of S row 0
+    const int pairs = rows + 5;                       // pair m <-> up-sampled indices 2 * (t_lo + m) - 5 (+ 1)
+    const int mruns = (pairs + RT - 1) / RT;
+    for (int item = tid; item < mruns * CP; item += TPB) {
+        const int ch = item % CP, run = item / CP;
+        if (ch >= CR) continue;                       // (pad channels: S is written as zero below, U never read)
+        const int m0 = run * RT, tq0 = t_lo + m0;
+        svcmi_f32x2 s2[RT];
+        // pairs whose every up-sampled index lies outside the sequence are only read for outputs that are zeroed: skip the arithmetic
+        if (2 * tq0 - 5 + 2 * RT - 1 < -12 || 2 * tq0 - 5 > 2 * n - 1 + 12) {
+#pragma unroll
+            for (int m = 0; m < RT; ++m) s2[m] = svcmi_splat2(0.f);
+        } else {
+            const float a = expf(alpha_log[ch]);
+            const float inv_b = 1.0f / (expf(beta_log[ch]) + 1e-9f);
+            const float* xc = xb + ch;
+            float xw[RT + 5];
+#pragma unroll
+            for (int i = 0; i < RT + 5; ++i) xw[i] = xc[(long long)clampi(tq0 - 5 + i, 0, n - 1) * ld];
+            snake_pairs<RT>(xw, f, a, inv_b, xc, ld, n, tq0, s2);
+        }
+#pragma unroll
+        for (int m = 0; m < RT; ++m)
+            if (m0 + m < pairs) *reinterpret_cast<float2*>(smem + (m0 + m) * LU + 2 * ch) = make_float2(s2[m][0], s2[m][1]);
+    }
+    __syncthreads();
+    const int runs = (rows + RT - 1) / RT;
+    float outs[MAXI][RT];                             // MAXI work items per thread: runs * CP <= MAXI * TPB
+#pragma unroll
+    for (int q = 0; q < MAXI; ++q) {
+        const int item = tid + q * TPB;
+        if (item < runs * CP) {
+            const int ch = item % CP, run = item / CP, r0 = run * RT, t0 = t_lo + r0;
+            if (ch >= CR || t0 + RT <= 0 || t0 >= n) {
+#pragma unroll
+                for (int r = 0; r < RT; ++r) outs[q][r] = 0.f;
+            } else {
+                svcmi_f32x2 P[RT + 5];
+#pragma unroll
+                for (int i = 0; i < RT + 5; ++i) {
+                    const int m = r0 + i < pairs ? r0 + i : pairs - 1;
+                    const float2 v = *reinterpret_cast<const float2*>(smem + m * LU + 2 * ch);
+                    P[i] = svcmi_f32x2{v.x, v.y};
+                }
+                snake_fir<RT>(P, f, outs[q]);
+#pragma unroll
+                for (int r = 0; r < RT; ++r) {
+                    const int t = t0 + r;
+                    if (t < 0 || t >= n) outs[q][r] = 0.f;      // the convolution's zero padding
+                }
+            }
+        }
+    }
+    __syncthreads();                                   // every read of U is done: S goes over the same memory
+#pragma unroll
+    for (int q = 0; q < MAXI; ++q) {
+        const int item = tid + q * TPB;
+        if (item < runs * CP) {
+            const int ch = item % CP, r0 = (item / CP) * RT;
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+                if (r0 + r < rows) smem[(r0 + r) * LS + ch] = outs[q][r];
+        }
+    }
+}
+
 // CP = padded channels (row length of x / y / res and of a weight tap), CR = real channels, KS = taps, G = channel
 // groups, TT = time steps per thread in the convolution (accumulators: TT x CO).  Small TT = small tiles = many
 // blocks: the activation phase is a long dependent chain per work item and needs >= 4 waves per SIMD to hide.
@@ -88,7 +171,7 @@ struct AmpTile {
 
 // KS_T = 0: taps from p.ks at run time (the grouped launch: one code path for 3 / 7 / 11 taps; three inlined
 // specialisations in one kernel cost 250 VGPRs).
-template <int CP, int CR, int KS_T, int G, int TT>
+template <int CP, int CR, int KS_T, int G, int TT, bool UT = false>
 __device__ __forceinline__ void snake_conv_body(const AmpArgs& p, float* S) {
     using TL = AmpTile<CP, G, TT, KS_T ? KS_T : 11>;
     const int KS = KS_T ? KS_T : p.ks;
@@ -104,7 +187,8 @@ __device__ __forceinline__ void snake_conv_body(const AmpArgs& p, float* S) {
     const int rows = TB + 2 * halo;                   // S rows used: S row r <-> time t_blk - halo + r
     const float* xb = p.x + (long long)b * n * ld;
 
-    snake_tile<CP, CR, LS>(S, xb, p.alpha_log, p.beta_log, p.filt, n, ld, t_blk, halo, rows, tid);
+    if constexpr (UT) snake_tile_u<CP, CR, LS, (((TL::ROWS + RT - 1) / RT) * CP + TPB - 1) / TPB>(S, xb, p.alpha_log, p.beta_log, p.filt, n, ld, t_blk, halo, rows, tid);
+    else snake_tile<CP, CR, LS>(S, xb, p.alpha_log, p.beta_log, p.filt, n, ld, t_blk, halo, rows, tid);
     __syncthreads();
 
     // ---- phase B: direct convolution from LDS with SGPR weights
@@ -190,6 +274,16 @@ __global__ __launch_bounds__(TPB) void snake_conv_group_kernel(AmpGroupArgs g) {
     using TL = AmpTile<CP, G, TT, 11>;
     __shared__ __attribute__((aligned(16))) float S[TL::ROWS * TL::LS];
     snake_conv_body<CP, CR, 0, G, TT>(g.p[blockIdx.z], S);
+}
+
+// the same with the up-sampled activation of the tile held in LDS (snake_tile_u): larger LDS allocation, fewer VALU instructions
+template <int CP, int CR, int G, int TT>
+__global__ __launch_bounds__(TPB) void snake_conv_group_u_kernel(AmpGroupArgs g) {
+    using TL = AmpTile<CP, G, TT, 11>;
+    constexpr int NU = (TL::ROWS + 5) * UTile<CP>::LU, NS = TL::ROWS * TL::LS;
+    static_assert(((TL::ROWS + RT - 1) / RT) * CP <= 4 * TPB, "snake_tile_u keeps at most 4 work items per thread in registers");
+    __shared__ __attribute__((aligned(16))) float S[NU > NS ? NU : NS];
+    snake_conv_body<CP, CR, 0, G, TT, true>(g.p[blockIdx.z], S);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -350,8 +444,29 @@ extern "C" int svcmi_snake_conv_f32(const float* x, const float* w, const float*
     return tt == 1 ? launch_amp<40, 40, 4, 1>(a, batch, ksize, stream) : tt == 2 ? launch_amp<40, 40, 4, 2>(a, batch, ksize, stream) : launch_amp<40, 40, 4, 4>(a, batch, ksize, stream);
 }
 
+// tuning knob ("amp_u", -1 | 0 | 1): the grouped fused kernel with the up-sampled activation tile in LDS (snake_tile_u).  0 = measured
+// choice (profiles/r03i_ampgroup_u.log, MI355X): at 10 channels it wins (65.2 -> 62.6 us per grouped launch, B = 4: 250 -> 234 us), at
+// 20 channels the 52 KB of LDS per block cost more occupancy than the saved instructions buy (84 -> 92.5 us); -1 = never, 1 = wherever it exists
+int g_amp_u = 0;
+
 template <int TT>
 static void launch_amp_group(const AmpGroupArgs& g, int count, int batch, int len, int c, void* stream) {
+    if constexpr (TT == 1) {           // (the U variant exists for the default tile of each width: 256 output rows per block)
+        if (g_amp_u >= 0 && c == 10) {
+            constexpr int TB = AmpTile<12, 1, 1, 3>::TB;
+            SVCMI_LAUNCH((snake_conv_group_u_kernel<12, 10, 1, 1>), dim3((unsigned)((len + TB - 1) / TB), (unsigned)batch, (unsigned)count),
+                         dim3(TPB), 0, stream, g);
+            return;
+        }
+    }
+    if constexpr (TT == 2) {
+        if (g_amp_u > 0 && c == 20) {
+            constexpr int TB = AmpTile<20, 2, 2, 3>::TB;
+            SVCMI_LAUNCH((snake_conv_group_u_kernel<20, 20, 2, 2>), dim3((unsigned)((len + TB - 1) / TB), (unsigned)batch, (unsigned)count),
+                         dim3(TPB), 0, stream, g);
+            return;
+        }
+    }
     if (c == 10) {
         constexpr int TB = AmpTile<12, 1, TT, 3>::TB;
         SVCMI_LAUNCH((snake_conv_group_kernel<12, 10, 1, TT>), dim3((unsigned)((len + TB - 1) / TB), (unsigned)batch, (unsigned)count),
@@ -447,5 +562,9 @@ extern "C" int svcmi_tune_set(const char* name, int32_t value) {
     int i = 0;
     while (k[i] && name[i] == k[i]) ++i;
     if (k[i] == 0 && name[i] == 0 && (value == 0 || value == 1 || value == 2 || value == 4)) { g_amp_tt = value; return 0; }
+    const char* ku = "amp_u";
+    i = 0;
+    while (ku[i] && name[i] == ku[i]) ++i;
+    if (ku[i] == 0 && name[i] == 0 && value >= -1 && value <= 1) { g_amp_u = value; return 0; }
     return SVCMI_EINVAL;
 }

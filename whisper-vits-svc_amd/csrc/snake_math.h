@@ -118,3 +118,50 @@ __device__ __forceinline__ void snake_run(const float (&xw)[RT + 10], const floa
         out[r] = z[0] + z[1];
     }
 }
+
+// The two halves of snake_run as separate steps, for kernels that keep the up-sampled SnakeBeta values of a whole tile in LDS so that
+// each is computed ONCE (snake_run recomputes the 5 pairs two neighbouring runs share: 13 pairs per 8 outputs).  Same operation
+// sequence per value as snake_run, so the results are bit-identical to it.
+//   snake_pairs:  s2[mm] = (s_up[2*tq0 - 5 + 2mm], s_up[2*tq0 - 5 + 2mm + 1]), mm < NP, from xw[i] = x[clamp(tq0 - 5 + i, 0, n-1)], i < NP + 5
+//   snake_fir:    out[r] = sum_i f2[i] . P[r + i], r < NR, from NR + 5 consecutive pairs P
+template <int NP>
+__device__ __forceinline__ void snake_pairs(const float (&xw)[NP + 5], const float (&f)[12], float a, float inv_b, const float* xc, int ld,
+                                            int n, int tq0, svcmi_f32x2 (&s2)[NP]) {
+    const SnakeConsts k = snake_consts();
+    svcmi_f32x2 f2[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) f2[j] = svcmi_f32x2{f[2 * j], f[2 * j + 1]};
+#pragma unroll
+    for (int m = 0; m < NP; ++m) {
+        svcmi_f32x2 y = svcmi_splat2(0.f);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) y = svcmi_fma2(f2[j], svcmi_splat2(xw[5 - j + m]), y);
+        s2[m] = snake_fn2(y * svcmi_splat2(k.two), a, inv_b, k);
+    }
+    const int u0 = 2 * tq0 - 5;
+    if (u0 < 0 || u0 + 2 * NP - 1 > 2 * n - 1) {      // replicate padding of the low-pass input (filter.py:86-95)
+        const float s_first = snake_s_at(xc, ld, n, 0, f, a, inv_b);
+        const float s_last = snake_s_at(xc, ld, n, 2 * n - 1, f, a, inv_b);
+#pragma unroll
+        for (int m = 0; m < NP; ++m)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int u = u0 + 2 * m + h;
+                s2[m][h] = u < 0 ? s_first : (u > 2 * n - 1 ? s_last : s2[m][h]);
+            }
+    }
+}
+
+template <int NR>
+__device__ __forceinline__ void snake_fir(const svcmi_f32x2 (&P)[NR + 5], const float (&f)[12], float (&out)[NR]) {
+    svcmi_f32x2 f2[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) f2[j] = svcmi_f32x2{f[2 * j], f[2 * j + 1]};
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        svcmi_f32x2 z = svcmi_splat2(0.f);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) z = svcmi_fma2(f2[i], P[r + i], z);
+        out[r] = z[0] + z[1];
+    }
+}
