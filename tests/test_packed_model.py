@@ -51,7 +51,7 @@ def test_packed_whisper_runs_like_the_facade(ops):
 def test_packed_synthesizer_runs_like_the_facade(ops):
     hp = C.tiny_hp()
     m, _ = E.make_model(hp, ops, "cpu")
-    d = I.synth_clip(T=4, hp=hp, seed=9, B=1)
+    d = I.synth_clip(T=3, hp=hp, seed=9, B=1)
     src = m.pitch2source(d["pit"], noise=(d["rand_ini"], d["src_noise"]))
     want = m.inference(d["ppg"], d["vec"], d["pit"], d["spk"], d["lengths"], src, noise=d["enc_noise"])
     cm, kind = packed.load_packed(packed.pack_model(m._weights()), ops.lib, "cpu")
@@ -67,9 +67,9 @@ def test_per_stage_entry_points_compose_to_the_whole(ops):
     the ones `return_parts` hands out."""
     hp = C.tiny_hp()
     m, _ = E.make_model(hp, ops, "cpu")
-    d = I.synth_clip(T=5, hp=hp, seed=4, B=2)
+    d = I.synth_clip(T=3, hp=hp, seed=4, B=2)
     lens = d["lengths"].clone()
-    lens[-1] = 3
+    lens[-1] = 2
     src = m.pitch2source(d["pit"], noise=(d["rand_ini"], d["src_noise"]))
     want, parts = m.inference(d["ppg"], d["vec"], d["pit"], d["spk"], lens, src, noise=d["enc_noise"], return_parts=True)
     wave, z_p, z = ops.synth_stages_fwd(m._cmodel(), d["ppg"], d["vec"], d["pit"], d["spk"], lens.to(torch.int32), src.view(2, -1), d["enc_noise"])
@@ -78,7 +78,7 @@ def test_per_stage_entry_points_compose_to_the_whole(ops):
     # a workspace smaller than svcmi_synth_workspace_bytes says is refused before anything is launched
     cm = m._cmodel()
     io = _lib.SynthIO()
-    io.batch, io.t = 2, 5
+    io.batch, io.t = 2, 3
     small = torch.empty(4096, dtype=torch.uint8)
     base = (small.data_ptr() + 255) & ~255
     assert ops.lib.svcmi_flow_reverse_fwd(ctypes.byref(cm.struct), ctypes.byref(io), z.data_ptr(), base, 1024, 0) == -1

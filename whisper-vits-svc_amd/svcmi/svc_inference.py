@@ -216,24 +216,29 @@ def main(args):
     from .whisper import inference as whisper_inf
     device = "cuda"
     f0_prec = None if getattr(args, "f0_precision", "bf16x3") == "f32" else getattr(args, "f0_precision", "bf16x3")
+    prec = None if getattr(args, "precision", "f32") == "f32" else args.precision
+
+    def _with_prec(m):
+        (m.encoder if hasattr(m, "encoder") else m).precision = prec
+        return m
     if args.ppg is None and args.vec is None and args.pit is None:
         # all three features from the wav: the extractors run in flight together (extract_features); the intermediate files keep
         # their names and formats
         from .whisper.audio import load_audio
         crepe = pitch_inf.load_crepe(args.crepe, device)
         crepe.precision = f0_prec
-        ppg_d, vec_d, f0 = extract_features(load_audio(args.wave), whisper_inf.load_model(args.whisper, device),
-                                            hubert_inf.load_model(args.hubert, device), crepe, device)
+        ppg_d, vec_d, f0 = extract_features(load_audio(args.wave), _with_prec(whisper_inf.load_model(args.whisper, device)),
+                                            _with_prec(hubert_inf.load_model(args.hubert, device)), crepe, device)
         args.ppg, args.vec, args.pit = "svc_tmp.ppg.npy", "svc_tmp.vec.npy", "svc_tmp.pit.csv"
         np.save(args.ppg, ppg_d.cpu().numpy(), allow_pickle=False)
         np.save(args.vec, vec_d.cpu().numpy(), allow_pickle=False)
         pitch_inf.save_csv_pitch(f0, args.pit)
     if args.ppg is None:
         args.ppg = "svc_tmp.ppg.npy"
-        whisper_inf.pred_ppg(whisper_inf.load_model(args.whisper, device), args.wave, args.ppg, device)
+        whisper_inf.pred_ppg(_with_prec(whisper_inf.load_model(args.whisper, device)), args.wave, args.ppg, device)
     if args.vec is None:
         args.vec = "svc_tmp.vec.npy"
-        hubert_inf.pred_vec(hubert_inf.load_model(args.hubert, device), args.wave, args.vec, device)
+        hubert_inf.pred_vec(_with_prec(hubert_inf.load_model(args.hubert, device)), args.wave, args.vec, device)
     if args.pit is None:
         args.pit = "svc_tmp.pit.csv"
         crepe = pitch_inf.load_crepe(args.crepe, device)
@@ -246,6 +251,7 @@ def main(args):
     retrieval = create_retrival(args, device)      # DummyRetrieval unless --enable-retrieval (:25-58)
     model.eval()
     model.to(device)
+    model.precision = prec
     spk = torch.FloatTensor(np.load(args.spk))
     ppg = torch.FloatTensor(np.repeat(np.load(args.ppg), 2, 0))      # 320 PPG -> 160 * 2 (:175-177)
     vec = torch.FloatTensor(np.repeat(np.load(args.vec), 2, 0))
@@ -279,6 +285,10 @@ def build_parser():
     p.add_argument("--hubert", type=str, default=os.path.join("hubert_pretrain", "hubert-soft-0d54a1f4.pt"))
     p.add_argument("--crepe", type=str, default=os.path.join("crepe", "assets", "full.pth"))
     p.add_argument("--debug", action="store_true")
+    p.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16", "f16"],
+                   help="GEMM operand precision of the Whisper / HuBERT encoders and the synthesizer (fp32 accumulation, LayerNorm / softmax / "
+                        "SnakeAlias in fp32 in every mode): f32 = the reference CPU path's arithmetic (parity default); bf16x3 = split-bf16, "
+                        "waveform within 2e-5 of fp32; f16 = what the reference's .half() accelerator path does (waveform within 1e-3); bf16 (7e-3)")
     p.add_argument("--f0-precision", default="bf16x3", choices=["f32", "bf16x3"],
                    help="GEMM operand precision of the CREPE F0 extractor: bf16x3 = split-bf16 operands, fp32 accumulate (posteriors within 1e-5 "
                         "of fp32, decoded track identical on the golden clip: tests/test_gpu_engine.py), 2x faster; f32 = exact-fp32 matrix cores")
