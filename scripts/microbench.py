@@ -260,6 +260,19 @@ def main():
             us = (_t.perf_counter() - t0) * 1e6 / 80
             print(f"attnlds 4 streams x T=500 code={code:2d}: {us:8.1f} us per launch  {4.0 * 500 * 500 * 1280 / us / 1e6:7.1f} TF/s", flush=True)
         ops.lib.svcmi_tune_set(b"attn_lds", 0)
+    if "attn16" in what:      # attention on the 16-bit matrix cores: block shapes (10 * QT + KS) against the fp32 kernels' choice
+        for (B, T, H, D) in ((1, 500, 20, 64), (2, 500, 20, 64), (4, 500, 20, 64), (16, 500, 20, 64), (1, 750, 20, 64), (2, 750, 20, 64), (1, 1500, 20, 64)):
+            qkv = torch.randn(B, T, 3 * H * D, device="cuda")
+            q16 = qkv.half()
+            out = torch.empty(B, T, H * D, device="cuda")
+            us = timeit(lambda: ops.attention(qkv, H, D ** -0.5, out=out))
+            print(f"attn16 B={B} T={T} fp32 kernels: {us:8.1f} us  {4.0 * B * T * T * H * D / us / 1e6:7.1f} TF/s", flush=True)
+            for code in (0, 41, 42, 44, 81, 82):
+                assert ops.lib.svcmi_tune_set(b"attn16", code) == 0
+                us = timeit(lambda: ops.attention16(q16, H, D ** -0.5))
+                o, _ = ops.attention16(q16, H, D ** -0.5)
+                print(f"attn16 B={B} T={T} f16 shape={code:2d}: {us:8.1f} us  {4.0 * B * T * T * H * D / us / 1e6:7.1f} TF/s  maxdiff vs fp32 {float((o - out).abs().max()):.1e}", flush=True)
+        ops.lib.svcmi_tune_set(b"attn16", 0)
     if "attn" in what:
         for (T, H, D, rel) in ((500, 20, 64, False), (1000, 2, 96, True), (1500, 20, 64, False), (2520, 2, 96, True)):
             qkv = torch.randn(1, T, 3 * H * D, device="cuda")

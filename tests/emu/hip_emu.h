@@ -134,6 +134,7 @@ static inline svcmi_f32x4 svcmi_mfma_16x16x4(float a, float b, svcmi_f32x4 c) {
 
 // 16-bit-operand MFMAs (bf16 / fp16 in, fp32 accumulate): operands as 4 packed dwords = 8 values per lane.
 typedef unsigned svcmi_u32x4 __attribute__((vector_size(16)));
+typedef unsigned svcmi_u32x2 __attribute__((vector_size(8)));
 static inline svcmi_u32x4 svcmi_as_u32x4(svcmi_f32x4 v) { svcmi_u32x4 r; memcpy(&r, &v, 16); return r; }
 static inline float svcmi_bits_f32(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 static inline unsigned emu_bf16_rne(float f) {

@@ -746,3 +746,38 @@ def check_outputs16(ops, device):
         lens = torch.tensor([70, 41], dtype=torch.int32)
         o, o16 = ops.attention(d(qkv), H, 32 ** -0.5, lengths=d(lens), out16=dt)            # (another kernel shape: masked)
         assert torch.equal(o16.cpu(), o.cpu().to(dt))
+
+
+# attention on the 16-bit matrix cores (svcmi_attention16): every block shape, ragged lengths, key ranges past T, both formats
+ATTN16_CASES = [
+    dict(id="a16_f16_d64_T130_41", B=1, T=130, H=2, D=64, fmt="f16", shape=41),
+    dict(id="a16_bf16_d64_T300_42", B=1, T=300, H=2, D=64, fmt="bf16", shape=42),
+    dict(id="a16_f16_d64_ragged_T257_42", B=2, T=257, H=2, D=64, fmt="f16", shape=42, lengths=[257, 140]),
+    dict(id="a16_f16_d32_T70_auto", B=1, T=70, H=3, D=32, fmt="f16", shape=0),
+    dict(id="a16_bf16_d32_T40_44_empty_ranges", B=1, T=40, H=1, D=32, fmt="bf16", shape=44),
+    dict(id="a16_f16_d64_T150_81", B=1, T=150, H=2, D=64, fmt="f16", shape=81),
+    dict(id="a16_f16_d64_ragged_T260_82", B=2, T=260, H=1, D=64, fmt="f16", shape=82, lengths=[200, 260]),
+]
+ATTN16_CASES_LARGE = [
+    dict(id="a16_f16_whisper_T500", B=1, T=500, H=20, D=64, fmt="f16", shape=0),
+    dict(id="a16_bf16_whisper_T750_B2", B=2, T=750, H=20, D=64, fmt="bf16", shape=0),
+    dict(id="a16_f16_whisper_T500_B16_81", B=16, T=500, H=20, D=64, fmt="f16", shape=81),
+]
+
+
+def check_attention16(ops, c, device):
+    g = _g(31 + c["T"])
+    B, T, H, D = c["B"], c["T"], c["H"], c["D"]
+    dt = torch.float16 if c["fmt"] == "f16" else torch.bfloat16
+    qkv16 = torch.randn(B, T, 3 * H * D, generator=g).to(dt)
+    lengths = torch.tensor(c["lengths"], dtype=torch.int32) if "lengths" in c else None
+    scale = D ** -0.5
+    want = attention_reference(qkv16.float(), H, scale, None, None, 0, lengths)        # fp64 attention of the SAME 16-bit operands
+    assert ops.lib.svcmi_tune_set(b"attn16", int(c["shape"])) == 0
+    try:
+        o, o16 = ops.attention16(qkv16.to(device), H, scale, lengths=None if lengths is None else lengths.to(device))
+    finally:
+        ops.lib.svcmi_tune_set(b"attn16", 0)
+    assert torch.equal(o16.cpu(), o.cpu().to(dt)), c["id"]
+    # the only rounding left is P -> 16 bits before the PV product: rel. 2^-11 (f16) / 2^-8 (bf16) per probability
+    _close(o, want, 1.5e-3 if c["fmt"] == "f16" else 1.2e-2, c["id"])

@@ -172,3 +172,8 @@ def test_inlaunch_splitk_combine_is_bit_identical_under_load(ops):
 
 def test_outputs16(ops):
     K.check_outputs16(ops, "cuda")
+
+
+@pytest.mark.parametrize("case", K.ATTN16_CASES + K.ATTN16_CASES_LARGE, ids=lambda c: c["id"])
+def test_attention16(ops, case):
+    K.check_attention16(ops, case, "cuda")

@@ -161,3 +161,8 @@ def test_svc_train_retrieval_cli_writes_loadable_indexes(ops, tmp_path, monkeypa
 
 def test_outputs16(ops):
     K.check_outputs16(ops, "cpu")
+
+
+@pytest.mark.parametrize("case", K.ATTN16_CASES, ids=lambda c: c["id"])
+def test_attention16(ops, case):
+    K.check_attention16(ops, case, "cpu")

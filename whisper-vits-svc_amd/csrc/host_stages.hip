@@ -23,14 +23,14 @@ enum Op {
     OP_CONV_F32, OP_CONV_LP, OP_CONV_GROUP_F32, OP_CONV_GROUP_LP, OP_LAYERNORM, OP_SPLITK_LN, OP_ATTENTION, OP_SNAKE_ALIAS,
     OP_SNAKE_ALIAS_GROUP, OP_BLOCK_MEAN, OP_SNAKE_CONV, OP_SNAKE_CONV_GROUP, OP_UPSAMPLE_NOISE, OP_SNAKE_POST, OP_WN_GATE,
     OP_COUPLING_PRE, OP_COUPLING_POST, OP_EMBED_PITCH, OP_SAMPLE_PRIOR, OP_NCL_TO_NLC, OP_COPY2D, OP_PITCH_PREFIX, OP_PITCH_SOURCE,
-    OP_COUNT
+    OP_ATTENTION16, OP_COUNT
 };
 const char* const OP_NAMES[OP_COUNT] = {
     "svcmi_conv_gemm_f32", "svcmi_conv_gemm_lp", "svcmi_conv_gemm_group_f32", "svcmi_conv_gemm_group_lp", "svcmi_layernorm_f32",
     "svcmi_splitk_layernorm_f32", "svcmi_attention_f32", "svcmi_snake_alias_f32", "svcmi_snake_alias_group_f32", "svcmi_block_mean_f32",
     "svcmi_snake_conv_f32", "svcmi_snake_conv_group_f32", "svcmi_upsample_noise_f32", "svcmi_snake_post_f32", "svcmi_wn_gate_f32",
     "svcmi_coupling_pre_f32", "svcmi_coupling_post_f32", "svcmi_embed_pitch_f32", "svcmi_sample_prior_f32", "svcmi_ncl_to_nlc_f32",
-    "svcmi_copy2d_f32", "svcmi_pitch_prefix_f64", "svcmi_pitch_source_f32"};
+    "svcmi_copy2d_f32", "svcmi_pitch_prefix_f64", "svcmi_pitch_source_f32", "svcmi_attention16"};
 
 // ------------------------------------------------------------------------------------------------ per-launch trace (bench.py)
 struct TraceRec {
@@ -256,6 +256,15 @@ void attention(Ctx& c, const float* qkv, float* o, int B, int T, int heads, int 
     });
 }
 
+// band-free attention on the 16-bit matrix cores from the QKV projection's 16-bit output copy (bf16 / f16 modes)
+void attention16(Ctx& c, const void* qkv16, float* o, void* o16, int B, int T, int heads, int C, float scale, const int32_t* lengths) {
+    const unsigned short* q = static_cast<const unsigned short*>(qkv16);
+    run(c, OP_ATTENTION16, 4.0 * B * T * (double)T * C, 10.0 * B * T * C, [&] {
+        return svcmi_attention16(q, q + C, q + 2 * C, 3 * C, (int64_t)T * 3 * C, o, C, (int64_t)T * C, o16, C, (int64_t)T * C, B, T, heads, C / heads, scale,
+                                 lengths, c.prec, c.stream);
+    });
+}
+
 void copy2d(Ctx& c, const float* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, int64_t cols) {
     run(c, OP_COPY2D, 0.0, 8.0 * rows * cols, [&] { return svcmi_copy2d_f32(x, ldx, y, ldy, rows, cols, c.stream); });
 }
@@ -324,15 +333,20 @@ void whisper_fwd(Ctx& c, const svcmi_whisper_model& m, const float* mel, const f
     void* h16 = a16 ? c.ar.take((int64_t)B * tw * S * 2) : nullptr;
     void* at16 = a16 ? c.ar.take((int64_t)B * tw * S * 2) : nullptr;
     void* mm16 = a16 ? c.ar.take((int64_t)B * tw * F * 2) : nullptr;
+    // ... and the attention itself runs on the 16-bit matrix cores from the QKV projection's 16-bit output copy (svcmi_attention16)
+    const bool att16 = a16 && (S / H == 64 || S / H == 32);
+    void* qkv16 = att16 ? c.ar.take((int64_t)B * tw * 3 * S * 2) : nullptr;
     layernorm(c, x, nullptr, m.blocks[0].ln1_g, m.blocks[0].ln1_b, h, B, tw, S, S, 0, S, 0, h16);
     for (int i = 0; i < nb; ++i) {
         const svcmi_whisper_block& blk = m.blocks[i];
         CV v; v.B = B; v.t_in = tw; v.c_in = v.ldx = S; v.x_bs = (int64_t)tw * S;
         {
             CV q = v; q.x = h; q.x16 = h16; q.w = &blk.qkv; q.y = qkv; q.y_bs = (int64_t)tw * 3 * S; q.ldy = 3 * S; q.tile = t_qkv; q.tile_lp = l_qkv;
+            if (att16) { q.y16 = qkv16; q.split_k = 1; }       // (the 16-bit copy comes out of the float4 epilogue: no K slices)
             conv(c, q);
         }
-        attention(c, qkv, a, B, tw, H, S, scale, nullptr, nullptr, 0, nullptr, at16);
+        if (att16) attention16(c, qkv16, a, at16, B, tw, H, S, scale, nullptr);
+        else attention(c, qkv, a, B, tw, H, S, scale, nullptr, nullptr, 0, nullptr, at16);
         {
             CV o = v; o.x = a; o.x16 = at16; o.w = &blk.o; o.bias = false; o.slabs = slabs; o.split_k = so; o.tile = t_o; o.tile_lp = l_o;
             conv(c, o);

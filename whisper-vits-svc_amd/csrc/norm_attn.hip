@@ -883,6 +883,253 @@ __global__ __launch_bounds__(64 * QT * KS) void attention_lds_kernel(AttnArgs p)
     }
 }
 
+// ------------------------------------------------------------------------------------ attention on the 16-bit matrix cores
+// The bf16 / f16 modes (reference: `.half()` on an accelerator, whisper/inference.py:22-23): the same decomposition as attention_lds_kernel
+// -- QT query tiles x KS key ranges per block, K / V tiles of a head staged once per block through LDS, both products swapped so that a lane
+// owns one query -- with Q / K / V arriving as 16-bit tensors (the QKV GEMM's 16-bit output copy) and both products on
+// v_mfma_f32_16x16x32_{bf16,f16}: 4 + 4 matrix instructions per 32-key step and wave instead of 32 + 32 exact-fp32 ones.  Softmax
+// statistics, the online rescale and the accumulators stay fp32; P is rounded to 16 bits right before the PV product.
+//   S^T tile: A = K rows (lane (key, g): 8 consecutive d = one ds_read_b128 from the [32][D] tile, rows padded to D * 2 + 16 bytes),
+//             B = Q^T (lane (query, g): 8 consecutive d, kept in registers);
+//   O^T tile: B = P^T -- the MFMA's contraction slot (g, e) is DEFINED as key 4g + e (e < 4) resp. 16 + 4g + e - 4, which is exactly the
+//             set of keys whose probabilities the lane already holds from the first product: P never moves between lanes;
+//             A = V^T in the same slot order: the V tile is stored TRANSPOSED in LDS as [key group of 4][d][4 keys] (16-bit), so the lane
+//             (d, g) reads two 8-byte units (key groups g and 4 + g).  The transposition happens in the staging writes (ds_write_b16).
+struct Attn16Args {
+    const unsigned short* q; const unsigned short* k; const unsigned short* v;
+    float* o; unsigned short* o16;
+    int ld16, ldo, ldo16;
+    long long bs16, o_bs, o16_bs;
+    int t, heads, nq;
+    float scale;
+    const int32_t* lengths;
+    int o16_f16;
+};
+
+template <int D, int QT, int KS, bool F16>
+__global__ __launch_bounds__(64 * QT * KS) void attention16_kernel(Attn16Args p) {
+    constexpr int DS = D / 16, DK = D / 32, OLD = D + 4, NW = QT * KS, NT = 64 * NW, QB = 16 * QT;
+    constexpr int KLD = D / 2 + 4;                      // K tile row stride in floats: D 16-bit values + 16 bytes
+    constexpr int KT = 32 * KLD;                        // floats per K tile
+    constexpr int VGS = (D + 16) * 2;                   // floats per key group of the transposed V tile: (D + 16) units of 4 keys x 2 bytes
+    constexpr int VT = 8 * VGS;                         // floats per V tile (8 key groups)
+    constexpr int STAGE = KS * 2 * (KT + VT);           // [ks][buffer][K | V]
+    constexpr int MERGE = NW * 16 * OLD + 2 * NW * 16;
+    __shared__ __attribute__((aligned(16))) float smem[STAGE > MERGE ? STAGE : MERGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = SVCMI_UNIFORM((int)(tid >> 6));
+    const int qt_l = w % QT, ks = w / QT;
+    const int lq = lane & 15, g4 = lane >> 4;
+    int L;
+    {
+        const int total = (int)gridDim.x, id = (int)blockIdx.x;
+        const int q8 = total >> 3, r8 = total & 7, xcd = id & 7, slot = id >> 3;
+        L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    }
+    const int qg = L % p.nq, hb = L / p.nq;
+    const int h = hb % p.heads, b = hb / p.heads;
+    const int T = p.t;
+    const int len = p.lengths ? p.lengths[b] : T;
+    const float scale2 = p.scale * LOG2E;
+    const int q0 = qg * QB + 16 * qt_l, qi = q0 + lq;
+
+    svcmi_u32x4 qf[DK];
+    {
+        const unsigned short* qp = p.q + (long long)b * p.bs16 + (long long)(qi < T ? qi : T - 1) * p.ld16 + h * D + 8 * g4;
+#pragma unroll
+        for (int s = 0; s < DK; ++s) qf[s] = *reinterpret_cast<const svcmi_u32x4*>(qp + 32 * s);
+    }
+    svcmi_f32x4 oacc[DS];
+#pragma unroll
+    for (int dt = 0; dt < DS; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) oacc[dt][r] = 0.f;
+    float mrun = NEG_BIG, lrun = 0.f;
+
+    const int per = ((T + KS - 1) / KS + 31) / 32 * 32;
+    const int steps = per / 32;
+    const int jbeg = ks * per;
+    // staging role inside the key range: QT * 64 threads move 32 rows x D/8 16-byte chunks of K and of V per step
+    constexpr int C8 = D / 8, CH = 32 * C8, PER_T = (2 * CH + 64 * QT - 1) / (64 * QT);
+    const int st = qt_l * 64 + lane;
+    const unsigned short* kg_ = p.k + (long long)b * p.bs16 + h * D;
+    const unsigned short* vg_ = p.v + (long long)b * p.bs16 + h * D;
+    float* const Kt = smem + ks * 2 * (KT + VT);            // [buffer][K | V] of this key range
+    svcmi_u32x4 sreg[PER_T];
+    auto fetch = [&](int kt) {
+#pragma unroll
+        for (int j = 0; j < PER_T; ++j) {
+            const int idx = st + j * 64 * QT;
+            if (idx < 2 * CH) {
+                const int c = idx < CH ? idx : idx - CH;
+                const int row = c / C8, c8 = c - row * C8;
+                const int key = kt + row;
+                const long long off = (long long)(key < T ? key : T - 1) * p.ld16 + 8 * c8;
+                sreg[j] = *reinterpret_cast<const svcmi_u32x4*>((idx < CH ? kg_ : vg_) + off);
+            }
+        }
+    };
+    auto stash = [&](int buf) {
+        float* const Kc = Kt + buf * (KT + VT);
+        unsigned short* const Vc = reinterpret_cast<unsigned short*>(Kc + KT);
+#pragma unroll
+        for (int j = 0; j < PER_T; ++j) {
+            const int idx = st + j * 64 * QT;
+            if (idx < 2 * CH) {
+                const int c = idx < CH ? idx : idx - CH;
+                const int row = c / C8, c8 = c - row * C8;
+                if (idx < CH) {
+                    *reinterpret_cast<svcmi_u32x4*>(Kc + row * KLD + 4 * c8) = sreg[j];
+                } else {                                   // transposed: element (key group row >> 2, d, key row & 3)
+                    unsigned short* dst = Vc + ((row >> 2) * (D + 16) + 8 * c8) * 4 + (row & 3);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        dst[(2 * e) * 4] = (unsigned short)(sreg[j][e] & 0xffffu);
+                        dst[(2 * e + 1) * 4] = (unsigned short)(sreg[j][e] >> 16);
+                    }
+                }
+            }
+        }
+    };
+    fetch(jbeg);
+    stash(0);
+    __syncthreads();
+    for (int it = 0; it < steps; ++it) {
+        const int kt = jbeg + 32 * it, buf = it & 1;
+        if (it + 1 < steps) fetch(kt + 32);
+        const float* Kc = Kt + buf * (KT + VT);
+        const unsigned short* Vc = reinterpret_cast<const unsigned short*>(Kc + KT);
+        svcmi_f32x4 sacc[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sacc[u][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < DK; ++s) {
+            const svcmi_u32x4 a0 = *reinterpret_cast<const svcmi_u32x4*>(Kc + lq * KLD + 4 * g4 + 16 * s);
+            const svcmi_u32x4 a1 = *reinterpret_cast<const svcmi_u32x4*>(Kc + (16 + lq) * KLD + 4 * g4 + 16 * s);
+            sacc[0] = svcmi_mfma16_16x16x32<F16>(a0, qf[s], sacc[0]);
+            sacc[1] = svcmi_mfma16_16x16x32<F16>(a1, qf[s], sacc[1]);
+        }
+        const bool clean = kt + 32 <= (len < T ? len : T) && q0 + 16 <= len;     // wave-uniform
+        float sv[2][4];
+        float mt = NEG_BIG;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt + 16 * u + 4 * g4 + r;
+                float a = sacc[u][r] * scale2;
+                if (!clean) {
+                    if (qi >= len || key >= len) a = MASKED2;       // masked_fill(mask == 0, -1e4)
+                    if (key >= T) a = NEG_BIG;                      // beyond the sequence: weight 0
+                }
+                sv[u][r] = a;
+                mt = fmaxf(mt, a);
+            }
+        mt = fmaxf(mt, __shfl_xor(mt, 16));
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float mnew = fmaxf(mrun, mt);
+        const float corr = mnew > -1.0e38f ? svcmi_exp2(mrun - mnew) : 0.f;
+        mrun = mnew;
+        lrun *= corr;
+#pragma unroll
+        for (int dt = 0; dt < DS; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) oacc[dt][r] *= corr;
+        float pv[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pv[u][r] = mnew > -1.0e38f ? svcmi_exp2(sv[u][r] - mnew) : 0.f;
+                lrun += pv[u][r];
+            }
+        svcmi_u32x4 pf;         // contraction slot (g, e): e < 4 -> key 4g + e of the first 16-key tile, else key 4g + e - 4 of the second
+        pf[0] = F16 ? svcmi_cvt_pk_f16(pv[0][0], pv[0][1]) : svcmi_cvt_pk_bf16(pv[0][0], pv[0][1]);
+        pf[1] = F16 ? svcmi_cvt_pk_f16(pv[0][2], pv[0][3]) : svcmi_cvt_pk_bf16(pv[0][2], pv[0][3]);
+        pf[2] = F16 ? svcmi_cvt_pk_f16(pv[1][0], pv[1][1]) : svcmi_cvt_pk_bf16(pv[1][0], pv[1][1]);
+        pf[3] = F16 ? svcmi_cvt_pk_f16(pv[1][2], pv[1][3]) : svcmi_cvt_pk_bf16(pv[1][2], pv[1][3]);
+#pragma unroll
+        for (int dt = 0; dt < DS; ++dt) {
+            const int d = 16 * dt + lq;
+            const svcmi_u32x2 lo = *reinterpret_cast<const svcmi_u32x2*>(Vc + (g4 * (D + 16) + d) * 4);
+            const svcmi_u32x2 hi = *reinterpret_cast<const svcmi_u32x2*>(Vc + ((4 + g4) * (D + 16) + d) * 4);
+            svcmi_u32x4 a;
+            a[0] = lo[0]; a[1] = lo[1]; a[2] = hi[0]; a[3] = hi[1];
+            oacc[dt] = svcmi_mfma16_16x16x32<F16>(a, pf, oacc[dt]);
+        }
+        if (it + 1 < steps) stash(buf ^ 1);
+        __syncthreads();
+    }
+
+    float* const Opart = smem;
+    float* const Mpart = Opart + NW * 16 * OLD;
+    float* const Lpart = Mpart + NW * 16;
+    lrun = quarter_sum(lrun);
+    {
+        float* orow = Opart + (w * 16 + lq) * OLD + 4 * g4;
+#pragma unroll
+        for (int dt = 0; dt < DS; ++dt)
+            *reinterpret_cast<float4*>(orow + 16 * dt) = make_float4(oacc[dt][0], oacc[dt][1], oacc[dt][2], oacc[dt][3]);
+        if (g4 == 0) {
+            Mpart[w * 16 + lq] = mrun;
+            Lpart[w * 16 + lq] = lrun;
+        }
+    }
+    __syncthreads();
+    for (int item = tid; item < QB * (D / 4); item += NT) {
+        const int qr = item / (D / 4), c4 = (item - qr * (D / 4)) * 4;
+        const int qtl = qr >> 4, ql = qr & 15;
+        float mall = NEG_BIG;
+#pragma unroll
+        for (int k2 = 0; k2 < KS; ++k2) mall = fmaxf(mall, Mpart[(k2 * QT + qtl) * 16 + ql]);
+        float den = 0.f;
+        float4 num = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k2 = 0; k2 < KS; ++k2) {
+            const int ww = k2 * QT + qtl;
+            const float mw = Mpart[ww * 16 + ql];
+            const float cw = mw > -1.0e38f ? svcmi_exp2(mw - mall) : 0.f;
+            den = fmaf(cw, Lpart[ww * 16 + ql], den);
+            const float4 ov = *reinterpret_cast<const float4*>(Opart + (ww * 16 + ql) * OLD + c4);
+            num.x = fmaf(cw, ov.x, num.x); num.y = fmaf(cw, ov.y, num.y);
+            num.z = fmaf(cw, ov.z, num.z); num.w = fmaf(cw, ov.w, num.w);
+        }
+        const int qrow = qg * QB + qr;
+        if (qrow < T) {
+            const float inv = 1.0f / den;
+            if (p.o) *reinterpret_cast<float4*>(p.o + (long long)b * p.o_bs + (long long)qrow * p.ldo + h * D + c4) = make_float4(num.x * inv, num.y * inv, num.z * inv, num.w * inv);
+            if (p.o16) store4_16(p.o16 + (long long)b * p.o16_bs + (long long)qrow * p.ldo16 + h * D + c4, num.x * inv, num.y * inv, num.z * inv, num.w * inv, p.o16_f16);
+        }
+    }
+}
+
+int g_attn16 = 0;       // tuning knob ("attn16", 0 = heuristic | 10 * QT + KS): block shape of attention16_kernel
+
+template <int D, bool F16>
+int launch_attn16(const Attn16Args& a_in, int batch, void* stream) {
+    Attn16Args a = a_in;
+    int code = g_attn16;
+    if (!code) {        // (shapes measured like the fp32 LDS kernel's: profiles/r03j_attn16.log)
+        const long long blocks4 = (long long)((a.t + 63) / 64) * a.heads * batch;
+        code = blocks4 >= 1024 ? 81 : (a.t >= 256 ? 42 : 41);
+    }
+    const int qt = code / 10;
+    a.nq = (a.t + 16 * qt - 1) / (16 * qt);
+    dim3 g((unsigned)((long long)a.nq * a.heads * batch));
+    switch (code) {
+        case 41: SVCMI_LAUNCH((attention16_kernel<D, 4, 1, F16>), g, dim3(64 * 4), 0, stream, a); break;
+        case 42: SVCMI_LAUNCH((attention16_kernel<D, 4, 2, F16>), g, dim3(64 * 8), 0, stream, a); break;
+        case 44: SVCMI_LAUNCH((attention16_kernel<D, 4, 4, F16>), g, dim3(64 * 16), 0, stream, a); break;
+        case 81: SVCMI_LAUNCH((attention16_kernel<D, 8, 1, F16>), g, dim3(64 * 8), 0, stream, a); break;
+        case 82: SVCMI_LAUNCH((attention16_kernel<D, 8, 2, F16>), g, dim3(64 * 16), 0, stream, a); break;
+        default: return SVCMI_EINVAL;
+    }
+    return SVCMI_LAST_ERROR();
+}
+
 int g_attn_lds = 0;     // tuning knob ("attn_lds"): 0 = heuristic, -1 = never, 1 / 10 * QT + KS = force the LDS-staged kernel (band-free, D <= 64)
 int g_attn_ns = 0;      // tuning knob (svcmi_tune_set("attn_ns", 0 | 1 | 2 | 4 | 8)); 0 = heuristic
 
@@ -1042,6 +1289,24 @@ extern "C" int svcmi_attention_f32(const float* q, const float* k, const float* 
     }
 }
 
+extern "C" int svcmi_attention16(const void* q, const void* k, const void* v, int32_t ld16, int64_t bstride16, float* o, int32_t ldo,
+                                 int64_t o_bstride, void* o16, int32_t ldo16, int64_t o16_bstride, int32_t batch, int32_t t, int32_t heads,
+                                 int32_t head_dim, float scale, const int32_t* lengths, int32_t format, void* stream) {
+    if (!q || !k || !v || (!o && !o16) || batch <= 0 || t <= 0 || heads <= 0) return SVCMI_EINVAL;
+    if (format != SVCMI_PREC_BF16 && format != SVCMI_PREC_F16) return SVCMI_EINVAL;
+    if (head_dim != 32 && head_dim != 64) return SVCMI_EUNSUPPORTED;
+    if (ld16 % 8 || bstride16 % 8 || ((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15)) return SVCMI_EALIGN;
+    if (o && (ldo % 4 || o_bstride % 4 || ((uintptr_t)o & 15))) return SVCMI_EALIGN;
+    if (o16 && (ldo16 % 4 || o16_bstride % 4 || ((uintptr_t)o16 & 7))) return SVCMI_EALIGN;
+    if ((long long)batch * heads * ((t + 31) / 32) > 0x7fffffffLL) return SVCMI_EUNSUPPORTED;
+    Attn16Args a;
+    a.q = static_cast<const unsigned short*>(q); a.k = static_cast<const unsigned short*>(k); a.v = static_cast<const unsigned short*>(v);
+    a.o = o; a.o16 = static_cast<unsigned short*>(o16); a.ld16 = ld16; a.ldo = ldo; a.ldo16 = ldo16; a.bs16 = bstride16; a.o_bs = o_bstride;
+    a.o16_bs = o16_bstride; a.t = t; a.heads = heads; a.nq = 0; a.scale = scale; a.lengths = lengths; a.o16_f16 = format == SVCMI_PREC_F16;
+    if (format == SVCMI_PREC_F16) return head_dim == 64 ? launch_attn16<64, true>(a, batch, stream) : launch_attn16<32, true>(a, batch, stream);
+    return head_dim == 64 ? launch_attn16<64, false>(a, batch, stream) : launch_attn16<32, false>(a, batch, stream);
+}
+
 // Development knob (reached through svcmi_tune_set): results do not depend on it beyond fp32 re-association of the key split.
 extern "C" int svcmi_attn_tune_set(const char* name, int32_t value) {
     const char* k = "attn_ns";
@@ -1053,6 +1318,10 @@ extern "C" int svcmi_attn_tune_set(const char* name, int32_t value) {
     while (k4[i] && name[i] == k4[i]) ++i;
     if (k4[i] == 0 && name[i] == 0 && (value == -1 || value == 0 || value == 1 || value == 21 || value == 22 || value == 24 || value == 41 || value == 42 ||
                                        value == 44 || value == 81 || value == 82)) { g_attn_lds = value; return 0; }
+    const char* k5 = "attn16";
+    i = 0;
+    while (k5[i] && name[i] == k5[i]) ++i;
+    if (k5[i] == 0 && name[i] == 0 && (value == 0 || value == 41 || value == 42 || value == 44 || value == 81 || value == 82)) { g_attn16 = value; return 0; }
     const char* k2 = "attn_q32";
     i = 0;
     while (k2[i] && name[i] == k2[i]) ++i;

@@ -49,6 +49,7 @@ __device__ __forceinline__ svcmi_f32x4 svcmi_mfma_16x16x4(float a, float b, svcm
 // packed dwords = 8 values; lane l supplies A[i = l&31][k = 8*(l>>5) .. +7] and B[k = 8*(l>>5) .. +7][j = l&31]
 // (32x32x16) resp. A[l&15][8*(l>>4) .. +7], B[8*(l>>4) .. +7][l&15] (16x16x32); C/D layouts as the fp32 forms above.
 typedef unsigned svcmi_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned svcmi_u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 svcmi_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 svcmi_bf16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 svcmi_f16x8 __attribute__((ext_vector_type(8)));
