@@ -1112,9 +1112,15 @@ template <int D, bool F16>
 int launch_attn16(const Attn16Args& a_in, int batch, void* stream) {
     Attn16Args a = a_in;
     int code = g_attn16;
-    if (!code) {        // (shapes measured like the fp32 LDS kernel's: profiles/r03j_attn16.log)
-        const long long blocks4 = (long long)((a.t + 63) / 64) * a.heads * batch;
-        code = blocks4 >= 1024 ? 81 : (a.t >= 256 ? 42 : 41);
+    if (!code) {
+        // measured on MI355X (profiles/r03j_attn16.log, f16, 20 heads x 64): one T = 500 / 750 window 4 x 4 (12.1 / 13.9 us; fp32 kernels 29.2 /
+        // 49.3), B = 2 windows or T = 1500 8 x 2 (16.4 / 22.2 / 37.2 us), B = 4 4 x 2 (26.7), B = 16 8 x 1 (62 us = 331 TFLOP/s; fp32 195 us)
+        const long long blocks8 = (long long)((a.t + 127) / 128) * a.heads * batch;
+        if (a.t < 128) code = 41;
+        else if (blocks8 >= 1024) code = 81;
+        else if (blocks8 >= 128 && blocks8 <= 256 && a.t >= 256) code = 82;
+        else if (blocks8 < 128 && a.t >= 512 - 64) code = 44;
+        else code = a.t >= 256 ? 42 : 41;
     }
     const int qt = code / 10;
     a.nq = (a.t + 16 * qt - 1) / (16 * qt);
