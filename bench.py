@@ -14,9 +14,9 @@ device inside the step.  `--config` selects the other BASELINE.json configuratio
     2  1 GPU: batch 16 x 10 s clips, flow + decoder only (pre-extracted PPG / F0), bf16 GEMM operands
     3  512 x 10 s utterances sharded over the ranks (64 per GPU at 8), batches of 16, full pipeline incl. Whisper; a step is
        one pass over this rank's shard, so the total work is fixed: "scaling": "strong"
-    4  30 s clips per rank through the reference schedule: two 15 s Whisper windows (Tw = 750 each, fp16 GEMM operands like
-       the reference's .half() accelerator path), T = 3000 frames -> synthesis chunks [0,2510) / [2490,3000) with the halo
-       trim of svc_inference.py:101-131
+    4  30 s clips per rank through the reference schedule: two 15 s Whisper windows (Tw = 750 each), T = 3000 frames -> synthesis
+       chunks [0,2510) / [2490,3000) with the halo trim of svc_inference.py:101-131; fp16 GEMM operands + 16-bit activations + fp16
+       attention in both networks, like the reference's .half() accelerator path
 Clips in flight (`--inflight`, default 4 for config 1): a step is still ONE batch-1 clip through the whole path, but the K timed steps are
 replayed round-robin on 4 lanes (HIP stream + captured HIP graph + own static buffers each, svcmi/lanes.py), so that one clip's
 latency-bound launches run beside another clip's Whisper GEMMs; `ms_per_step` = wall time / K (the throughput figure), and
@@ -238,7 +238,9 @@ class LongForm(Workload):
 
 WORKLOADS = {1: Workload, 2: FlowDecoderBatch, 3: ShardedUtterances, 4: LongForm}
 # per-config defaults: (batch, seconds, whisper precision, synthesizer precision)
-DEFAULTS = {1: (1, 10.0, "f32", "f32"), 2: (16, 10.0, None, "bf16"), 3: (16, 10.0, "f32", "f32"), 4: (1, 30.0, "f16", "f32")}
+# (configs[4] is "fp16 MFMA" in BASELINE.json: both networks in f16 since round 3 -- 9.4e-4 on the waveform, inside the 1e-3 bar
+#  (profiles/r03k_precision_report.json); `--precision` / the r02 lines used f16 Whisper + fp32 synthesizer)
+DEFAULTS = {1: (1, 10.0, "f32", "f32"), 2: (16, 10.0, None, "bf16"), 3: (16, 10.0, "f32", "f32"), 4: (1, 30.0, "f16", "f16")}
 
 
 def build_graph(fn, warm=2, stream=None):
