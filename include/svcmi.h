@@ -190,15 +190,17 @@ int svcmi_attention_f32(const float* q, const float* k, const float* v, float* o
                         const float* rel_k, const float* rel_v, int32_t window,
                         const int32_t* lengths, void* o16, int32_t ldo16, int64_t o16_bstride, int32_t o16_format, void* stream);
 
-/* The same attention (band-free: no rel_k / rel_v) on the 16-bit matrix cores, for the bf16 / f16 modes: q / k / v are 16-bit tensors
+/* The same attention on the 16-bit matrix cores, for the bf16 / f16 modes (rel_k / rel_v / window as above, fp32 tables, or NULL): q / k / v are 16-bit tensors
  * (`format` = SVCMI_PREC_BF16 | SVCMI_PREC_F16; element (b, t, h, d) at base + b*bstride16 + t*ld16 + h*head_dim + d, in 16-bit elements --
  * the y16 copy of the fused QKV projection), products on v_mfma_f32_16x16x32, softmax statistics / rescale / accumulation in fp32, P
  * rounded to `format` before the PV product.  K / V tiles of a head are staged once per block through LDS (V transposed on the way in).
- * Outputs: o (fp32, may be NULL) and / or o16 (16-bit copy in `format`, may be NULL): the out-projection's A operand.  head_dim in {32, 64}.
- * Replaces whisper/model.py:88-101 under `.half()` (whisper/inference.py:22-23). */
+ * Outputs: o (fp32, may be NULL) and / or o16 (16-bit copy in `format`, may be NULL): the out-projection's A operand.  head_dim in {32, 64}
+ * without the band, {32, 96} with it.  Replaces whisper/model.py:88-101 under `.half()` (whisper/inference.py:22-23) and, in the 16-bit
+ * modes of the synthesizer, vits/attentions.py:225-274. */
 int svcmi_attention16(const void* q, const void* k, const void* v, int32_t ld16, int64_t bstride16, float* o, int32_t ldo,
                       int64_t o_bstride, void* o16, int32_t ldo16, int64_t o16_bstride, int32_t batch, int32_t t, int32_t heads,
-                      int32_t head_dim, float scale, const int32_t* lengths, int32_t format, void* stream);
+                      int32_t head_dim, float scale, const float* rel_k, const float* rel_v, int32_t window,
+                      const int32_t* lengths, int32_t format, void* stream);
 
 /* Anti-aliased SnakeBeta (vits_decoder/alias/act.py:124-129): 2x Kaiser-sinc polyphase upsample with
  * replicate padding (resample.py:25-33), x + sin^2(x*e^alpha)/(e^beta + 1e-9) (act.py:79-92), 12-tap
@@ -276,7 +278,7 @@ int svcmi_snake_post_f32(const float* x, const float* w, float* y, const float* 
  *   "group_nst" {0 = default, 2, 3}     LDS ring depth of the grouped implicit-GEMM launches
  *   "attn_ns"  {0 = heuristic, 1, 2, 4, 8}  key-split waves per block of svcmi_attention_f32
  *   "attn_q32" {-1 = heuristic, 0, 1}   two query tiles per wave (band-free attention, head_dim <= 64)
- *   "attn16"   {0 = heuristic, 41, 42, 44, 81, 82}  block shape (10 * query tiles + key ranges) of svcmi_attention16
+ *   "attn16"   {0 = heuristic, 41, 42, 44, 81, 82; with the band: 14, 21, 24, 42, 44}  block shape (10 * query tiles + key ranges) of svcmi_attention16
  *   "attn_lds" {0 = heuristic, -1 = never, 1, 10*QT+KS}  band-free attention with K / V tiles staged through LDS and shared by QT in
  *              {2, 4, 8} query tiles x KS in {1, 2, 4} key ranges per block (1 = 4 x 2; compiled shapes 21 22 24 41 42 44 81 82)
  * Process-wide, not thread-safe against concurrent launches.  Returns 0, or SVCMI_EINVAL for an unknown name / value. */

@@ -272,6 +272,18 @@ def main():
                 us = timeit(lambda: ops.attention16(q16, H, D ** -0.5))
                 o, _ = ops.attention16(q16, H, D ** -0.5)
                 print(f"attn16 B={B} T={T} f16 shape={code:2d}: {us:8.1f} us  {4.0 * B * T * T * H * D / us / 1e6:7.1f} TF/s  maxdiff vs fp32 {float((o - out).abs().max()):.1e}", flush=True)
+        for (B, T, H, D) in ((1, 1000, 2, 96), (16, 1000, 2, 96), (1, 2510, 2, 96), (1, 510, 2, 96)):       # the prior encoder's rel-pos attention
+            qkv = torch.randn(B, T, 3 * H * D, device="cuda")
+            q16 = qkv.half()
+            rk, rv = torch.randn(9, D, device="cuda") * 0.1, torch.randn(9, D, device="cuda") * 0.1
+            out = torch.empty(B, T, H * D, device="cuda")
+            us = timeit(lambda: ops.attention(qkv, H, D ** -0.5, rel_k=rk, rel_v=rv, window=4, out=out))
+            print(f"attn16 rel B={B} T={T} fp32 kernel: {us:8.1f} us  {4.0 * B * T * T * H * D / us / 1e6:7.1f} TF/s", flush=True)
+            for code in (0, 14, 21, 24, 42, 44):
+                assert ops.lib.svcmi_tune_set(b"attn16", code) == 0
+                us = timeit(lambda: ops.attention16(q16, H, D ** -0.5, rel_k=rk, rel_v=rv, window=4))
+                o, _ = ops.attention16(q16, H, D ** -0.5, rel_k=rk, rel_v=rv, window=4)
+                print(f"attn16 rel B={B} T={T} f16 shape={code:2d}: {us:8.1f} us  {4.0 * B * T * T * H * D / us / 1e6:7.1f} TF/s  maxdiff vs fp32 {float((o - out).abs().max()):.1e}", flush=True)
         ops.lib.svcmi_tune_set(b"attn16", 0)
     if "attn" in what:
         for (T, H, D, rel) in ((500, 20, 64, False), (1000, 2, 96, True), (1500, 20, 64, False), (2520, 2, 96, True)):

@@ -757,11 +757,20 @@ ATTN16_CASES = [
     dict(id="a16_bf16_d32_T40_44_empty_ranges", B=1, T=40, H=1, D=32, fmt="bf16", shape=44),
     dict(id="a16_f16_d64_T150_81", B=1, T=150, H=2, D=64, fmt="f16", shape=81),
     dict(id="a16_f16_d64_ragged_T260_82", B=2, T=260, H=1, D=64, fmt="f16", shape=82, lengths=[200, 260]),
+    # with the relative-position band of the prior encoder (2 heads x 96 at base.yaml)
+    dict(id="a16_f16_d96_rel_T67_21", B=1, T=67, H=2, D=96, fmt="f16", shape=21, rel=True, W=4, lengths=[60]),
+    dict(id="a16_bf16_d96_rel_T260_24", B=2, T=260, H=2, D=96, fmt="bf16", shape=24, rel=True, W=4, lengths=[260, 201]),
+    dict(id="a16_f16_d96_rel_T140_14", B=1, T=140, H=2, D=96, fmt="f16", shape=14, rel=True, W=4),
+    dict(id="a16_f16_d32_rel_w2_T140_42", B=1, T=140, H=2, D=32, fmt="f16", shape=42, rel=True, W=2, lengths=[133]),
+    dict(id="a16_f16_d96_rel_short_T3_auto", B=1, T=3, H=2, D=96, fmt="f16", shape=0, rel=True, W=4),
+    dict(id="a16_f16_d32_rel_T300_44", B=1, T=300, H=1, D=32, fmt="f16", shape=44, rel=True, W=4),
 ]
 ATTN16_CASES_LARGE = [
     dict(id="a16_f16_whisper_T500", B=1, T=500, H=20, D=64, fmt="f16", shape=0),
     dict(id="a16_bf16_whisper_T750_B2", B=2, T=750, H=20, D=64, fmt="bf16", shape=0),
     dict(id="a16_f16_whisper_T500_B16_81", B=16, T=500, H=20, D=64, fmt="f16", shape=81),
+    dict(id="a16_f16_encp_T1000_rel", B=1, T=1000, H=2, D=96, fmt="f16", shape=0, rel=True, W=4),
+    dict(id="a16_bf16_encp_ragged_B3_rel", B=3, T=301, H=2, D=96, fmt="bf16", shape=0, rel=True, W=4, lengths=[301, 250, 7]),
 ]
 
 
@@ -772,10 +781,13 @@ def check_attention16(ops, c, device):
     qkv16 = torch.randn(B, T, 3 * H * D, generator=g).to(dt)
     lengths = torch.tensor(c["lengths"], dtype=torch.int32) if "lengths" in c else None
     scale = D ** -0.5
-    want = attention_reference(qkv16.float(), H, scale, None, None, 0, lengths)        # fp64 attention of the SAME 16-bit operands
+    rel_k = torch.randn(2 * c["W"] + 1, D, generator=g) * D ** -0.5 if c.get("rel") else None
+    rel_v = torch.randn(2 * c["W"] + 1, D, generator=g) * D ** -0.5 if c.get("rel") else None
+    want = attention_reference(qkv16.float(), H, scale, rel_k, rel_v, c.get("W", 0), lengths)        # fp64 attention of the SAME 16-bit operands
     assert ops.lib.svcmi_tune_set(b"attn16", int(c["shape"])) == 0
+    dev = lambda t: None if t is None else t.to(device)
     try:
-        o, o16 = ops.attention16(qkv16.to(device), H, scale, lengths=None if lengths is None else lengths.to(device))
+        o, o16 = ops.attention16(qkv16.to(device), H, scale, rel_k=dev(rel_k), rel_v=dev(rel_v), window=c.get("W", 0), lengths=dev(lengths))
     finally:
         ops.lib.svcmi_tune_set(b"attn16", 0)
     assert torch.equal(o16.cpu(), o.cpu().to(dt)), c["id"]

@@ -257,11 +257,12 @@ void attention(Ctx& c, const float* qkv, float* o, int B, int T, int heads, int 
 }
 
 // band-free attention on the 16-bit matrix cores from the QKV projection's 16-bit output copy (bf16 / f16 modes)
-void attention16(Ctx& c, const void* qkv16, float* o, void* o16, int B, int T, int heads, int C, float scale, const int32_t* lengths) {
+void attention16(Ctx& c, const void* qkv16, float* o, void* o16, int B, int T, int heads, int C, float scale, const int32_t* lengths,
+                 const float* rel_k = nullptr, const float* rel_v = nullptr, int window = 0) {
     const unsigned short* q = static_cast<const unsigned short*>(qkv16);
     run(c, OP_ATTENTION16, 4.0 * B * T * (double)T * C, 10.0 * B * T * C, [&] {
         return svcmi_attention16(q, q + C, q + 2 * C, 3 * C, (int64_t)T * 3 * C, o, C, (int64_t)T * C, o16, C, (int64_t)T * C, B, T, heads, C / heads, scale,
-                                 lengths, c.prec, c.stream);
+                                 rel_k, rel_v, window, lengths, c.prec, c.stream);
     });
 }
 
@@ -405,28 +406,44 @@ void prior_fwd(Ctx& c, const svcmi_synth_model& m, const svcmi_synth_io& io, flo
     float* yo = c.ar.f((int64_t)B * T * H);
     float* hf = c.ar.f((int64_t)B * T * F);
     float* slabs = c.ar.f((int64_t)B * f2_split * T * H);
+    // bf16 / f16 modes: 16-bit activation copies from the producers (the LayerNorms, the attention, the ReLU epilogue) for the _A16
+    // GEMMs -- which only take over where a launch is large enough (B = 16: all of them; one clip: none) -- and the attention itself on
+    // the 16-bit matrix cores from the QKV projection's 16-bit output copy (head widths the kernel has: 32 and 96)
+    const int hd = H / m.n_heads;
+    const bool a16 = mode16(c.prec) && H % 8 == 0 && F % 8 == 0;
+    const bool att16 = a16 && (hd == 96 || hd == 32) && m.enc_window <= 4;
+    void* x16 = a16 ? c.ar.take((int64_t)B * T * H * 2) : nullptr;
+    void* at16 = a16 ? c.ar.take((int64_t)B * T * H * 2) : nullptr;
+    void* hf16 = a16 ? c.ar.take((int64_t)B * T * F * 2) : nullptr;
+    void* qkv16 = att16 ? c.ar.take((int64_t)B * T * 3 * H * 2) : nullptr;
     float *x = xa, *x2 = xb;
     for (int i = 0; i < m.n_enc; ++i) {
         const svcmi_enc_layer& L = m.enc[i];
         CV v; v.B = B; v.t_in = T; v.c_in = v.ldx = H; v.x_bs = (int64_t)T * H;
-        { CV q = v; q.x = x; q.w = &L.qkv; q.y = qkv; q.y_bs = (int64_t)T * 3 * H; q.ldy = 3 * H; conv(c, q); }
-        attention(c, qkv, att, B, T, m.n_heads, H, scale, L.rel_k, L.rel_v, m.enc_window, io.lengths);
-        { CV o = v; o.x = att; o.w = &L.o; o.y = yo; o.y_bs = (int64_t)T * H; o.ldy = H; conv(c, o); }
-        layernorm(c, x, yo, L.g1, L.b1, x2, B, T, H, H, H, H, 0);
         {
-            CV f = v; f.x = x2; f.w = &L.f1; f.ksize = kf; f.pad = pl; f.act = SVCMI_ACT_RELU; f.lengths = io.lengths; f.mask_in = f.mask_out = true;
-            f.y = hf; f.y_bs = (int64_t)T * F; f.ldy = F;
+            CV q = v; q.x = x; q.x16 = i > 0 ? x16 : nullptr; q.w = &L.qkv; q.y = qkv; q.y_bs = (int64_t)T * 3 * H; q.ldy = 3 * H;
+            if (att16) { q.y16 = qkv16; q.split_k = 1; }
+            conv(c, q);
+        }
+        if (att16) attention16(c, qkv16, att, at16, B, T, m.n_heads, H, scale, io.lengths, L.rel_k, L.rel_v, m.enc_window);
+        else attention(c, qkv, att, B, T, m.n_heads, H, scale, L.rel_k, L.rel_v, m.enc_window, io.lengths, at16);
+        { CV o = v; o.x = att; o.x16 = at16; o.w = &L.o; o.y = yo; o.y_bs = (int64_t)T * H; o.ldy = H; conv(c, o); }
+        layernorm(c, x, yo, L.g1, L.b1, x2, B, T, H, H, H, H, 0, x16);
+        {
+            CV f = v; f.x = x2; f.x16 = x16; f.w = &L.f1; f.ksize = kf; f.pad = pl; f.act = SVCMI_ACT_RELU; f.lengths = io.lengths; f.mask_in = f.mask_out = true;
+            f.y = hf; f.y_bs = (int64_t)T * F; f.ldy = F; f.y16 = hf16;
+            if (a16) f.split_k = 1;
             conv(c, f);
         }
         // second FFN convolution: raw split-K slabs -> one launch that sums them with the bias and the residual and applies
         // norm_layers_2 (the `* x_mask` of attentions.py:209 only affects rows past the length, which no valid row ever reads:
         // keys are masked in the attention, inputs in the convolutions)
         {
-            CV f = v; f.x = hf; f.c_in = f.ldx = F; f.x_bs = (int64_t)T * F; f.w = &L.f2; f.bias = false; f.ksize = kf; f.pad = pl;
+            CV f = v; f.x = hf; f.x16 = hf16; f.c_in = f.ldx = F; f.x_bs = (int64_t)T * F; f.w = &L.f2; f.bias = false; f.ksize = kf; f.pad = pl;
             f.slabs = slabs; f.split_k = f2_split;
             conv(c, f);
         }
-        splitk_layernorm(c, slabs, f2_split, L.f2.bias, x2, L.g2, L.b2, x, B, T, H);
+        splitk_layernorm(c, slabs, f2_split, L.f2.bias, x2, L.g2, L.b2, x, B, T, H, x16);
     }
     float* stats = qkv;            // [B][T][2I] (2I <= 3H checked by the caller)
     {

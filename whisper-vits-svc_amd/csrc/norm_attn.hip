@@ -904,9 +904,21 @@ struct Attn16Args {
     float scale;
     const int32_t* lengths;
     int o16_f16;
+    const float* rel_k; const float* rel_v;      // REL instantiations: the relative-position band of vits/attentions.py:225-347 (fp32 tables)
+    int window;
 };
 
-template <int D, int QT, int KS, bool F16>
+template <bool F16>
+__device__ __forceinline__ float h16_to_f32(unsigned h) {       // low 16 bits of h
+#ifdef SVCMI_EMU
+    return F16 ? emu_f16_f32(h & 0xffffu) : emu_bf16_f32(h & 0xffffu);
+#else
+    if constexpr (F16) return (float)__builtin_bit_cast(_Float16, (unsigned short)(h & 0xffffu));
+    else return svcmi_bits_f32(h << 16);
+#endif
+}
+
+template <int D, int QT, int KS, bool F16, bool REL = false>
 __global__ __launch_bounds__(64 * QT * KS) void attention16_kernel(Attn16Args p) {
     constexpr int DS = D / 16, DK = D / 32, OLD = D + 4, NW = QT * KS, NT = 64 * NW, QB = 16 * QT;
     constexpr int KLD = D / 2 + 4;                      // K tile row stride in floats: D 16-bit values + 16 bytes
@@ -914,8 +926,11 @@ __global__ __launch_bounds__(64 * QT * KS) void attention16_kernel(Attn16Args p)
     constexpr int VGS = (D + 16) * 2;                   // floats per key group of the transposed V tile: (D + 16) units of 4 keys x 2 bytes
     constexpr int VT = 8 * VGS;                         // floats per V tile (8 key groups)
     constexpr int STAGE = KS * 2 * (KT + VT);           // [ks][buffer][K | V]
-    constexpr int MERGE = NW * 16 * OLD + 2 * NW * 16;
-    __shared__ __attribute__((aligned(16))) float smem[STAGE > MERGE ? STAGE : MERGE];
+    constexpr int MERGE = NW * 16 * OLD + 2 * NW * 16 + (REL ? NW * 16 * BST : 0);
+    constexpr int MAIN = STAGE > MERGE ? STAGE : MERGE;
+    __shared__ __attribute__((aligned(16))) float smem[MAIN + (REL ? 2 * NREL * D : 0)];
+    float* const Ek = smem + MAIN;                      // [NREL][D]  (REL only; never aliased by the tiles / the merge state)
+    float* const Ev = Ek + NREL * D;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = SVCMI_UNIFORM((int)(tid >> 6));
@@ -933,12 +948,37 @@ __global__ __launch_bounds__(64 * QT * KS) void attention16_kernel(Attn16Args p)
     const int len = p.lengths ? p.lengths[b] : T;
     const float scale2 = p.scale * LOG2E;
     const int q0 = qg * QB + 16 * qt_l, qi = q0 + lq;
+    const int W = REL ? p.window : 0;
+    const int nrel = REL ? 2 * W + 1 : 0;
 
     svcmi_u32x4 qf[DK];
     {
         const unsigned short* qp = p.q + (long long)b * p.bs16 + (long long)(qi < T ? qi : T - 1) * p.ld16 + h * D + 8 * g4;
 #pragma unroll
         for (int s = 0; s < DK; ++s) qf[s] = *reinterpret_cast<const svcmi_u32x4*>(qp + 32 * s);
+    }
+    // relative-position band (vits/attentions.py:225-347): R[e] = q . E_k[e] per query (from the 16-bit q the matrix cores see), added to
+    // the <= 2W + 1 in-band scores of diagonal tiles; Pb[e] collects the in-band probabilities so that sum_e Pb[e] E_v[e] is added in the merge
+    float R[REL ? NREL : 1], Pb[REL ? NREL : 1];
+    if constexpr (REL) {
+        for (int i = tid; i < nrel * D; i += NT) { Ek[i] = p.rel_k[i]; Ev[i] = p.rel_v[i]; }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < NREL; ++e) {
+            R[e] = 0.f; Pb[e] = 0.f;
+            if (e < nrel) {           // wave-uniform
+                float a = 0.f;
+#pragma unroll
+                for (int s2 = 0; s2 < DK; ++s2)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int d = 8 * g4 + 32 * s2 + 2 * j;
+                        a = fmaf(h16_to_f32<F16>(qf[s2][j]), Ek[e * D + d], a);
+                        a = fmaf(h16_to_f32<F16>(qf[s2][j] >> 16), Ek[e * D + d + 1], a);
+                    }
+                R[e] = quarter_sum(a);
+            }
+        }
     }
     svcmi_f32x4 oacc[DS];
 #pragma unroll
@@ -1013,6 +1053,7 @@ __global__ __launch_bounds__(64 * QT * KS) void attention16_kernel(Attn16Args p)
             sacc[1] = svcmi_mfma16_16x16x32<F16>(a1, qf[s], sacc[1]);
         }
         const bool clean = kt + 32 <= (len < T ? len : T) && q0 + 16 <= len;     // wave-uniform
+        const bool diag = REL && (kt + 31 >= q0 - W) && (kt <= q0 + 15 + W);       // wave-uniform: this step touches the band
         float sv[2][4];
         float mt = NEG_BIG;
 #pragma unroll
@@ -1020,7 +1061,17 @@ __global__ __launch_bounds__(64 * QT * KS) void attention16_kernel(Attn16Args p)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = kt + 16 * u + 4 * g4 + r;
-                float a = sacc[u][r] * scale2;
+                float a = sacc[u][r];
+                if constexpr (REL) {
+                    if (diag) {
+                        const int rel = key - qi + W;
+                        float add = 0.f;
+#pragma unroll
+                        for (int e = 0; e < NREL; ++e) add = (rel == e && e < nrel) ? R[e] : add;
+                        a += add;
+                    }
+                }
+                a *= scale2;
                 if (!clean) {
                     if (qi >= len || key >= len) a = MASKED2;       // masked_fill(mask == 0, -1e4)
                     if (key >= T) a = NEG_BIG;                      // beyond the sequence: weight 0
@@ -1046,6 +1097,20 @@ __global__ __launch_bounds__(64 * QT * KS) void attention16_kernel(Attn16Args p)
                 pv[u][r] = mnew > -1.0e38f ? svcmi_exp2(sv[u][r] - mnew) : 0.f;
                 lrun += pv[u][r];
             }
+        if constexpr (REL) {
+#pragma unroll
+            for (int e = 0; e < NREL; ++e) Pb[e] *= corr;
+            if (diag) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int rel = kt + 16 * u + 4 * g4 + r - qi + W;
+#pragma unroll
+                        for (int e = 0; e < NREL; ++e) Pb[e] += (rel == e && e < nrel) ? pv[u][r] : 0.f;
+                    }
+            }
+        }
         svcmi_u32x4 pf;         // contraction slot (g, e): e < 4 -> key 4g + e of the first 16-key tile, else key 4g + e - 4 of the second
         pf[0] = F16 ? svcmi_cvt_pk_f16(pv[0][0], pv[0][1]) : svcmi_cvt_pk_bf16(pv[0][0], pv[0][1]);
         pf[1] = F16 ? svcmi_cvt_pk_f16(pv[0][2], pv[0][3]) : svcmi_cvt_pk_bf16(pv[0][2], pv[0][3]);
@@ -1067,7 +1132,12 @@ __global__ __launch_bounds__(64 * QT * KS) void attention16_kernel(Attn16Args p)
     float* const Opart = smem;
     float* const Mpart = Opart + NW * 16 * OLD;
     float* const Lpart = Mpart + NW * 16;
+    float* const Bpart = Lpart + NW * 16;                  // [NW][16][BST]  (REL)
     lrun = quarter_sum(lrun);
+    if constexpr (REL) {
+#pragma unroll
+        for (int e = 0; e < NREL; ++e) Pb[e] = quarter_sum(Pb[e]);
+    }
     {
         float* orow = Opart + (w * 16 + lq) * OLD + 4 * g4;
 #pragma unroll
@@ -1076,6 +1146,10 @@ __global__ __launch_bounds__(64 * QT * KS) void attention16_kernel(Attn16Args p)
         if (g4 == 0) {
             Mpart[w * 16 + lq] = mrun;
             Lpart[w * 16 + lq] = lrun;
+            if constexpr (REL) {
+#pragma unroll
+                for (int e = 0; e < NREL; ++e) Bpart[(w * 16 + lq) * BST + e] = Pb[e];
+            }
         }
     }
     __syncthreads();
@@ -1087,6 +1161,9 @@ __global__ __launch_bounds__(64 * QT * KS) void attention16_kernel(Attn16Args p)
         for (int k2 = 0; k2 < KS; ++k2) mall = fmaxf(mall, Mpart[(k2 * QT + qtl) * 16 + ql]);
         float den = 0.f;
         float4 num = make_float4(0.f, 0.f, 0.f, 0.f);
+        float bs[REL ? NREL : 1];
+#pragma unroll
+        for (int e = 0; e < (REL ? NREL : 1); ++e) bs[e] = 0.f;
 #pragma unroll
         for (int k2 = 0; k2 < KS; ++k2) {
             const int ww = k2 * QT + qtl;
@@ -1096,6 +1173,20 @@ __global__ __launch_bounds__(64 * QT * KS) void attention16_kernel(Attn16Args p)
             const float4 ov = *reinterpret_cast<const float4*>(Opart + (ww * 16 + ql) * OLD + c4);
             num.x = fmaf(cw, ov.x, num.x); num.y = fmaf(cw, ov.y, num.y);
             num.z = fmaf(cw, ov.z, num.z); num.w = fmaf(cw, ov.w, num.w);
+            if constexpr (REL) {
+#pragma unroll
+                for (int e = 0; e < NREL; ++e) bs[e] = fmaf(cw, Bpart[(ww * 16 + ql) * BST + e], bs[e]);
+            }
+        }
+        if constexpr (REL) {
+#pragma unroll
+            for (int e = 0; e < NREL; ++e) {
+                if (e < nrel) {
+                    const float4 ev = *reinterpret_cast<const float4*>(Ev + e * D + c4);
+                    num.x = fmaf(bs[e], ev.x, num.x); num.y = fmaf(bs[e], ev.y, num.y);
+                    num.z = fmaf(bs[e], ev.z, num.z); num.w = fmaf(bs[e], ev.w, num.w);
+                }
+            }
         }
         const int qrow = qg * QB + qr;
         if (qrow < T) {
@@ -1107,6 +1198,29 @@ __global__ __launch_bounds__(64 * QT * KS) void attention16_kernel(Attn16Args p)
 }
 
 int g_attn16 = 0;       // tuning knob ("attn16", 0 = heuristic | 10 * QT + KS): block shape of attention16_kernel
+
+// the relative-position variant (prior encoder: 2 heads x 96): few (head, query group) pairs, so the shapes trade query tiles for key ranges
+template <int D, bool F16>
+int launch_attn16_rel(const Attn16Args& a_in, int batch, void* stream) {
+    Attn16Args a = a_in;
+    int code = g_attn16;
+    if (!code) {
+        const long long pairs2 = (long long)((a.t + 31) / 32) * a.heads * batch;       // blocks at 2 query tiles each
+        code = a.t < 128 ? 21 : (pairs2 >= 512 ? 42 : (pairs2 >= 128 ? 24 : 14));
+    }
+    const int qt = code / 10;
+    a.nq = (a.t + 16 * qt - 1) / (16 * qt);
+    dim3 g((unsigned)((long long)a.nq * a.heads * batch));
+    switch (code) {
+        case 21: SVCMI_LAUNCH((attention16_kernel<D, 2, 1, F16, true>), g, dim3(64 * 2), 0, stream, a); break;
+        case 24: SVCMI_LAUNCH((attention16_kernel<D, 2, 4, F16, true>), g, dim3(64 * 8), 0, stream, a); break;
+        case 14: SVCMI_LAUNCH((attention16_kernel<D, 1, 4, F16, true>), g, dim3(64 * 4), 0, stream, a); break;
+        case 42: SVCMI_LAUNCH((attention16_kernel<D, 4, 2, F16, true>), g, dim3(64 * 8), 0, stream, a); break;
+        case 44: SVCMI_LAUNCH((attention16_kernel<D, 4, 4, F16, true>), g, dim3(64 * 16), 0, stream, a); break;
+        default: return SVCMI_EINVAL;
+    }
+    return SVCMI_LAST_ERROR();
+}
 
 template <int D, bool F16>
 int launch_attn16(const Attn16Args& a_in, int batch, void* stream) {
@@ -1297,10 +1411,13 @@ extern "C" int svcmi_attention_f32(const float* q, const float* k, const float* 
 
 extern "C" int svcmi_attention16(const void* q, const void* k, const void* v, int32_t ld16, int64_t bstride16, float* o, int32_t ldo,
                                  int64_t o_bstride, void* o16, int32_t ldo16, int64_t o16_bstride, int32_t batch, int32_t t, int32_t heads,
-                                 int32_t head_dim, float scale, const int32_t* lengths, int32_t format, void* stream) {
+                                 int32_t head_dim, float scale, const float* rel_k, const float* rel_v, int32_t window,
+                                 const int32_t* lengths, int32_t format, void* stream) {
     if (!q || !k || !v || (!o && !o16) || batch <= 0 || t <= 0 || heads <= 0) return SVCMI_EINVAL;
     if (format != SVCMI_PREC_BF16 && format != SVCMI_PREC_F16) return SVCMI_EINVAL;
-    if (head_dim != 32 && head_dim != 64) return SVCMI_EUNSUPPORTED;
+    if ((rel_k == nullptr) != (rel_v == nullptr)) return SVCMI_EINVAL;
+    if (rel_k && (window < 0 || window > MAXW)) return SVCMI_EUNSUPPORTED;
+    if (rel_k ? (head_dim != 32 && head_dim != 96) : (head_dim != 32 && head_dim != 64)) return SVCMI_EUNSUPPORTED;
     if (ld16 % 8 || bstride16 % 8 || ((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15)) return SVCMI_EALIGN;
     if (o && (ldo % 4 || o_bstride % 4 || ((uintptr_t)o & 15))) return SVCMI_EALIGN;
     if (o16 && (ldo16 % 4 || o16_bstride % 4 || ((uintptr_t)o16 & 7))) return SVCMI_EALIGN;
@@ -1309,6 +1426,11 @@ extern "C" int svcmi_attention16(const void* q, const void* k, const void* v, in
     a.q = static_cast<const unsigned short*>(q); a.k = static_cast<const unsigned short*>(k); a.v = static_cast<const unsigned short*>(v);
     a.o = o; a.o16 = static_cast<unsigned short*>(o16); a.ld16 = ld16; a.ldo = ldo; a.ldo16 = ldo16; a.bs16 = bstride16; a.o_bs = o_bstride;
     a.o16_bs = o16_bstride; a.t = t; a.heads = heads; a.nq = 0; a.scale = scale; a.lengths = lengths; a.o16_f16 = format == SVCMI_PREC_F16;
+    a.rel_k = rel_k; a.rel_v = rel_v; a.window = window;
+    if (rel_k) {
+        if (format == SVCMI_PREC_F16) return head_dim == 96 ? launch_attn16_rel<96, true>(a, batch, stream) : launch_attn16_rel<32, true>(a, batch, stream);
+        return head_dim == 96 ? launch_attn16_rel<96, false>(a, batch, stream) : launch_attn16_rel<32, false>(a, batch, stream);
+    }
     if (format == SVCMI_PREC_F16) return head_dim == 64 ? launch_attn16<64, true>(a, batch, stream) : launch_attn16<32, true>(a, batch, stream);
     return head_dim == 64 ? launch_attn16<64, false>(a, batch, stream) : launch_attn16<32, false>(a, batch, stream);
 }
@@ -1327,7 +1449,8 @@ extern "C" int svcmi_attn_tune_set(const char* name, int32_t value) {
     const char* k5 = "attn16";
     i = 0;
     while (k5[i] && name[i] == k5[i]) ++i;
-    if (k5[i] == 0 && name[i] == 0 && (value == 0 || value == 41 || value == 42 || value == 44 || value == 81 || value == 82)) { g_attn16 = value; return 0; }
+    if (k5[i] == 0 && name[i] == 0 && (value == 0 || value == 14 || value == 21 || value == 24 || value == 41 || value == 42 || value == 44 ||
+                                       value == 81 || value == 82)) { g_attn16 = value; return 0; }
     const char* k2 = "attn_q32";
     i = 0;
     while (k2[i] && name[i] == k2[i]) ++i;

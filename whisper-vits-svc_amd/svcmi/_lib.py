@@ -121,7 +121,7 @@ SIGNATURES = {
     "svcmi_channel_norm_gelu_f32": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "svcmi_splitk_layernorm_f32": (c_int, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _I, _I, _P]),
     "svcmi_attention_f32": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _I, _I, _I, _I, _F, _P, _P, _I, _P, _P, _I, _L, _I, _P]),
-    "svcmi_attention16": (c_int, [_P, _P, _P, _I, _L, _P, _I, _L, _P, _I, _L, _I, _I, _I, _I, _F, _P, _I, _P]),
+    "svcmi_attention16": (c_int, [_P, _P, _P, _I, _L, _P, _I, _L, _P, _I, _L, _I, _I, _I, _I, _F, _P, _P, _I, _P, _I, _P]),
     "svcmi_snake_alias_f32": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "svcmi_snake_conv_supported": (c_int, [_I, _I, _I, _I]),
     "svcmi_snake_conv_preferred": (c_int, [_I, _I, _I, _I]),

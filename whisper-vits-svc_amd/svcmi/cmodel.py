@@ -71,10 +71,10 @@ def synth_cmodel(w, ops, prec=PREC_F32):
     m.pit_emb = w.pit_emb.data_ptr()
     for i, L in enumerate(w.enc):
         e = m.enc[i]
-        W(e.qkv, L["qkv_w"], L["qkv_b"])
-        W(e.o, L["o_w"], L["o_b"])
-        W(e.f1, L["f1_w"], L["f1_b"])
-        W(e.f2, L["f2_w"], L["f2_b"])
+        W(e.qkv, L["qkv_w"], L["qkv_b"], a16=True)          # (16-bit activations from LayerNorm / attention / the ReLU epilogue in the bf16 / f16 modes)
+        W(e.o, L["o_w"], L["o_b"], a16=True)
+        W(e.f1, L["f1_w"], L["f1_b"], a16=True)
+        W(e.f2, L["f2_w"], L["f2_b"], a16=True)
         e.rel_k, e.rel_v = L["rel_k"].data_ptr(), L["rel_v"].data_ptr()
         e.g1, e.b1, e.g2, e.b2 = (L[k].data_ptr() for k in ("g1", "b1", "g2", "b2"))
     for i, L in enumerate(w.flow):

@@ -424,17 +424,18 @@ class Ops:
                    work={"flops": 4.0 * B * T * T * Cc})
         return out if out16 is None else (out, o16)
 
-    def attention16(self, qkv16, heads, scale, *, lengths=None, want_f32=True):
+    def attention16(self, qkv16, heads, scale, *, rel_k=None, rel_v=None, window=0, lengths=None, want_f32=True):
         """qkv16: [B, T, 3*C] bf16 / float16 fused projection (the 16-bit output copy of the QKV GEMM).  Attention on the 16-bit matrix
         cores (svcmi_attention16); returns (o fp32 [B,T,C] or None, o16 [B,T,C] in qkv16's dtype)."""
-        self._chk(qkv16, lengths)
+        self._chk(qkv16, lengths, rel_k, rel_v)
         B, T, C3 = qkv16.shape
         Cc = C3 // 3
         o = torch.empty(B, T, Cc, dtype=torch.float32, device=qkv16.device) if want_f32 else None
         o16 = torch.empty(B, T, Cc, dtype=qkv16.dtype, device=qkv16.device)
         base, esz = qkv16.data_ptr(), 2
         self._call("svcmi_attention16", base, base + esz * Cc, base + 2 * esz * Cc, C3, qkv16.stride(0), _ptr(o), Cc, T * Cc, _ptr(o16), Cc, T * Cc,
-                   B, T, heads, Cc // heads, scale, _ptr(lengths), _fmt16(qkv16.dtype), self._stream(), work={"flops": 4.0 * B * T * T * Cc})
+                   B, T, heads, Cc // heads, scale, _ptr(rel_k), _ptr(rel_v), window, _ptr(lengths), _fmt16(qkv16.dtype), self._stream(),
+                   work={"flops": 4.0 * B * T * T * Cc})
         return o, o16
 
     # ------------------------------------------------------------------ generator pieces
