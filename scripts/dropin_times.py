@@ -75,6 +75,11 @@ def main():
                      ("f0", lambda: PI.compute_f0_sing(wav, dev, model=crepe))):
         ms, _ = timed(fn)
         print(f"   {name}: {ms:6.2f} ms")
+    for nb in (512, 1024, 2048):
+        PI.NET_BATCH = nb
+        ms, _ = timed(lambda: PI.compute_f0_sing(wav, dev, model=crepe))
+        print(f"   f0 with network batches of {nb} frames: {ms:6.2f} ms")
+    PI.NET_BATCH = int(os.environ.get("SVCMI_F0_BATCH", PI.NET_BATCH))
     ms_b, out = timed(wav2wav)
     print(f"wav -> wav (3 extractors in flight, CREPE {f0_prec}, fp32 elsewhere): {ms_b:7.2f} ms per {secs:g} s clip = {secs * 1e3 / ms_b:6.0f}x real time "
           f"(out {out.shape})")

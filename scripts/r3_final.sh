@@ -16,3 +16,14 @@ for C in 2 3 4; do timeout 900 python bench.py --config $C > $OUT/bench_c$C.json
 timeout 600 python bench.py --config 2 --precision f16 > $OUT/bench_c2_f16.json 2>/dev/null; show $OUT/bench_c2_f16.json
 timeout 600 python bench.py --config 3 --precision bf16x3 --no-roofline > $OUT/bench_c3_bf16x3.json 2>/dev/null; show $OUT/bench_c3_bf16x3.json
 timeout 600 python scripts/dropin_times.py 10 bf16x3 > $OUT/dropin_times.log 2>&1; tail -9 $OUT/dropin_times.log
+# two ranks on the one GPU (gloo: RCCL refuses duplicate devices): the N > 1 code path of bench.py (packed broadcast -> views -> C model structs)
+SVCMI_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 6 --warmup 2 --no-roofline > $OUT/bench_2ranks_1gpu.json 2> $OUT/bench_2ranks_1gpu.err; echo "2 ranks rc=$?"; show $OUT/bench_2ranks_1gpu.json
+# rocprofv3 kernel stats + PMC of the f16 line (16-bit activations, f16 attention)
+cd /tmp
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_f16 -o trace -- python $ROOT/bench.py --precision f16 --inflight 1 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/prof_f16_bench.json 2> $OUT/prof_f16.err; echo "rocprof f16 rc=$?"
+cd $ROOT
+python scripts/prof_summary.py $OUT/prof_f16 $OUT/kernel_stats_f16.csv 11 > /dev/null 2>&1; head -16 $OUT/kernel_stats_f16.csv
+find $OUT/prof_f16 -name "*kernel_trace.csv" -delete
+BENCH_ARGS="--precision f16" bash scripts/pmc_bench.sh $TAG/pmc_f16
+python scripts/pmc_summary.py $OUT/pmc_f16 $OUT/pmc_f16.json 2>&1 | tail -6
+find $OUT -name "*counter_collection.csv" -delete

@@ -20,6 +20,7 @@ from ..ops import ACT_RELU, ACT_SIGMOID, Ops
 
 CENTS_PER_BIN, PITCH_BINS, SAMPLE_RATE, WINDOW_SIZE = 20, 360, 16000, 1024
 FRAME_LD = 1536          # 254 + 1024 + 258 floats: 384 rows of 4 samples
+NET_BATCH = 512          # frames per pass through the network in compute_f0_sing
 
 
 class Crepe:
@@ -177,7 +178,9 @@ def compute_f0_sing_begin(filename, device, model=None, noise=None, decoder="vit
     audio = audio.to(model.device)
     nz = torch.randn_like(audio) if noise is None else torch.as_tensor(noise, dtype=torch.float32).to(model.device)
     audio = audio + nz * 0.001
-    prob = model.probabilities(audio, hop=320, batch_size=512)
+    # (network batch: frames are independent, so its size only shapes the launches -- the reference's 512 is a memory bound; the Viterbi
+    #  decoder below restarts every 512 frames like crepe/core.py:683-686 whatever this is)
+    prob = model.probabilities(audio, hop=320, batch_size=NET_BATCH)
     on_device = decoder == "viterbi" and model.ops.on_gpu
     if on_device:      # the DP on the device (one block per 512-frame decoding batch)
         lt, band = _viterbi_constants(prob.device)
