@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SVCMI_ABI_VERSION 17
+#define SVCMI_ABI_VERSION 18
 
 enum svcmi_status { SVCMI_OK = 0, SVCMI_EINVAL = -1, SVCMI_EUNSUPPORTED = -2, SVCMI_EALIGN = -3 };
 
@@ -101,7 +101,7 @@ typedef struct svcmi_conv_desc {
     int32_t* counters;     /* optional: >= one int32 per output tile, ALL ZERO on entry (the library leaves them zero).  With it   */
     int64_t counters_len;  /* the slices are combined inside the GEMM launch by the last-arriving block of each tile (fixed slice */
                            /* order: still deterministic); without it a second kernel does the reduction.                         */
-    void* y16;             /* optional: a 16-bit copy of y (same values rounded to y16_format = SVCMI_PREC_BF16 | SVCMI_PREC_F16), element (b,t,n) */
+    void* y16;             /* optional: a 16-bit copy of y (same values rounded to y16_format = SVCMI_PREC_BF16 | SVCMI_PREC_F16 | _BF16X3 = split), element (b,t,n) */
     int64_t y16_bstride;   /* at y16 + b*y16_bstride + t*ldy16 + n (in 16-bit elements): the A operand of a following _A16 launch, written by    */
     int32_t ldy16;         /* THIS launch's epilogue instead of being rounded in that launch's registers.  Needs the float4 epilogue (n_out,    */
     int32_t y16_format;    /* ldy % 4 == 0, aligned operands), no split-K.                                                                       */
@@ -137,8 +137,11 @@ enum svcmi_precision { SVCMI_PREC_F32 = 0, SVCMI_PREC_BF16X3 = 1, SVCMI_PREC_BF1
                         * aligned, no x_row_shift) that the producing kernel wrote (y16 of a convolution, svcmi_splitk_layernorm_f32, svcmi_layernorm_f32,
                         * svcmi_attention_f32, svcmi_snake_alias_group_f32), so nothing is rounded in this launch's registers and the operand tile in LDS is
                         * half the size.  Same products as SVCMI_PREC_BF16 / _F16 (the same fp32 values, rounded the same way); the weight image is packed
-                        * by svcmi_pack_weights_lp with the _A16 code (natural k order instead of the permuted order of the other modes). */
-                       SVCMI_PREC_BF16_A16 = 4, SVCMI_PREC_F16_A16 = 5 };
+                        * by svcmi_pack_weights_lp with the _A16 code (natural k order instead of the permuted order of the other modes).
+                        * SVCMI_PREC_BF16X3_A16: the split-bf16 products of SVCMI_PREC_BF16X3 on 16-bit activations: a row of d->x is [hi: ldx/2 values |
+                        * lo: ldx/2 values] (what the producers write for y16_format = SVCMI_PREC_BF16X3; ldx % 16 == 0, c_in <= ldx/2), the weight image
+                        * [hi row | lo row] in natural k order. */
+                       SVCMI_PREC_BF16_A16 = 4, SVCMI_PREC_F16_A16 = 5, SVCMI_PREC_BF16X3_A16 = 6 };
 int svcmi_pack_weights_lp(const float* w, int32_t n, int32_t ldw, int32_t precision, void* out, int32_t ldw16, void* stream);
 int svcmi_conv_gemm_lp(const svcmi_conv_desc* d, int32_t precision, void* stream);
 int svcmi_conv_gemm_group_lp(const svcmi_conv_desc* descs, int32_t count, int32_t precision, void* stream);
@@ -156,7 +159,8 @@ int svcmi_layernorm_f32(const float* x, const float* res, const float* gamma, co
                         int32_t gb_bstride, float eps, void* y16, int32_t ldy16, int32_t y16_format, void* stream);
 /* (y16 / ldy16 / y16_format here and below: an optional second output, the same rows rounded to bf16 / fp16 (SVCMI_PREC_BF16 |
  * SVCMI_PREC_F16) with leading dimension ldy16 in 16-bit elements -- the A operand of a following SVCMI_PREC_*_A16 convolution.
- * NULL = none.) */
+ * SVCMI_PREC_BF16X3: split rows, hi = bf16(v) at [c] and lo = bf16(v - hi) at [ldy16/2 + c] (ldy16 % 8 == 0, ldy16/2 >= the row
+ * length) for SVCMI_PREC_BF16X3_A16.  NULL = none.) */
 
 /* Per-channel normalisation over time + GELU: GroupNorm(num_groups = c, c) followed by exact-erf GELU, the first layer of
  * HuBERT's feature extractor (hubert/hubert_model.py:78,88): y[b,t,ch] = gelu((x[b,t,ch] - mean_t) / sqrt(var_t + eps) *
@@ -214,7 +218,8 @@ int svcmi_snake_alias_group_f32(const float* const* x, float* const* y, const fl
                                 const float* const* beta_log, const float* filt, int32_t count, int32_t batch,
                                 int32_t len, int32_t c, int32_t ld, void* const* y16, int32_t y16_format, void* stream);
 /* (y16 != NULL: tensor i is written as bf16 / fp16 rows (y16_format, same ld) to y16[i] INSTEAD of fp32 to y[i] -- the activation only
- * feeds the following convolution, which then runs as an SVCMI_PREC_*_A16 launch; y / y[i] may be NULL then.) */
+ * feeds the following convolution, which then runs as an SVCMI_PREC_*_A16 launch; y / y[i] may be NULL then.  y16_format =
+ * SVCMI_PREC_BF16X3: split rows of 2*ld values, [hi: ld | lo: ld].) */
 /* y[i] = ((xs[0][i] + xs[1][i]) + xs[2][i]) / count, count <= 3: the `xs / num_kernels` of vits_decoder/generator.py:188-194
  * when the AMP blocks ran side by side in grouped launches.  n % 4 == 0, 16-byte aligned pointers; y may alias xs[0]. */
 int svcmi_block_mean_f32(const float* const* xs, int32_t count, float* y, int64_t n, void* stream);
@@ -358,7 +363,9 @@ int svcmi_logmel_finish_f32(float* mel_power, float* scratch, float* out, int32_
  *                 because every per-frame length is even. */
 int svcmi_crepe_frames_f32(const float* audio, int64_t n, int32_t hop, int32_t frame0, int32_t frames, float* out, int32_t ld, void* stream);
 int svcmi_bn_maxpool2_f32(const float* x, const float* scale, const float* shift, float* y, int64_t rows_out, int32_t c,
-                          int32_t ldx, int32_t ldy, void* stream);
+                          int32_t ldx, int32_t ldy, void* y16, int32_t ldy16, int32_t y16_format, void* stream);
+/* (y16: optional 16-bit copy of the pooled rows for the next layer's SVCMI_PREC_*_A16 convolution, formats as for svcmi_layernorm_f32;
+ * y may be NULL when y16 is given.) */
 /* Viterbi decoding of the 360-bin pitch posteriorgram (crepe/decode.py:53-80; librosa.sequence.viterbi semantics: uniform
  * prior, log domain): prob [frames][360] = the network's sigmoid outputs; bins outside [minidx, maxidx) are excluded
  * (crepe/core.py:597-598); softmax over the rest in fp32, DP in fp64, independently per batch of `batch_frames` frames
@@ -561,6 +568,8 @@ int svcmi_copy2d_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t
  * kernel launch the host makes on the calling thread is bracketed by HIP events on its stream.  svcmi_trace_end waits for the last one and
  * fills `out` (up to `cap` records, in launch order); returns the number of launches seen.  Not for production use. */
 typedef struct svcmi_trace_record { int32_t op; float ms; double flops, bytes; } svcmi_trace_record;
+/* (op: bits 0-7 = the entry point, svcmi_trace_op_name(op); bits 8+ = the enum svcmi_precision code a reduced-precision GEMM launch ran
+ * with, so a test can tell an _A16 launch from one that rounds in registers) */
 int svcmi_trace_begin(int32_t max_records);
 int svcmi_trace_end(svcmi_trace_record* out, int32_t cap);
 const char* svcmi_trace_op_name(int32_t op);

@@ -37,7 +37,12 @@ def gemm(ops, tag, T, cin, n, k=1, dil=1, res=False, tiles=(0, 1, 2, 3), splits=
     r = torch.randn(B, T, n, generator=g).cuda() if res else None
     out = torch.empty(B, T, n, device="cuda")
     fl = 2.0 * B * T * n * k * cin
-    x16 = x.to({"f16": torch.float16, "bf16": torch.bfloat16}[prec]) if a16 else None      # the producer's 16-bit copy: _A16 kernels
+    x16 = None                                                                             # the producer's 16-bit copy: _A16 kernels
+    if a16 and prec == "bf16x3":                                                           # ... split rows [hi | lo]
+        hi = x.bfloat16()
+        x16 = torch.cat([hi, (x - hi.float()).bfloat16()], dim=-1).contiguous()
+    elif a16:
+        x16 = x.to({"f16": torch.float16, "bf16": torch.bfloat16}[prec])
     for tile in tiles:
         for sk in splits:
             try:
@@ -85,6 +90,18 @@ def main():
                 gemm(ops, "whisper_mlp1", T, 1280, 5120, tiles=(1, 9, 3), splits=(1,), prec="f16", a16=a16)
                 gemm(ops, "whisper_o", T, 1280, 1280, tiles=(1, 9), splits=(1, 2, 4), prec="f16", partials=True, a16=a16)
                 gemm(ops, "whisper_mlp2", T, 5120, 1280, tiles=(1, 9), splits=(1, 2, 4, 8), prec="f16", partials=True, a16=a16)
+    if "x3a" in what:         # split-bf16 products: in-register split (K-step 32) vs split activation rows from the producer (K-step 64)
+        for T in (500, 750):
+            for a16 in (False, True):
+                gemm(ops, "whisper_qkv", T, 1280, 3840, tiles=(1, 9, 3), splits=(1,), prec="bf16x3", a16=a16)
+                gemm(ops, "whisper_mlp1", T, 1280, 5120, tiles=(1, 9, 3), splits=(1,), prec="bf16x3", a16=a16)
+                gemm(ops, "whisper_o", T, 1280, 1280, tiles=(1, 9), splits=(2, 4), prec="bf16x3", partials=True, a16=a16)
+                gemm(ops, "whisper_mlp2", T, 5120, 1280, tiles=(1, 9), splits=(2, 4, 8), prec="bf16x3", partials=True, a16=a16)
+        for a16 in (False, True):
+            gemm(ops, "square4096", 4096, 4096, 4096, tiles=(9, 3), splits=(1,), prec="bf16x3", a16=a16)
+            gemm(ops, "crepe_l2_B512", 128, 1024, 128, k=64, tiles=(1, 9, 3), splits=(1,), B=512, prec="bf16x3", a16=a16)
+            gemm(ops, "crepe_l5_B512", 16, 128, 256, k=64, tiles=(1, 9, 3), splits=(1,), B=512, prec="bf16x3", a16=a16)
+    if "a16" in what:
         for a16 in (False, True):
             gemm(ops, "square4096", 4096, 4096, 4096, tiles=(9, 3), splits=(1,), prec="bf16", a16=a16)
             gemm(ops, "stage1_C80_B16", 20000, 80, 80, k=7, dil=3, res=True, tiles=(0,), splits=(1,), B=16, prec="bf16", a16=a16)

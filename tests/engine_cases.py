@@ -89,6 +89,8 @@ def check_generator_widths_against_oracle(ops, device, T=5, B=2, tol=TIGHT, prec
         assert trace.get("svcmi_conv_gemm_lp", {}).get("launches", 0) >= 20 and trace.get("svcmi_conv_gemm_group_lp", {}).get("launches", 0) >= 6, \
             f"reduced-precision kernels did not run: { {k: v['launches'] for k, v in trace.items()} }"
         assert errs["wave"] > 0.0
+        if precision in ("f16", "bf16"):      # the wide stages' grouped GEMMs read SnakeAlias's 16-bit rows
+            assert trace["svcmi_conv_gemm_group_lp"]["a16_launches"] >= 6, trace["svcmi_conv_gemm_group_lp"]
     assert errs["source"] <= 5e-5 and errs["wave"] <= min(tol * 5, WAVE_TOL), errs
     return errs
 
@@ -108,6 +110,10 @@ def check_whisper_golden(ops, device, tag, dims, tol=TIGHT, precision=None):
     ops.lp_min_flops = saved
     if precision is not None:
         assert trace.get("svcmi_conv_gemm_lp", {}).get("launches", 0) >= 4 * len(wm.weights.blocks), "reduced-precision kernels did not run"
+        # ... and the block GEMMs took their A operand as 16-bit rows from the producer (LayerNorm / attention / GELU epilogue);
+        # bf16x3: the QKV projection and MLP-down only (split rows)
+        per_block = 2 if precision == "bf16x3" else 4
+        assert trace["svcmi_conv_gemm_lp"]["a16_launches"] >= per_block * len(wm.weights.blocks), trace["svcmi_conv_gemm_lp"]
     err = maxerr(out, _t(g["ppg"]))
     assert err <= tol * max(1.0, float(np.abs(g["ppg"]).max())), err
     return err
@@ -246,6 +252,29 @@ def check_crepe_against_oracle(ops, device, capacity, n, tol=2e-5):
     same = np.isclose(f0, f0_ref, rtol=1e-5, atol=1e-3, equal_nan=True)
     assert same.mean() >= 0.98, float(same.mean())
     return err, float(same.mean())
+
+
+def check_crepe_precision(ops, device, capacity, n, precision, tol):
+    """CREPE posteriors in a reduced-precision mode vs the fp32 oracle: layers 2-6 read the 16-bit rows the pooling kernel wrote
+    (the _A16 GEMM kernels; bf16x3: split rows), error inside the mode's class."""
+    from oracle import crepe_oracle as CO
+    from svcmi._lib import PRECISIONS
+    from svcmi.pitch import load_crepe
+    sd = W.make_crepe_state(capacity)
+    m = load_crepe(sd, device, ops=ops)
+    m.precision = precision
+    audio = crepe_test_audio(n, 5)
+    saved, ops.lp_min_flops = ops.lp_min_flops, 0.0
+    got = m.probabilities(audio, hop=320)
+    ops.lp_min_flops = saved
+    with torch.no_grad():
+        want = CO.network(sd, CO.preprocess(audio[None], 320))
+    err = maxerr(got, want)
+    code = PRECISIONS[precision] + 2
+    for L in m.w.layers[1:]:
+        assert getattr(L["w"], "_svcmi_lp", {}).get(code) is not None, "the 16-bit-activation kernel did not run"
+    assert 0.0 < err <= tol, err
+    return err
 
 
 def check_crepe_golden(ops, device, tol=2e-5, precision=None):

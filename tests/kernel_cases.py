@@ -15,7 +15,7 @@ import torch.nn.functional as F
 from oracle import svc_oracle as O
 from workload import weights as W
 from svcmi import weights as PW
-from svcmi.ops import ACT_GELU, ACT_MISH, ACT_NONE, ACT_RELU, ACT_TANH
+from svcmi.ops import ACT_GELU, ACT_MISH, ACT_NONE, ACT_RELU, ACT_TANH, SPLIT16
 
 
 def _g(seed):
@@ -80,6 +80,12 @@ CONV_CASES_LP_SMALL = [
     dict(id="a16_bf16_vec_c24_masks_ktail", B=2, T=37, cin=24, n=20, k=5, pad=2, lengths=[37, 20], mask_in=True, mask_out=True, prec="bf16", a16=True),
     dict(id="a16_f16_128x128_splitk_partials", B=1, T=150, cin=256, n=140, k=1, prec="f16", a16=True, tile=3),
     dict(id="a16_f16_stride2_k3", B=1, T=81, cin=32, n=40, k=3, stride=2, pad=1, prec="f16", a16=True, out16=True),
+    dict(id="a16_x3_64x64_chunk_k1_out16", B=2, T=70, cin=128, n=72, k=1, prec="bf16x3", a16=True, out16=True, act=ACT_GELU),
+    dict(id="a16_x3_64x128_chunk_k3", B=1, T=90, cin=64, n=150, k=3, pad=1, prec="bf16x3", a16=True, tile=9, res=True),
+    dict(id="a16_x3_vec_c40_k11_d5_p16_out16", B=1, T=300, cin=40, n=40, k=11, dil=5, pad=25, res=True, prec="bf16x3", a16=True, tile=4, out16=True),
+    dict(id="a16_x3_vec_c24_masks_ktail", B=2, T=37, cin=24, n=20, k=5, pad=2, lengths=[37, 20], mask_in=True, mask_out=True, prec="bf16x3", a16=True),
+    dict(id="a16_x3_128x128_k1", B=1, T=150, cin=256, n=140, k=1, prec="bf16x3", a16=True, tile=3),
+    dict(id="a16_x3_stride2_k3_splitk", B=1, T=81, cin=96, n=40, k=3, stride=2, pad=1, prec="bf16x3", a16=True, split_k=3),
 ]
 CONV_CASES_LP_LARGE = [
     dict(id="lp_whisper_qkv_bf16x3", B=1, T=750, cin=1280, n=3840, k=1, prec="bf16x3"),
@@ -91,6 +97,9 @@ CONV_CASES_LP_LARGE = [
     dict(id="a16_whisper_qkv_f16", B=1, T=750, cin=1280, n=3840, k=1, prec="f16", a16=True),
     dict(id="a16_whisper_mlp1_gelu_out16_bf16", B=2, T=500, cin=1280, n=5120, k=1, prec="bf16", a16=True, out16=True, act=ACT_GELU),
     dict(id="a16_whisper_mlp2_f16_splitk4", B=1, T=500, cin=5120, n=1280, k=1, res=True, prec="f16", a16=True, split_k=4),
+    dict(id="a16_whisper_qkv_x3", B=1, T=750, cin=1280, n=3840, k=1, prec="bf16x3", a16=True),
+    dict(id="a16_whisper_mlp1_gelu_out16_x3", B=2, T=500, cin=1280, n=5120, k=1, prec="bf16x3", a16=True, out16=True, act=ACT_GELU),
+    dict(id="a16_whisper_mlp2_x3_splitk4", B=1, T=500, cin=5120, n=1280, k=1, res=True, prec="bf16x3", a16=True, split_k=4),
 ]
 CONV_CASES_LARGE = [
     dict(id="whisper_qkv", B=1, T=500, cin=1280, n=3840, k=1),
@@ -152,7 +161,10 @@ def check_conv(ops, c, device):
     launches, saved_min = ops.launches, ops.lp_min_flops
     ops.lp_min_flops = 0.0
     dt16 = {"f16": torch.float16, "bf16": torch.bfloat16}.get(prec)
-    x16 = xd.to(dt16) if c.get("a16") else None          # what a producing kernel's 16-bit output holds: the same values, rounded
+    x16 = xd.to(dt16) if c.get("a16") and dt16 else None          # what a producing kernel's 16-bit output holds: the same values, rounded
+    if c.get("a16") and prec == "bf16x3":                # ... or split into (hi, lo) bf16 planes: rows [hi: Cp | lo: Cp]
+        x16 = _split16(xd)
+        dt16 = SPLIT16
     with ops.use_precision(prec):
         y = ops.conv(xd, wp, dev(bias), ksize=k, stride=stride, dilation=dil, pad=pad, act=act, res=dev(res),
                      alpha=c.get("alpha", 1.0), accumulate=c.get("accumulate", False), lengths=dev(lengths),
@@ -163,12 +175,25 @@ def check_conv(ops, c, device):
     if prec is not None:
         assert getattr(wp, "_svcmi_lp", None), f"{c['id']}: the reduced-precision kernel did not run"
         if c.get("a16"):
-            assert wp._svcmi_lp.get(PRECISIONS[prec] + 2) is not None, f"{c['id']}: the 16-bit-activation kernel did not run"
+            a16_code = 6 if prec == "bf16x3" else PRECISIONS[prec] + 2
+            assert wp._svcmi_lp.get(a16_code) is not None, f"{c['id']}: the 16-bit-activation kernel did not run"
     if c.get("out16"):
         y, y16 = y
-        assert torch.equal(y16.cpu(), y.cpu().to(dt16)), f"{c['id']}: the 16-bit output copy is not the rounded fp32 output"
+        want16 = _split16(y.cpu()) if dt16 == SPLIT16 else y.cpu().to(dt16)
+        assert torch.equal(y16.cpu(), want16), f"{c['id']}: the 16-bit output copy is not the rounded fp32 output"
     assert y.shape == ref.shape
     _close(y, ref, 2e-5 if cin * k < 4096 else 1e-4, c["id"])
+
+
+def _split16(x):
+    """fp32 [..., C] -> the SPLIT16 layout [..., 2*Cp] (ops.SPLIT16): hi = bf16(x), lo = bf16(x - hi), zero pads."""
+    c = x.shape[-1]
+    cp = (c + 7) // 8 * 8
+    hi = x.bfloat16()
+    lo = (x - hi.float()).bfloat16()
+    out = torch.zeros(*x.shape[:-1], 2 * cp, dtype=torch.bfloat16, device=x.device)
+    out[..., :c], out[..., cp:cp + c] = hi, lo
+    return out
 
 
 def check_layernorm(ops, c, device):
@@ -559,6 +584,12 @@ def check_grouped_launches(ops, device, B=2, n=333, c=40, ld=40, prec=None):
     got = ops.snake_alias_group(xs, als, bes, filt, [torch.empty_like(x) for x in xs])
     for w_, g_ in zip(want, got):
         assert torch.equal(w_, g_)
+    if ld % 8 == 0:     # 16-bit-only outputs (the A operand of an _A16 GEMM): the fp32 result rounded / split
+        for dt in (torch.float16, torch.bfloat16, SPLIT16):
+            outs = [torch.empty(B, n, 2 * ld if dt == SPLIT16 else ld, dtype=torch.bfloat16 if dt == SPLIT16 else dt, device=device) for _ in xs]
+            got16 = ops.snake_alias_group(xs, als, bes, filt, outs)
+            for w_, g_ in zip(want, got16):
+                assert torch.equal(g_.cpu(), _split16(w_.cpu()) if dt == SPLIT16 else w_.cpu().to(dt)), dt
     ks, ds = (3, 7, 11), (1, 3, 5)
     ws = [PW.pack_conv(torch.randn(c, c, k, generator=g) / math.sqrt(c * k), ld, ld).to(device) for k in ks]
     bs = [torch.randn(ld, generator=g).to(device) for _ in ks]
@@ -727,25 +758,28 @@ def check_source2wav(ops, device):
 
 def check_outputs16(ops, device):
     """The optional 16-bit output copies of LayerNorm / split-K LayerNorm / attention (the A operands of the _A16 GEMMs): exactly the fp32
-    output rounded to the requested type."""
+    output rounded to the requested type, or split into (hi, lo) bf16 planes (SPLIT16)."""
     g = _g(99)
     B, T, c, H = 2, 37, 64, 2
     x, r = torch.randn(B, T, c, generator=g), torch.randn(B, T, c, generator=g)
     gamma, beta = torch.randn(c, generator=g), torch.randn(c, generator=g)
     d = lambda t: t.to(device)
-    for dt in (torch.float16, torch.bfloat16):
+    for dt in (torch.float16, torch.bfloat16, SPLIT16):
+        want = (lambda y: _split16(y.cpu())) if dt == SPLIT16 else (lambda y: y.cpu().to(dt))
         y, y16 = ops.layernorm(d(x), d(gamma), d(beta), res=d(r), out16=dt)
-        assert y16.dtype == dt and torch.equal(y16.cpu(), y.cpu().to(dt))
+        assert torch.equal(y16.cpu(), want(y))
         part = torch.randn(B, 3, T, c, generator=g)
         xs = d(x.clone())
         y, y16 = ops.splitk_layernorm(d(part), d(beta), xs, d(gamma), d(beta), out16=dt)
-        assert torch.equal(y16.cpu(), y.cpu().to(dt))
+        assert torch.equal(y16.cpu(), want(y))
         qkv = torch.randn(B, 70, 3 * H * 32, generator=g)
         o, o16 = ops.attention(d(qkv), H, 32 ** -0.5, out16=dt)
-        assert torch.equal(o16.cpu(), o.cpu().to(dt))
+        assert torch.equal(o16.cpu(), want(o))
         lens = torch.tensor([70, 41], dtype=torch.int32)
         o, o16 = ops.attention(d(qkv), H, 32 ** -0.5, lengths=d(lens), out16=dt)            # (another kernel shape: masked)
-        assert torch.equal(o16.cpu(), o.cpu().to(dt))
+        assert torch.equal(o16.cpu(), want(o))
+    y, y16 = ops.layernorm(d(x[..., :36].contiguous()), out16=SPLIT16)                      # a row length with pad columns (Cp = 40)
+    assert y16.shape[-1] == 80 and torch.equal(y16.cpu(), _split16(y.cpu()))
 
 
 # attention on the 16-bit matrix cores (svcmi_attention16): every block shape, ragged lengths, key ranges past T, both formats

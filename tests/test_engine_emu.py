@@ -34,6 +34,10 @@ def test_crepe_tiny_matches_oracle(ops):
     print(E.check_crepe_against_oracle(ops, "cpu", "tiny", n=1600))
 
 
+def test_crepe_tiny_f16_activation_chain(ops):
+    print(E.check_crepe_precision(ops, "cpu", "tiny", 1600, "f16", 2e-2))
+
+
 def test_svc_infer_with_knn_retrieval(ops):
     print(E.check_svc_infer_retrieval(ops, "cpu", T=10, check_changed=False))
 
@@ -58,6 +62,12 @@ def test_whisper_tiny_f16_operands(ops):
     """fp16 operands (what the reference's `.half()` accelerator path uses, whisper/inference.py:22-23) on the tiny encoder:
     error in the fp16 class, far from fp32's 1e-6 but bounded."""
     print(E.check_whisper_golden(ops, "cpu", "whisper_tiny", C.WHISPER_TINY_TEST, tol=2e-2, precision="f16"))
+
+
+def test_whisper_tiny_bf16x3_split_activations(ops):
+    """bf16x3 mode: the producers hand the GEMMs split (hi, lo) bf16 rows and the _BF16X3_A16 kernel runs -- same products as the
+    in-register split, fp32-class error."""
+    print(E.check_whisper_golden(ops, "cpu", "whisper_tiny", C.WHISPER_TINY_TEST, tol=1e-4, precision="bf16x3"))
 
 
 def test_outlier_stress_weights_whisper_and_generator(ops):

@@ -168,3 +168,13 @@ def test_extractors_in_bf16x3_match_the_reference_goldens(ops):
     e_c = E.check_crepe_golden(ops, "cuda", tol=1e-4, precision="bf16x3")
     REPORT["extractors_bf16x3"] = dict(hubert_units_max_abs=e_h, crepe_posterior_max_abs=e_c)
     print(f"bf16x3 extractors: hubert units err {e_h:.2e}, crepe posterior err {e_c:.2e}")
+
+
+@pytest.mark.parametrize("mode,tol", [("f16", 2e-2), ("bf16", 1e-1)])
+def test_crepe_full_16bit_activation_chain(ops, mode, tol):
+    """CREPE `full` on 3 s: layers 2-6 take the pooling kernel's 16-bit rows through the _A16 GEMM kernels; posterior error against
+    the fp32 oracle inside the mode's class."""
+    err = E.check_crepe_precision(ops, "cuda", "full", 48000, mode, tol)
+    REPORT.setdefault("crepe_a16", {})[mode] = err
+    print(f"crepe full {mode} (16-bit activation chain): posterior err {err:.2e}")
+

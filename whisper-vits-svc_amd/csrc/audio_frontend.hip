@@ -123,7 +123,7 @@ __global__ __launch_bounds__(TPB) void crepe_frames_kernel(const float* audio, l
 }
 
 __global__ __launch_bounds__(TPB) void bn_maxpool2_kernel(const float* x, const float* scale, const float* shift, float* y,
-                                                          long long rows_out, int c, int ldx, int ldy) {
+                                                          long long rows_out, int c, int ldx, int ldy, unsigned short* y16, int ldy16, int fmt16) {
     const int c4 = c >> 2;
     const long long total = rows_out * c4;
     for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
@@ -138,7 +138,8 @@ __global__ __launch_bounds__(TPB) void bn_maxpool2_kernel(const float* x, const 
         o.y = fmaxf(fmaf(a.y, sc.y, sh.y), fmaf(b.y, sc.y, sh.y));
         o.z = fmaxf(fmaf(a.z, sc.z, sh.z), fmaf(b.z, sc.z, sh.z));
         o.w = fmaxf(fmaf(a.w, sc.w, sh.w), fmaf(b.w, sc.w, sh.w));
-        *reinterpret_cast<float4*>(y + r * ldy + cc) = o;
+        if (y) *reinterpret_cast<float4*>(y + r * ldy + cc) = o;
+        if (y16) svcmi_store4_16(y16 + r * ldy16 + cc, ldy16 >> 1, o.x, o.y, o.z, o.w, fmt16);
     }
 }
 
@@ -341,13 +342,15 @@ extern "C" int svcmi_crepe_frames_f32(const float* audio, int64_t n, int32_t hop
 }
 
 extern "C" int svcmi_bn_maxpool2_f32(const float* x, const float* scale, const float* shift, float* y, int64_t rows_out, int32_t c,
-                                     int32_t ldx, int32_t ldy, void* stream) {
-    if (!x || !scale || !shift || !y || rows_out <= 0 || c <= 0) return SVCMI_EINVAL;
+                                     int32_t ldx, int32_t ldy, void* y16, int32_t ldy16, int32_t y16_format, void* stream) {
+    if (!x || !scale || !shift || (!y && !y16) || rows_out <= 0 || c <= 0) return SVCMI_EINVAL;
+    if (y16 && (svcmi_fmt16(y16_format) < 0 || !svcmi_fmt16_row_ok(y16_format, ldy16, c) || ((uintptr_t)y16 & 7))) return SVCMI_EINVAL;
     if (c % 4 || ldx % 4 || ldy % 4 || ((uintptr_t)x & 15) || ((uintptr_t)y & 15) || ((uintptr_t)scale & 15) || ((uintptr_t)shift & 15))
         return SVCMI_EALIGN;
     long long nb = (rows_out * (c / 4) + TPB - 1) / TPB;
     if (nb > 8192) nb = 8192;
-    SVCMI_LAUNCH(bn_maxpool2_kernel, dim3((unsigned)nb), dim3(TPB), 0, stream, x, scale, shift, y, (long long)rows_out, c, ldx, ldy);
+    SVCMI_LAUNCH(bn_maxpool2_kernel, dim3((unsigned)nb), dim3(TPB), 0, stream, x, scale, shift, y, (long long)rows_out, c, ldx, ldy,
+                 static_cast<unsigned short*>(y16), ldy16, y16 ? svcmi_fmt16(y16_format) : 0);
     return SVCMI_LAST_ERROR();
 }
 

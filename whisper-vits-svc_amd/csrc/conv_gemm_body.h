@@ -62,13 +62,16 @@ namespace {
 constexpr int BK = 32;
 enum { MODE_CHUNK = 0, MODE_VEC = 1, MODE_SCALAR = 2, MODE_CHUNK_RS = 3 };   // _RS: CHUNK with x_row_shift != 0
 
-enum { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_BF16 = 2, PREC_F16 = 3, PREC_BF16_A16 = 4, PREC_F16_A16 = 5 };   // == enum svcmi_precision
+enum { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_BF16 = 2, PREC_F16 = 3, PREC_BF16_A16 = 4, PREC_F16_A16 = 5, PREC_BF16X3_A16 = 6 };   // == enum svcmi_precision
 // _A16: the ACTIVATIONS arrive as a 16-bit tensor too (written by the producing kernel's epilogue) and the weight image is in natural
 // k order (svcmi_pack_weights_lp with an _A16 precision).  Both tiles then use the fp32 kernel's data movement unchanged -- rows of 128
 // bytes, eight 16-byte chunks XOR-swizzled by swz(row), 8 rows per 1-KiB DMA piece -- on 16-bit data: a K-step covers 64 k instead of
 // 32, a lane's ds_read_b128 fragment (8 consecutive k) feeds ONE 16-bit MFMA where the fp32 kernel issues four, and nothing is rounded
 // in registers.  Half the barriers / DMA issues / LDS bytes per FLOP of the plain 16-bit modes, and the same products (the same fp32
 // values rounded the same way by the producer).
+// BF16X3_A16: the same with BOTH operands as (hi, lo) bf16 pairs -- activation rows are [hi: ldx/2 values | lo: ldx/2 values] (a producer's
+// 16-bit output in format SVCMI_PREC_BF16X3), weight rows [hi | lo] in natural k order -- and three MFMAs per fragment pair
+// (hi*hi + lo*hi + hi*lo, fp32 accumulation): the products of PREC_BF16X3 without its in-register splitting, on 64-k K-steps.
 
 struct ConvArgs {
     const float* x; const float* w; const float* bias; const float* res; float* y; const int32_t* lengths;
@@ -81,7 +84,7 @@ struct ConvArgs {
     int ldw16;
     unsigned short* y16;         // optional 16-bit copy of the output (bf16 or f16, y16_f16), rows of ldy16 values: the next GEMM's A operand
     long long y16_bs;
-    int ldy16, y16_f16;
+    int ldy16, y16_f16;          // y16_f16: 0 bf16, 1 f16, 2 split bf16 (hi at [n], lo at [ldy16/2 + n])
     int vec;                     // 1: y / res / bias / workspace rows are 16-byte aligned multiples of 4 floats -> float4 epilogue
     int ktot;                    // ksize * c_in
     int split;                   // K slices (1 = none)
@@ -131,11 +134,7 @@ __device__ __forceinline__ void epilogue4(const ConvArgs& p, float4 v, const flo
         o[e] = masked ? 0.f : q;
     }
     *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-    if (dst16) {
-        unsigned* h = reinterpret_cast<unsigned*>(dst16);          // 8-byte aligned: n % 4 == 0, ldy16 % 4 == 0
-        h[0] = p.y16_f16 ? svcmi_cvt_pk_f16(o[0], o[1]) : svcmi_cvt_pk_bf16(o[0], o[1]);
-        h[1] = p.y16_f16 ? svcmi_cvt_pk_f16(o[2], o[3]) : svcmi_cvt_pk_bf16(o[2], o[3]);
-    }
+    if (dst16) svcmi_store4_16(dst16, p.ldy16 >> 1, o[0], o[1], o[2], o[3], p.y16_f16);          // 8-byte aligned: n % 4 == 0, ldy16 % 4 == 0
 }
 
 __device__ __forceinline__ int div_magic(int q, unsigned magic) {   // q / c_in, exact while q * c_in < 2^32
@@ -168,7 +167,9 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
     constexpr int KS = A16 ? 2 * BK : BK;             // k per K-step
     constexpr unsigned ESZ = A16 ? 2u : 4u;           // bytes per activation element
     constexpr bool F16OP = PREC == PREC_F16 || PREC == PREC_F16_A16;
-    constexpr int NB = PREC == PREC_BF16X3 ? 2 : 1;   // B images per stage (hi, lo)
+    constexpr bool X3A = PREC == PREC_BF16X3_A16;     // ... both as (hi, lo) bf16 pairs
+    constexpr int NB = (PREC == PREC_BF16X3 || X3A) ? 2 : 1;   // B images per stage (hi, lo)
+    constexpr int NA = X3A ? 2 : 1;                   // A images per stage
     constexpr int BM = 64 * WM, BN = P16 ? 16 * WN : 64 * WN;
     constexpr int BROW = LP ? BK / 2 : BK;            // floats per B row in LDS (LP: 32 x 2 bytes)
     constexpr int BNL = LP ? (BN + 63) / 64 * 64 : (BN + 31) / 32 * 32;   // B rows held in LDS (whole 4-wave DMA rounds)
@@ -178,12 +179,12 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
     // LDS ring of NST operand tiles (48 / 72 / 64 KiB per block): tile it+NST-1 is in flight while tile
     // `it` is consumed, so a K-step never waits a full HBM/L2 round trip -- what short K ranges (split-K slices,
     // the k=1 projections of the prior encoder / flow, k=3 convolutions) would otherwise pay on every step.
-    constexpr int NST = NSTO ? NSTO : (LP ? 3 : (P16 ? ((BM + BNL) > 192 ? 2 : 3) : ((WM * WN == 1) ? 3 : (WM * WN == 2 ? 3 : 2))));
-    constexpr int RING = NST * (BM * BK + NB * BTILE);
+    constexpr int NST = NSTO ? NSTO : X3A ? 2 : (LP ? 3 : (P16 ? ((BM + BNL) > 192 ? 2 : 3) : ((WM * WN == 1) ? 3 : (WM * WN == 2 ? 3 : 2))));
+    constexpr int RING = NST * (NA * BM * BK + NB * BTILE);
     static_assert(LP || A16 || BM * CLD <= RING, "C tile must fit in the operand buffers");
     __shared__ __attribute__((aligned(16))) float smem[(RING > BM * CLD ? RING : BM * CLD) + 4];   // + the split-K ticket word
-    float* const As0 = smem;                          // As[slot] = As0 + slot*BM*BK, rows of 32 floats, chunk-swizzled
-    float* const Bs0 = smem + NST * BM * BK;          // Bs[slot][image] = Bs0 + (slot*NB + image)*BTILE
+    float* const As0 = smem;                          // As[slot][image] = As0 + (slot*NA + image)*BM*BK, rows of 32 floats, chunk-swizzled
+    float* const Bs0 = smem + NST * NA * BM * BK;          // Bs[slot][image] = Bs0 + (slot*NB + image)*BTILE
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = SVCMI_UNIFORM((int)(tid >> 6));
@@ -277,7 +278,12 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
             a_koff = kk < p.ktot ? (unsigned)(tap_v * p.dil * p.ldx + ci_v) * ESZ : OOB;
         }
     };
-    auto stage_a = [&](int it, int buf, int i) {          // piece i of the A tile
+    auto stage_a = [&](int it, int buf, int i) {          // piece i of the A tile (X3A: i >= A_PER = the lo image)
+        if constexpr (X3A) {
+            const int im = i >= A_PER, ii = i - im * A_PER;
+            svcmi_bdma16(a_row[ii] + a_koff + (im ? (unsigned)p.ldx : 0u), svcmi_lds_advance(lds_a, (buf * NA + im) * BM * BK + 4 * ii * 8 * BK), xr);
+            return;
+        }
         const svcmi_ldsaddr dst = svcmi_lds_advance(lds_a, buf * BM * BK + 4 * i * 8 * BK);
         if (MODE == MODE_SCALAR) {
             // 4-byte DMA: a wave-instruction fills 2 rows (64 floats); the piece needs 4 of them.
@@ -312,23 +318,24 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
     const int frow = lane & (FR - 1), fhi = P16 ? (lane >> 4) : (lane >> 5);
     const int a_off = (wm * FR * WM + frow) * BK, b_off = (wn * FR * WN + frow) * BROW;
     // Fragment reads of sub-step s into (a4, b4).  `tie` is a register the MFMAs issued next consume.
-    auto load_frags = [&](const float* Ab, const float* Bb, int s, svcmi_f32x4 (&a4)[WM], svcmi_f32x4 (&b4)[WN], svcmi_f32x4& tie) {
+    constexpr int FA = NA * WM, FB = (X3A ? 2 : 1) * WN;      // fragments per sub-step (X3A: hi images first, then lo)
+    auto load_frags = [&](const float* Ab, const float* Bb, int s, svcmi_f32x4 (&a4)[FA], svcmi_f32x4 (&b4)[FB], svcmi_f32x4& tie) {
         const int pos = ((((P16 ? 4 : 2) * s + fhi) ^ swz(frow)) << 2);
 #pragma unroll
-        for (int i = 0; i < WM; ++i) svcmi_lds_read16(a4[i], Ab + i * FR * BK + pos, tie);
+        for (int i = 0; i < FA; ++i) svcmi_lds_read16(a4[i], Ab + (i / WM) * BM * BK + (i % WM) * FR * BK + pos, tie);
 #pragma unroll
-        for (int j = 0; j < WN; ++j) svcmi_lds_read16(b4[j], Bb + j * FR * BK + pos, tie);
+        for (int j = 0; j < FB; ++j) svcmi_lds_read16(b4[j], Bb + (j / WN) * BTILE + (j % WN) * FR * BK + pos, tie);
     };
     auto mma = [&](acc_t& c, float a, float b) {
         if constexpr (P16) c = svcmi_mfma_16x16x4(a, b, c);
         else c = svcmi_mfma_32x32x2(a, b, c);
     };
-    auto frags_arrive = [&](svcmi_f32x4 (&a4)[WM], svcmi_f32x4 (&b4)[WN]) {      // one s_waitcnt, every fragment pinned behind it
+    auto frags_arrive = [&](svcmi_f32x4 (&a4)[FA], svcmi_f32x4 (&b4)[FB]) {      // one s_waitcnt, every fragment pinned behind it
         svcmi_lds_arrive(a4[0]);
 #pragma unroll
-        for (int i = 1; i < WM; ++i) svcmi_lds_landed(a4[i]);
+        for (int i = 1; i < FA; ++i) svcmi_lds_landed(a4[i]);
 #pragma unroll
-        for (int j = 0; j < WN; ++j) svcmi_lds_landed(b4[j]);
+        for (int j = 0; j < FB; ++j) svcmi_lds_landed(b4[j]);
     };
     // Reduced precision.  Sub-step s of a K-step contracts the 16 (32x32x16: s = 0, 1) or all 32 (16x16x32) k of the step: the
     // lane reads 16-byte chunk q = 2s + (lane>>5) resp. lane>>4 of its 16-bit B row(s) and the fp32 A chunks q and q + 4.
@@ -377,15 +384,16 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
 
     // sub-steps per tile: fp32 4 x 8 k (32x32x2) or 2 x 16 k (16x16x4); 16-bit 2 x 16 k (32x32x16) or 1 x 32 k (16x16x32)
     constexpr int NSUB = LP ? (P16 ? 1 : 2) : (P16 ? BK / 16 : BK / 8);
-    constexpr int PIECES = A_PER + NB * B_PER;            // pieces per tile per wave ...
-    constexpr int DMAS = (MODE == MODE_SCALAR ? 4 * A_PER : A_PER) + NB * B_PER;   // ... and the DMA instructions they take
+    constexpr int APCS = NA * A_PER;
+    constexpr int PIECES = APCS + NB * B_PER;             // pieces per tile per wave ...
+    constexpr int DMAS = (MODE == MODE_SCALAR ? 4 * A_PER : APCS) + NB * B_PER;   // ... and the DMA instructions they take
     // prologue: tiles it_beg .. it_beg+NST-2 into slots 0 .. NST-2
 #pragma unroll
     for (int s0 = 0; s0 < NST - 1; ++s0) {
         if (it_beg + s0 < it_end) {
             stage_prep(it_beg + s0);
 #pragma unroll
-            for (int i = 0; i < A_PER; ++i) stage_a(it_beg + s0, s0, i);
+            for (int i = 0; i < APCS; ++i) stage_a(it_beg + s0, s0, i);
 #pragma unroll
             for (int i = 0; i < NB * B_PER; ++i) stage_b(s0, i);
         }
@@ -403,7 +411,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
         int nslot = slot + NST - 1;
         if (nslot >= NST) nslot -= NST;
         if (ISSUE) stage_prep(it + NST - 1);
-        const float* Ab = As0 + slot * BM * BK + a_off;
+        const float* Ab = As0 + slot * NA * BM * BK + a_off;
         const float* Bb = Bs0 + slot * NB * BTILE + b_off;
         svcmi_f32x4 tie0 = {0.f, 0.f, 0.f, 0.f};
         if constexpr (LP) {
@@ -447,23 +455,36 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
             }
             return;
         }
-        svcmi_f32x4 a4[2][WM], b4[2][WN];
+        svcmi_f32x4 a4[2][FA], b4[2][FB];
         load_frags(Ab, Bb, 0, a4[0], b4[0], tie0);
         frags_arrive(a4[0], b4[0]);
 #pragma unroll
         for (int s = 0; s < NSUB; ++s) {
-            svcmi_f32x4(&af)[WM] = a4[s & 1];
-            svcmi_f32x4(&bf)[WN] = b4[s & 1];
+            svcmi_f32x4(&af)[FA] = a4[s & 1];
+            svcmi_f32x4(&bf)[FB] = b4[s & 1];
             // next sub-step's fragments are requested before this sub-step's MFMAs are issued ...
             if (s + 1 < NSUB) load_frags(Ab, Bb, s + 1, a4[(s + 1) & 1], b4[(s + 1) & 1], af[0]);
             if (ISSUE) {
 #pragma unroll
                 for (int q = s * PIECES / NSUB; q < (s + 1) * PIECES / NSUB; ++q) {
-                    if (q < A_PER) stage_a(it + NST - 1, nslot, q);
-                    else stage_b(nslot, q - A_PER);
+                    if (q < APCS) stage_a(it + NST - 1, nslot, q);
+                    else stage_b(nslot, q - APCS);
                 }
             }
-            if constexpr (A16) {         // the fragment's 16 bytes are 8 consecutive 16-bit k: one MFMA per (i, j)
+            if constexpr (X3A) {         // hi*hi + lo*hi + hi*lo; the lo fragments sit behind the hi ones
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) mma16(acc[i][j], svcmi_as_u32x4(af[i]), svcmi_as_u32x4(bf[j]));
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) mma16(acc[i][j], svcmi_as_u32x4(af[WM + i]), svcmi_as_u32x4(bf[j]));
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) mma16(acc[i][j], svcmi_as_u32x4(af[i]), svcmi_as_u32x4(bf[WN + j]));
+            } else if constexpr (A16) {         // the fragment's 16 bytes are 8 consecutive 16-bit k: one MFMA per (i, j)
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -725,14 +746,15 @@ int launch_group(GroupArgs& g, int count, int batch, int mode, void* stream) {
 // Validation + argument block + gather mode of one convolution (shared by the single and the grouped entry points).
 // lp: d->w is the 16-bit image of svcmi_pack_weights_lp and d->ldw its leading dimension in 16-bit values.
 int prepare(const svcmi_conv_desc* d, ConvArgs& a, int& mode, int prec = PREC_F32) {
-    const bool lp = prec != PREC_F32, a16 = prec >= PREC_BF16_A16;
+    const bool lp = prec != PREC_F32, a16 = prec >= PREC_BF16_A16, x3a = prec == PREC_BF16X3_A16;
     if (!d || !d->x || !d->w || !d->y) return SVCMI_EINVAL;
     if (a16 && (d->c_in % 8 || d->ldx % 8 || d->x_bstride % 8 || ((uintptr_t)d->x & 15) || d->x_row_shift)) return SVCMI_EUNSUPPORTED;
-    if (d->y16 && (d->ldy16 % 4 || d->ldy16 < d->n_out || d->y16_bstride % 4 || ((uintptr_t)d->y16 & 7) ||
-                   (d->y16_format != SVCMI_PREC_BF16 && d->y16_format != SVCMI_PREC_F16) || (d->flags & SVCMI_CONV_PARTIALS) || d->split_k > 1))
+    if (x3a && (d->ldx % 16 || d->ldx / 2 < d->c_in)) return SVCMI_EUNSUPPORTED;     // rows [hi: ldx/2 | lo: ldx/2]
+    if (d->y16 && (svcmi_fmt16(d->y16_format) < 0 || !svcmi_fmt16_row_ok(d->y16_format, d->ldy16, d->n_out) || d->y16_bstride % 4 ||
+                   ((uintptr_t)d->y16 & 7) || (d->flags & SVCMI_CONV_PARTIALS) || d->split_k > 1))
         return SVCMI_EINVAL;
     /* 32-bit buffer offsets with a 2^30 out-of-range sentinel: each operand buffer stays below 2^29 bytes */
-    if ((long long)d->t_in * d->ldx >= (1LL << 27) || (long long)d->n_out * d->ldw * (prec == PREC_BF16X3 ? 2 : 1) >= (1LL << (lp ? 28 : 27))) return SVCMI_EUNSUPPORTED;
+    if ((long long)d->t_in * d->ldx >= (1LL << 27) || (long long)d->n_out * d->ldw * ((prec == PREC_BF16X3 || x3a) ? 2 : 1) >= (1LL << (lp ? 28 : 27))) return SVCMI_EUNSUPPORTED;
     if (((long long)d->ksize * d->dilation + d->pad) * d->ldx >= (1LL << 27)) return SVCMI_EUNSUPPORTED;
     if (d->batch <= 0 || d->t_in <= 0 || d->t_out <= 0 || d->c_in <= 0 || d->n_out <= 0 || d->ksize <= 0) return SVCMI_EINVAL;
     if (d->stride <= 0 || d->dilation <= 0 || d->x_row_shift < 0 || d->x_row_shift > 1) return SVCMI_EINVAL;
@@ -747,7 +769,7 @@ int prepare(const svcmi_conv_desc* d, ConvArgs& a, int& mode, int prec = PREC_F3
 
     a.w16 = lp ? reinterpret_cast<const unsigned short*>(d->w) : nullptr;
     a.ldw16 = lp ? d->ldw : 0;
-    a.y16 = reinterpret_cast<unsigned short*>(d->y16); a.y16_bs = d->y16_bstride; a.ldy16 = d->ldy16; a.y16_f16 = d->y16_format == SVCMI_PREC_F16;
+    a.y16 = reinterpret_cast<unsigned short*>(d->y16); a.y16_bs = d->y16_bstride; a.ldy16 = d->ldy16; a.y16_f16 = svcmi_fmt16(d->y16_format);
     a.x = d->x; a.w = d->w; a.bias = d->bias; a.res = d->res; a.y = d->y; a.lengths = d->lengths;
     a.ws = d->workspace;
     a.cnt = nullptr;

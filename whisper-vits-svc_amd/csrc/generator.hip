@@ -22,7 +22,7 @@ struct SnakeArgs {
     const float* filt;
     int n, c, ld;
     unsigned short* y16[SNAKE_GROUP];      // when set: the output goes out as bf16 / fp16 rows INSTEAD of fp32 (a following _A16 GEMM's A operand)
-    int f16;
+    int f16;                               // 0 bf16, 1 f16, 2 split bf16 rows [hi: ld | lo: ld] (svcmi_store4_16's codes)
 };
 
 __global__ __launch_bounds__(TPB) void snake_alias_kernel(SnakeArgs p) {
@@ -39,7 +39,8 @@ __global__ __launch_bounds__(TPB) void snake_alias_kernel(SnakeArgs p) {
     const float inv_b = 1.0f / (expf(p.beta_log[gi][ch]) + 1e-9f);
     const float* xc = p.x[gi] + (long long)b * n * ld + ch;
     float* yc = p.y[gi] ? p.y[gi] + (long long)b * n * ld + ch : nullptr;
-    unsigned short* yh = p.y16[gi] ? p.y16[gi] + (long long)b * n * ld + ch : nullptr;
+    const int ld16 = p.f16 == 2 ? 2 * ld : ld;      // split rows: [hi: ld | lo: ld]
+    unsigned short* yh = p.y16[gi] ? p.y16[gi] + (long long)b * n * ld16 + ch : nullptr;
 
     float f[12];
 #pragma unroll
@@ -53,7 +54,16 @@ __global__ __launch_bounds__(TPB) void snake_alias_kernel(SnakeArgs p) {
 #pragma unroll
     for (int r = 0; r < RT; ++r)
         if (t0 + r < n) {
-            if (yh) yh[(long long)(t0 + r) * ld] = (unsigned short)((p.f16 ? svcmi_cvt_pk_f16(out[r], 0.f) : svcmi_cvt_pk_bf16(out[r], 0.f)) & 0xffffu);
+            if (yh) {
+                unsigned short* q = yh + (long long)(t0 + r) * ld16;
+                if (p.f16 == 1) {
+                    q[0] = (unsigned short)(svcmi_cvt_pk_f16(out[r], 0.f) & 0xffffu);
+                } else {
+                    const unsigned h = svcmi_cvt_pk_bf16(out[r], 0.f) & 0xffffu;
+                    q[0] = (unsigned short)h;
+                    if (p.f16 == 2) q[ld] = (unsigned short)(svcmi_cvt_pk_bf16(out[r] - svcmi_bits_f32(h << 16), 0.f) & 0xffffu);
+                }
+            }
             else yc[(long long)(t0 + r) * ld] = out[r];
         }
 }
@@ -162,7 +172,7 @@ extern "C" int svcmi_snake_alias_group_f32(const float* const* x, float* const* 
                                            const float* const* beta_log, const float* filt, int32_t count, int32_t batch,
                                            int32_t len, int32_t c, int32_t ld, void* const* y16, int32_t y16_format, void* stream) {
     if (!x || (!y && !y16) || !alpha_log || !beta_log || !filt || count < 1 || count > SNAKE_GROUP) return SVCMI_EINVAL;
-    if (y16 && y16_format != SVCMI_PREC_BF16 && y16_format != SVCMI_PREC_F16) return SVCMI_EINVAL;
+    if (y16 && svcmi_fmt16(y16_format) < 0) return SVCMI_EINVAL;
     if (batch <= 0 || len <= 0 || c <= 0 || ld < c) return SVCMI_EINVAL;
     if (batch > 65535) return SVCMI_EUNSUPPORTED;
     SnakeArgs a;
@@ -174,7 +184,7 @@ extern "C" int svcmi_snake_alias_group_f32(const float* const* x, float* const* 
         if (x[j] == yj) return SVCMI_EINVAL;              // halo reads: not an in-place op
         a.x[i] = x[j]; a.y[i] = yj; a.y16[i] = hj; a.alpha_log[i] = alpha_log[j]; a.beta_log[i] = beta_log[j];
     }
-    a.filt = filt; a.n = len; a.c = c; a.ld = ld; a.f16 = y16_format == SVCMI_PREC_F16;
+    a.filt = filt; a.n = len; a.c = c; a.ld = ld; a.f16 = y16 ? svcmi_fmt16(y16_format) : 0;
     const long long runs = ((long long)len + RT - 1) / RT;
     const long long threads = runs * c;
     SVCMI_LAUNCH(snake_alias_kernel, dim3((unsigned)((threads + TPB - 1) / TPB), batch, count), dim3(TPB), 0, stream, a);

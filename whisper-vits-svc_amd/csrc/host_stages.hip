@@ -118,6 +118,10 @@ struct CV {
 };
 
 bool mode16(int prec) { return prec == SVCMI_PREC_BF16 || prec == SVCMI_PREC_F16; }
+// Modes whose GEMM chains hand 16-bit activations from producer to consumer: bf16 / f16 rows, or (bf16x3) split rows [hi: C | lo: C].
+bool act16(int prec) { return mode16(prec) || prec == SVCMI_PREC_BF16X3; }
+int w16(int prec, int C) { return prec == SVCMI_PREC_BF16X3 ? 2 * C : C; }             // 16-bit values per row of C channels
+int a16_code(int prec) { return prec == SVCMI_PREC_BF16X3 ? SVCMI_PREC_BF16X3_A16 : prec + 2; }
 
 int conv_t_out(const CV& v) { return v.t_out >= 0 ? v.t_out : (v.t_in + 2 * v.pad - v.dil * (v.ksize - 1) - 1) / v.stride + 1; }
 
@@ -153,19 +157,20 @@ int conv_desc(const Ctx& c, const CV& v, svcmi_conv_desc& d, double& flops, doub
     } else {
         d.split_k = 1;
     }
-    if (v.y16 && mode16(c.prec) && !partials && d.split_k == 1) {
-        d.y16 = v.y16; d.y16_bstride = d.y_bstride; d.ldy16 = d.ldy; d.y16_format = c.prec;
-        bytes += 2.0 * v.B * t_out * N;
+    if (v.y16 && act16(c.prec) && !partials && d.split_k == 1) {
+        d.y16 = v.y16; d.y16_bstride = w16(c.prec, 1) * d.y_bstride; d.ldy16 = w16(c.prec, d.ldy); d.y16_format = c.prec;
+        bytes += 2.0 * v.B * t_out * w16(c.prec, N);
     }
     if (!lp) return SVCMI_PREC_F32;
     d.w = static_cast<const float*>(v.w->w16);
     d.ldw = v.w->ldw16;
     bytes += (double)N * v.ksize * v.c_in * ((c.prec == SVCMI_PREC_BF16X3 ? 4.0 : 2.0) - 4.0);
-    if (v.x16 && mode16(c.prec) && v.w->w16a && v.c_in % 8 == 0 && v.ldx % 8 == 0 && v.x_bs % 8 == 0 && !v.rshift) {
+    if (v.x16 && act16(c.prec) && v.w->w16a && v.c_in % 8 == 0 && v.ldx % 8 == 0 && v.x_bs % 8 == 0 && !v.rshift) {
         d.x = static_cast<const float*>(v.x16);
         d.w = static_cast<const float*>(v.w->w16a);
-        bytes -= 2.0 * v.B * (double)v.t_in * v.c_in;
-        return c.prec + 2;          // SVCMI_PREC_BF16_A16 / _F16_A16
+        d.ldx = w16(c.prec, v.ldx); d.x_bstride = w16(c.prec, 1) * v.x_bs;
+        bytes -= (4.0 - 2.0 * w16(c.prec, 1)) * v.B * (double)v.t_in * v.c_in;
+        return a16_code(c.prec);    // SVCMI_PREC_BF16_A16 / _F16_A16 / _BF16X3_A16
     }
     return c.prec;
 }
@@ -175,7 +180,7 @@ void conv(Ctx& c, const CV& v) {
     svcmi_conv_desc d;
     double flops, bytes;
     const int prec = conv_desc(c, v, d, flops, bytes);
-    if (prec != SVCMI_PREC_F32) run(c, OP_CONV_LP, flops, bytes, [&] { return svcmi_conv_gemm_lp(&d, prec, c.stream); });
+    if (prec != SVCMI_PREC_F32) run(c, OP_CONV_LP | (prec << 8), flops, bytes, [&] { return svcmi_conv_gemm_lp(&d, prec, c.stream); });
     else run(c, OP_CONV_F32, flops, bytes, [&] { return svcmi_conv_gemm_f32(&d, c.stream); });
 }
 
@@ -212,7 +217,7 @@ int conv_group(Ctx& c, const CV* vs, int count, bool dry = false) {
                 v.x16 = nullptr;
                 conv_desc(c, v, d[i], flops[i], bytes[i], total);
             }
-        if (lp) prec = a16 ? c.prec + 2 : c.prec;
+        if (lp) prec = a16 ? a16_code(c.prec) : c.prec;
         if (!lp)
             for (int i = 0; i < count; ++i) {      // back to fp32 descriptors: a group runs on ONE kernel
                 CV v = vs[i];
@@ -224,7 +229,7 @@ int conv_group(Ctx& c, const CV* vs, int count, bool dry = false) {
     }
     for (int i = 0; i < count; ++i) tb += bytes[i];
     if (dry) return prec;
-    if (lp) run(c, OP_CONV_GROUP_LP, total, tb, [&] { return svcmi_conv_gemm_group_lp(d, count, prec, c.stream); });
+    if (lp) run(c, OP_CONV_GROUP_LP | (prec << 8), total, tb, [&] { return svcmi_conv_gemm_group_lp(d, count, prec, c.stream); });
     else run(c, OP_CONV_GROUP_F32, total, tb, [&] { return svcmi_conv_gemm_group_f32(d, count, c.stream); });
     return prec;
 }
@@ -232,27 +237,27 @@ int conv_group(Ctx& c, const CV* vs, int count, bool dry = false) {
 // (y16 / o16: optional 16-bit copies of the outputs, rows of C values, in the format of the bf16 / f16 mode; nullptr = none)
 void layernorm(Ctx& c, const float* x, const float* res, const float* g, const float* b, float* y, int B, int T, int C, int ldx, int ldr,
                int ldy, int gb_bs, void* y16 = nullptr) {
-    if (!mode16(c.prec)) y16 = nullptr;
+    if (!act16(c.prec)) y16 = nullptr;
     run(c, OP_LAYERNORM, 0.0, 4.0 * B * T * C * (2 + (res != nullptr)), [&] {
-        return svcmi_layernorm_f32(x, res, g, b, y, B, T, C, ldx, ldr, ldy, gb_bs, 1e-5f, y16, C, c.prec, c.stream);
+        return svcmi_layernorm_f32(x, res, g, b, y, B, T, C, ldx, ldr, ldy, gb_bs, 1e-5f, y16, w16(c.prec, C), c.prec, c.stream);
     });
 }
 
 void splitk_layernorm(Ctx& c, const float* part, int split, const float* bias, float* x, const float* g, const float* b, float* y, int B,
                       int T, int C, void* y16 = nullptr) {
-    if (!mode16(c.prec)) y16 = nullptr;
+    if (!act16(c.prec)) y16 = nullptr;
     run(c, OP_SPLITK_LN, 0.0, 4.0 * B * T * C * (3 + split), [&] {
-        return svcmi_splitk_layernorm_f32(part, split, bias, x, g, b, y, B, T, C, C, C, 1e-5f, y16, C, c.prec, c.stream);
+        return svcmi_splitk_layernorm_f32(part, split, bias, x, g, b, y, B, T, C, C, C, 1e-5f, y16, w16(c.prec, C), c.prec, c.stream);
     });
 }
 
 void attention(Ctx& c, const float* qkv, float* o, int B, int T, int heads, int C, float scale, const float* rel_k, const float* rel_v,
                int window, const int32_t* lengths, void* o16 = nullptr) {
     const int64_t bs = (int64_t)T * 3 * C;
-    if (!mode16(c.prec)) o16 = nullptr;
+    if (!act16(c.prec)) o16 = nullptr;
     run(c, OP_ATTENTION, 4.0 * B * T * (double)T * C, 16.0 * B * T * C, [&] {
         return svcmi_attention_f32(qkv, qkv + C, qkv + 2 * C, o, 3 * C, 3 * C, 3 * C, C, bs, bs, bs, (int64_t)T * C, B, T, heads, C / heads,
-                                   scale, rel_k, rel_v, window, lengths, o16, C, (int64_t)T * C, c.prec, c.stream);
+                                   scale, rel_k, rel_v, window, lengths, o16, w16(c.prec, C), (int64_t)T * w16(c.prec, C), c.prec, c.stream);
     });
 }
 
@@ -330,12 +335,17 @@ void whisper_fwd(Ctx& c, const svcmi_whisper_model& m, const float* mel, const f
     // bf16 / f16 modes: every GEMM's A operand is written as a 16-bit tensor by its producer (LayerNorm -> QKV and MLP-up, attention ->
     // out-projection, MLP-up's GELU epilogue -> MLP-down), so the GEMMs take the _A16 kernels: half the LDS bytes per MFMA, no rounding
     // in registers.  (The fp32 copies stay: LayerNorm output and residual stream are fp32 in every mode.)
-    const bool a16 = mode16(c.prec) && S % 8 == 0 && F % 8 == 0;
-    void* h16 = a16 ? c.ar.take((int64_t)B * tw * S * 2) : nullptr;
-    void* at16 = a16 ? c.ar.take((int64_t)B * tw * S * 2) : nullptr;
-    void* mm16 = a16 ? c.ar.take((int64_t)B * tw * F * 2) : nullptr;
+    // bf16x3: split rows [hi | lo] and the _BF16X3_A16 kernel for the QKV projection and MLP-down only -- the two launches it measurably
+    // speeds up (T = 500: 30.5 -> 23.9 us, 36.0 -> 31.9 us; the out-projection's short K slices and MLP-up are no faster or slower:
+    // profiles/r03p_microbench_x3a.log); the attention stays on the fp32 matrix cores.
+    const bool x3 = c.prec == SVCMI_PREC_BF16X3;
+    const bool a16 = act16(c.prec) && S % 8 == 0 && F % 8 == 0;
+    const int64_t e16 = 2 * w16(c.prec, 1);           // bytes per channel of a 16-bit row
+    void* h16 = a16 ? c.ar.take((int64_t)B * tw * S * e16) : nullptr;
+    void* at16 = a16 && !x3 ? c.ar.take((int64_t)B * tw * S * e16) : nullptr;
+    void* mm16 = a16 ? c.ar.take((int64_t)B * tw * F * e16) : nullptr;
     // ... and the attention itself runs on the 16-bit matrix cores from the QKV projection's 16-bit output copy (svcmi_attention16)
-    const bool att16 = a16 && (S / H == 64 || S / H == 32);
+    const bool att16 = a16 && mode16(c.prec) && (S / H == 64 || S / H == 32);
     void* qkv16 = att16 ? c.ar.take((int64_t)B * tw * 3 * S * 2) : nullptr;
     layernorm(c, x, nullptr, m.blocks[0].ln1_g, m.blocks[0].ln1_b, h, B, tw, S, S, 0, S, 0, h16);
     for (int i = 0; i < nb; ++i) {
@@ -354,7 +364,7 @@ void whisper_fwd(Ctx& c, const svcmi_whisper_model& m, const float* mel, const f
         }
         splitk_layernorm(c, slabs, so, blk.o.bias, x, blk.ln2_g, blk.ln2_b, h, B, tw, S, h16);
         {
-            CV u = v; u.x = h; u.x16 = h16; u.w = &blk.m1; u.act = SVCMI_ACT_GELU; u.y = mm; u.y_bs = (int64_t)tw * F; u.ldy = F; u.split_k = 1;
+            CV u = v; u.x = h; u.x16 = x3 ? nullptr : h16; u.w = &blk.m1; u.act = SVCMI_ACT_GELU; u.y = mm; u.y_bs = (int64_t)tw * F; u.ldy = F; u.split_k = 1;
             u.tile = t_m1; u.tile_lp = l_m1; u.y16 = mm16;
             conv(c, u);
         }
@@ -589,6 +599,7 @@ bool amp_stage_grouped(Ctx& c, const svcmi_synth_model& m, const svcmi_gen_stage
     for (int j = 0; j < nb; ++j) t2[j] = c.ar.f(n);
     // bf16 / f16 modes, wide stages: SnakeAlias writes its output as 16-bit rows ONLY (it feeds nothing but the convolution) and
     // the grouped GEMM takes the _A16 kernel -- a quarter less activation traffic per half-step, half the operand bytes through LDS
+    // (not in bf16x3: split rows + the _BF16X3_A16 kernel are no faster than the in-register split here, profiles/r03p_*)
     if (!fused && mode16(c.prec) && cp % 8 == 0)
         for (int j = 0; j < nb; ++j) t1h[j] = c.ar.take(n * 2);
     const float* xc[3] = {y, y, y};
@@ -624,7 +635,7 @@ bool amp_stage_grouped(Ctx& c, const svcmi_synth_model& m, const svcmi_gen_stage
                     pb[j] = second ? st.blocks[j].a2_beta[q] : st.blocks[j].a1_beta[q];
                     if (!h16) vs[j].x16 = nullptr;
                 }
-                run(c, OP_SNAKE_ALIAS_GROUP, 0.0, (h16 ? 6.0 : 8.0) * nb * B * L * cp, [&] {
+                run(c, OP_SNAKE_ALIAS_GROUP, 0.0, (h16 ? 4.0 + 2.0 * w16(c.prec, 1) : 8.0) * nb * B * L * cp, [&] {
                     return svcmi_snake_alias_group_f32(px, h16 ? nullptr : py, pa, pb, m.filt, nb, B, (int32_t)L, cp, cp, h16 ? t1h : nullptr, c.prec,
                                                        c.stream);
                 });
@@ -903,7 +914,7 @@ extern "C" int svcmi_trace_end(svcmi_trace_record* out, int32_t cap) {
     return n;
 }
 
-extern "C" const char* svcmi_trace_op_name(int32_t op) { return op >= 0 && op < OP_COUNT ? OP_NAMES[op] : ""; }
+extern "C" const char* svcmi_trace_op_name(int32_t op) { return op >= 0 && (op & 255) < OP_COUNT ? OP_NAMES[op & 255] : ""; }
 
 // layout check for FFI bindings: sizeof of the structs a caller fills, in the order svcmi/_lib.py lists them
 extern "C" int svcmi_struct_sizes(int64_t* out, int32_t cap) {

@@ -12,11 +12,6 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // 16-bit copy of four consecutive outputs (the A operand of a following SVCMI_PREC_*_A16 GEMM), 8-byte store
-__device__ __forceinline__ void store4_16(unsigned short* dst, float a, float b, float c, float d, int f16) {
-    unsigned* h = reinterpret_cast<unsigned*>(dst);
-    h[0] = f16 ? svcmi_cvt_pk_f16(a, b) : svcmi_cvt_pk_bf16(a, b);
-    h[1] = f16 ? svcmi_cvt_pk_f16(c, d) : svcmi_cvt_pk_bf16(c, d);
-}
 
 // ------------------------------------------------------------------------------------ LayerNorm
 // One wave per row; a lane owns float4 #(lane + 64*i).  Two-pass (mean, then centred variance) like
@@ -75,7 +70,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
             o.z = (v[i].z - mean) * rstd * g.z + bb.z;
             o.w = (v[i].w - mean) * rstd * g.w + bb.w;
             *reinterpret_cast<float4*>(yr + 4 * q) = o;
-            if (y16) store4_16(y16 + (long long)row * ldy16 + 4 * q, o.x, o.y, o.z, o.w, f16);
+            if (y16) svcmi_store4_16(y16 + (long long)row * ldy16 + 4 * q, ldy16 >> 1, o.x, o.y, o.z, o.w, f16);
         }
     }
 }
@@ -224,7 +219,7 @@ __global__ __launch_bounds__(256) void splitk_layernorm_kernel(const float* part
             o.z = (v[i].z - mean) * rstd * g.z + bb.z;
             o.w = (v[i].w - mean) * rstd * g.w + bb.w;
             *reinterpret_cast<float4*>(yr + 4 * q) = o;
-            if (y16) store4_16(y16 + (long long)row * ldy16 + 4 * q, o.x, o.y, o.z, o.w, f16);
+            if (y16) svcmi_store4_16(y16 + (long long)row * ldy16 + 4 * q, ldy16 >> 1, o.x, o.y, o.z, o.w, f16);
         }
     }
 }
@@ -505,7 +500,7 @@ __global__ __launch_bounds__(64 * NS) void attention_kernel(AttnArgs p) {
         if (qrow < T) {
             const float inv = 1.0f / den;
             *reinterpret_cast<float4*>(ob + (long long)qrow * p.ldo + c4) = make_float4(num.x * inv, num.y * inv, num.z * inv, num.w * inv);
-            if (p.o16) store4_16(p.o16 + (long long)b * p.o16_bs + (long long)qrow * p.ldo16 + h * D + c4, num.x * inv, num.y * inv, num.z * inv, num.w * inv, p.o16_f16);
+            if (p.o16) svcmi_store4_16(p.o16 + (long long)b * p.o16_bs + (long long)qrow * p.ldo16 + h * D + c4, p.ldo16 >> 1, num.x * inv, num.y * inv, num.z * inv, num.w * inv, p.o16_f16);
         }
     }
 }
@@ -678,7 +673,7 @@ __global__ __launch_bounds__(64 * NS) void attention_q32_kernel(AttnArgs p) {
         if (qrow < T) {
             const float inv = 1.0f / den;
             *reinterpret_cast<float4*>(ob + (long long)qrow * p.ldo + c4) = make_float4(num.x * inv, num.y * inv, num.z * inv, num.w * inv);
-            if (p.o16) store4_16(p.o16 + (long long)b * p.o16_bs + (long long)qrow * p.ldo16 + h * D + c4, num.x * inv, num.y * inv, num.z * inv, num.w * inv, p.o16_f16);
+            if (p.o16) svcmi_store4_16(p.o16 + (long long)b * p.o16_bs + (long long)qrow * p.ldo16 + h * D + c4, p.ldo16 >> 1, num.x * inv, num.y * inv, num.z * inv, num.w * inv, p.o16_f16);
         }
     }
 }
@@ -878,7 +873,7 @@ __global__ __launch_bounds__(64 * QT * KS) void attention_lds_kernel(AttnArgs p)
         if (qrow < T) {
             const float inv = 1.0f / den;
             *reinterpret_cast<float4*>(ob + (long long)qrow * p.ldo + c4) = make_float4(num.x * inv, num.y * inv, num.z * inv, num.w * inv);
-            if (p.o16) store4_16(p.o16 + (long long)b * p.o16_bs + (long long)qrow * p.ldo16 + h * D + c4, num.x * inv, num.y * inv, num.z * inv, num.w * inv, p.o16_f16);
+            if (p.o16) svcmi_store4_16(p.o16 + (long long)b * p.o16_bs + (long long)qrow * p.ldo16 + h * D + c4, p.ldo16 >> 1, num.x * inv, num.y * inv, num.z * inv, num.w * inv, p.o16_f16);
         }
     }
 }
@@ -1192,7 +1187,7 @@ __global__ __launch_bounds__(64 * QT * KS) void attention16_kernel(Attn16Args p)
         if (qrow < T) {
             const float inv = 1.0f / den;
             if (p.o) *reinterpret_cast<float4*>(p.o + (long long)b * p.o_bs + (long long)qrow * p.ldo + h * D + c4) = make_float4(num.x * inv, num.y * inv, num.z * inv, num.w * inv);
-            if (p.o16) store4_16(p.o16 + (long long)b * p.o16_bs + (long long)qrow * p.ldo16 + h * D + c4, num.x * inv, num.y * inv, num.z * inv, num.w * inv, p.o16_f16);
+            if (p.o16) svcmi_store4_16(p.o16 + (long long)b * p.o16_bs + (long long)qrow * p.ldo16 + h * D + c4, p.ldo16 >> 1, num.x * inv, num.y * inv, num.z * inv, num.w * inv, p.o16_f16);
         }
     }
 }
@@ -1330,7 +1325,7 @@ extern "C" int svcmi_layernorm_f32(const float* x, const float* res, const float
                                    int32_t batch, int32_t rows_per_batch, int32_t c, int32_t ldx, int32_t ldr,
                                    int32_t ldy, int32_t gb_bstride, float eps, void* y16, int32_t ldy16, int32_t y16_format, void* stream) {
     if (!x || !y || batch <= 0 || rows_per_batch <= 0 || c <= 0) return SVCMI_EINVAL;
-    if (y16 && (ldy16 % 4 || ldy16 < c || ((uintptr_t)y16 & 7) || (y16_format != SVCMI_PREC_BF16 && y16_format != SVCMI_PREC_F16))) return SVCMI_EINVAL;
+    if (y16 && (svcmi_fmt16(y16_format) < 0 || !svcmi_fmt16_row_ok(y16_format, ldy16, c) || ((uintptr_t)y16 & 7))) return SVCMI_EINVAL;
     if (c % 4 != 0 || c > 64 * 4 * LN_MAXV) return SVCMI_EUNSUPPORTED;
     if (ldx % 4 || ldy % 4 || (res && ldr % 4) || gb_bstride % 4) return SVCMI_EALIGN;
     if (((uintptr_t)x & 15) || ((uintptr_t)y & 15) || ((uintptr_t)res & 15) || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15))
@@ -1339,7 +1334,7 @@ extern "C" int svcmi_layernorm_f32(const float* x, const float* res, const float
     if (rows > 0x7fffffffLL) return SVCMI_EUNSUPPORTED;
     SVCMI_LAUNCH(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, res, gamma, beta, y,
                  (int)rows, rows_per_batch, c, ldx, ldr, ldy, gb_bstride, eps, static_cast<unsigned short*>(y16), ldy16,
-                 (int)(y16_format == SVCMI_PREC_F16));
+                 svcmi_fmt16(y16_format));
     return SVCMI_LAST_ERROR();
 }
 
@@ -1368,7 +1363,7 @@ extern "C" int svcmi_splitk_layernorm_f32(const float* partials, int32_t split, 
                                           const float* beta, float* y, int32_t batch, int32_t rows_per_batch, int32_t c,
                                           int32_t ldx, int32_t ldy, float eps, void* y16, int32_t ldy16, int32_t y16_format, void* stream) {
     if (!partials || !x || !y || split < 1 || batch <= 0 || rows_per_batch <= 0 || c <= 0) return SVCMI_EINVAL;
-    if (y16 && (ldy16 % 4 || ldy16 < c || ((uintptr_t)y16 & 7) || (y16_format != SVCMI_PREC_BF16 && y16_format != SVCMI_PREC_F16))) return SVCMI_EINVAL;
+    if (y16 && (svcmi_fmt16(y16_format) < 0 || !svcmi_fmt16_row_ok(y16_format, ldy16, c) || ((uintptr_t)y16 & 7))) return SVCMI_EINVAL;
     if (c % 4 != 0 || c > 256 * 4 * SKV) return SVCMI_EUNSUPPORTED;
     if (ldx % 4 || ldy % 4) return SVCMI_EALIGN;
     if (((uintptr_t)partials & 15) || ((uintptr_t)x & 15) || ((uintptr_t)y & 15) || ((uintptr_t)bias & 15) ||
@@ -1376,7 +1371,7 @@ extern "C" int svcmi_splitk_layernorm_f32(const float* partials, int32_t split, 
     const long long rows = (long long)batch * rows_per_batch;
     if (rows > 0x7fffffffLL) return SVCMI_EUNSUPPORTED;
     SVCMI_LAUNCH(splitk_layernorm_kernel, dim3((unsigned)rows), dim3(256), 0, stream, partials, split, bias, x, gamma,
-                 beta, y, rows_per_batch, c, ldx, ldy, eps, static_cast<unsigned short*>(y16), ldy16, (int)(y16_format == SVCMI_PREC_F16));
+                 beta, y, rows_per_batch, c, ldx, ldy, eps, static_cast<unsigned short*>(y16), ldy16, svcmi_fmt16(y16_format));
     return SVCMI_LAST_ERROR();
 }
 
@@ -1387,8 +1382,8 @@ extern "C" int svcmi_attention_f32(const float* q, const float* k, const float* 
                                    const float* rel_k, const float* rel_v, int32_t window,
                                    const int32_t* lengths, void* o16, int32_t ldo16, int64_t o16_bstride, int32_t o16_format, void* stream) {
     if (!q || !k || !v || !o || batch <= 0 || t <= 0 || heads <= 0) return SVCMI_EINVAL;
-    if (o16 && (ldo16 % 4 || ldo16 < heads * head_dim || o16_bstride % 4 || ((uintptr_t)o16 & 7) ||
-                (o16_format != SVCMI_PREC_BF16 && o16_format != SVCMI_PREC_F16))) return SVCMI_EINVAL;
+    if (o16 && (svcmi_fmt16(o16_format) < 0 || !svcmi_fmt16_row_ok(o16_format, ldo16, heads * head_dim) || o16_bstride % 4 || ((uintptr_t)o16 & 7)))
+        return SVCMI_EINVAL;
     if ((rel_k == nullptr) != (rel_v == nullptr)) return SVCMI_EINVAL;
     if (rel_k && (window < 0 || window > MAXW)) return SVCMI_EUNSUPPORTED;
     if (ldq % 4 || ldk % 4 || ldv % 4 || ldo % 4 || q_bstride % 4 || k_bstride % 4 || v_bstride % 4 || o_bstride % 4)
@@ -1399,7 +1394,7 @@ extern "C" int svcmi_attention_f32(const float* q, const float* k, const float* 
     a.q = q; a.k = k; a.v = v; a.o = o; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
     a.q_bs = q_bstride; a.k_bs = k_bstride; a.v_bs = v_bstride; a.o_bs = o_bstride;
     a.t = t; a.heads = heads; a.nq = (t + 15) / 16; a.scale = scale; a.rel_k = rel_k; a.rel_v = rel_v; a.window = window; a.lengths = lengths;
-    a.o16 = static_cast<unsigned short*>(o16); a.ldo16 = ldo16; a.o16_bs = o16_bstride; a.o16_f16 = o16_format == SVCMI_PREC_F16;
+    a.o16 = static_cast<unsigned short*>(o16); a.ldo16 = ldo16; a.o16_bs = o16_bstride; a.o16_f16 = svcmi_fmt16(o16_format);
     switch (head_dim) {
         case 16: return launch_attn<16>(a, batch, stream);
         case 32: return launch_attn<32>(a, batch, stream);

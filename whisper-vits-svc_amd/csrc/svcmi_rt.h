@@ -164,3 +164,31 @@ __device__ __forceinline__ void svcmi_store16_sc1(svcmi_f32x4 v, svcmi_rsrc r, u
 #endif
 
 #define SVCMI_WAVE 64
+
+// Four consecutive values as a 16-bit copy (8-byte store): fmt 0 bf16, 1 f16, 2 split bf16 -- hi = rne(x) at dst, lo = rne(x - hi) at
+// dst + lo_off: the activation-row format of the _A16 GEMM kernels (conv_gemm_body.h).
+#ifndef SVCMI_EMU
+__device__ __forceinline__
+#else
+static inline
+#endif
+void svcmi_store4_16(unsigned short* dst, int lo_off, float a, float b, float c, float d, int fmt) {
+    unsigned* h = reinterpret_cast<unsigned*>(dst);
+    if (fmt == 1) {
+        h[0] = svcmi_cvt_pk_f16(a, b);
+        h[1] = svcmi_cvt_pk_f16(c, d);
+        return;
+    }
+    const unsigned h0 = svcmi_cvt_pk_bf16(a, b), h1 = svcmi_cvt_pk_bf16(c, d);
+    h[0] = h0;
+    h[1] = h1;
+    if (fmt == 2) {
+        unsigned* l = reinterpret_cast<unsigned*>(dst + lo_off);
+        l[0] = svcmi_cvt_pk_bf16(a - svcmi_bits_f32(h0 << 16), b - svcmi_bits_f32(h0 & 0xffff0000u));
+        l[1] = svcmi_cvt_pk_bf16(c - svcmi_bits_f32(h1 << 16), d - svcmi_bits_f32(h1 & 0xffff0000u));
+    }
+}
+// Host side: the kernels' format code of a 16-bit activation output from an `enum svcmi_precision` value (BF16 = 2 -> 0, F16 = 3 -> 1,
+// BF16X3 = 1 -> 2 = split rows); -1 = not an activation format.  Row check: `ld` 16-bit values hold n outputs (split: two planes of ld/2).
+static inline int svcmi_fmt16(int format) { return format == 2 ? 0 : format == 3 ? 1 : format == 1 ? 2 : -1; }
+static inline bool svcmi_fmt16_row_ok(int format, int ld, int n) { return format == 1 ? (ld % 8 == 0 && ld / 2 >= n) : (ld % 4 == 0 && ld >= n); }

@@ -15,7 +15,7 @@ class CModel:
 
 
 def _weight(cw, ops, w, bias, prec, keep, a16=False):
-    """``a16``: also pack the natural-order image of the 16-bit-activation kernels (bf16 / f16 modes only)."""
+    """``a16``: also pack the natural-order image of the 16-bit-activation kernels."""
     cw.w, cw.bias = w.data_ptr(), (0 if bias is None else bias.data_ptr())
     cw.n, cw.ldw = int(w.shape[0]), int(w.shape[1])
     cw.w16, cw.w16a, cw.ldw16 = 0, 0, 0
@@ -23,8 +23,8 @@ def _weight(cw, ops, w, bias, prec, keep, a16=False):
         img = ops.lp_weight(w, prec)
         cw.w16, cw.ldw16 = img.data_ptr(), img.shape[1] // (2 if prec == PREC_BF16X3 else 1)
         keep.append(img)
-        if a16 and prec in (PREC_BF16, PREC_F16):
-            img_a = ops.lp_weight(w, prec + 2)          # PREC_BF16_A16 / PREC_F16_A16
+        if a16:
+            img_a = ops.lp_weight(w, _lib.PREC_BF16X3_A16 if prec == PREC_BF16X3 else prec + 2)          # PREC_BF16_A16 / PREC_F16_A16 / PREC_BF16X3_A16
             cw.w16a = img_a.data_ptr()
             keep.append(img_a)
     keep.append(w)
@@ -38,6 +38,7 @@ def whisper_cmodel(w, ops, prec=PREC_F32):
         raise _lib.SvcmiError(f"{w.n_layers} encoder blocks > {_lib.MAX_WHISPER_BLOCKS}")
     m.n_state, m.n_heads, m.n_layers, m.n_mels = w.S, w.heads, w.n_layers, w.n_mels
     m.n_ctx, m.precision = int(w.pos.shape[0]), prec
+    x3 = prec == PREC_BF16X3         # split-bf16: only the QKV projection and MLP-down take 16-bit (split) activation rows (host_stages.hip)
     _weight(m.conv1, ops, w.conv1_w, w.conv1_b, prec, keep)
     _weight(m.conv2, ops, w.conv2_w, w.conv2_b, prec, keep)
     m.pos, m.lnp_g, m.lnp_b = w.pos.data_ptr(), w.lnp_g.data_ptr(), w.lnp_b.data_ptr()
@@ -45,8 +46,8 @@ def whisper_cmodel(w, ops, prec=PREC_F32):
         cb = m.blocks[i]
         cb.ln1_g, cb.ln1_b, cb.ln2_g, cb.ln2_b = (b[k].data_ptr() for k in ("ln1_g", "ln1_b", "ln2_g", "ln2_b"))
         _weight(cb.qkv, ops, b["qkv_w"], b["qkv_b"], prec, keep, a16=True)
-        _weight(cb.o, ops, b["o_w"], b["o_b"], prec, keep, a16=True)
-        _weight(cb.m1, ops, b["m1_w"], b["m1_b"], prec, keep, a16=True)
+        _weight(cb.o, ops, b["o_w"], b["o_b"], prec, keep, a16=not x3)
+        _weight(cb.m1, ops, b["m1_w"], b["m1_b"], prec, keep, a16=not x3)
         _weight(cb.m2, ops, b["m2_w"], b["m2_b"], prec, keep, a16=True)
     return CModel(m, keep)
 
@@ -64,7 +65,7 @@ def synth_cmodel(w, ops, prec=PREC_F32):
     m.upsample_input, m.hop = w.U, w.hop
     m.precision, m.lp_min_flops = prec, 0.0
     m.sampling_rate, m.merge_b = float(hp.data.sampling_rate), float(w.merge_b)
-    W = lambda cw, wt, b=None, a16=False: _weight(cw, ops, wt, b, prec, keep, a16=a16)
+    W = lambda cw, wt, b=None, a16=False: _weight(cw, ops, wt, b, prec, keep, a16=a16 and prec != PREC_BF16X3)     # 16-bit activation rows: bf16 / f16 modes
     W(m.pre, w.pre_w, w.pre_b)
     W(m.hub, w.hub_w, w.hub_b)
     W(m.proj, w.proj_w, w.proj_b)

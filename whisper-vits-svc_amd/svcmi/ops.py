@@ -17,9 +17,26 @@ from ._lib import (ACT_GELU, ACT_MISH, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH
                    SynthIO, TraceRecord)
 
 
+SPLIT16 = "bf16x3"      # ``out16`` value: rows [hi: Cp bf16 | lo: Cp bf16], hi = bf16(v), lo = bf16(v - hi), Cp = C rounded up to 8
+
+
 def _fmt16(dtype):
-    """torch.bfloat16 / torch.float16 -> the svcmi_precision code of a 16-bit output copy."""
-    return {torch.bfloat16: PREC_BF16, torch.float16: PREC_F16}[dtype]
+    """torch.bfloat16 / torch.float16 / SPLIT16 -> the svcmi_precision code of a 16-bit output copy."""
+    return {torch.bfloat16: PREC_BF16, torch.float16: PREC_F16, SPLIT16: PREC_BF16X3}[dtype]
+
+
+def _alloc16(lead, c, out16, device):
+    """The 16-bit second output of a producer: [*lead, c] in the 16-bit dtype, or the split layout [*lead, 2*Cp] (zero-filled pads)."""
+    if out16 == SPLIT16:
+        cp = (c + 7) // 8 * 8
+        return (torch.zeros if cp != c else torch.empty)(*lead, 2 * cp, dtype=torch.bfloat16, device=device)
+    return torch.empty(*lead, c, dtype=out16, device=device)
+
+
+def split16_to_f32(x16, c):
+    """hi + lo of a SPLIT16 tensor as fp32 [..., c] (tests, debugging)."""
+    cp = x16.shape[-1] // 2
+    return x16[..., :c].float() + x16[..., cp:cp + c].float()
 
 
 def _ptr(t):
@@ -119,7 +136,7 @@ class Ops:
                 if img is None:
                     n, ldw = w.shape
                     ldw16 = (ldw + 31) // 32 * 32
-                    img = torch.empty(n, (2 if prec == PREC_BF16X3 else 1) * ldw16, dtype=torch.int16, device=w.device)
+                    img = torch.empty(n, (2 if prec in (PREC_BF16X3, _lib.PREC_BF16X3_A16) else 1) * ldw16, dtype=torch.int16, device=w.device)
                     self._call("svcmi_pack_weights_lp", _ptr(w), n, ldw, prec, _ptr(img), ldw16, self._stream())
                     if self.on_gpu:            # packed on THIS thread's stream; other streams may read it right away
                         torch.cuda.current_stream().synchronize()
@@ -259,14 +276,15 @@ class Ops:
         tl, self.timeline = self.timeline or [], None
         agg = {}
 
-        def add(name, ms, flops, nbytes):
-            a = agg.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        def add(name, ms, flops, nbytes, a16=False):
+            a = agg.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "a16_launches": 0})
             a["launches"] += 1
             a["ms"] += ms
             a["flops"] += flops
             a["bytes"] += nbytes
+            a["a16_launches"] += int(a16)         # GEMM launches that took 16-bit activations (SVCMI_PREC_*_A16)
         for i in range(n):
-            add(self.lib.svcmi_trace_op_name(recs[i].op).decode(), recs[i].ms, recs[i].flops, recs[i].bytes)
+            add(self.lib.svcmi_trace_op_name(recs[i].op).decode(), recs[i].ms, recs[i].flops, recs[i].bytes, (recs[i].op >> 8) >= _lib.PREC_BF16_A16)
         if tl and self.on_gpu:
             torch.cuda.synchronize()
         for name, work, e0, e1 in tl:
@@ -330,15 +348,17 @@ class Ops:
         d, out, ws, B, t_out, N, work = self._conv_desc(x, w, bias, **kw)
         y16 = None
         if out16 is not None:
-            y16 = torch.empty(out.shape, dtype=out16, device=out.device)
+            y16 = _alloc16(out.shape[:-1], N, out16, out.device)
             d.y16, d.y16_bstride, d.ldy16, d.y16_format = y16.data_ptr(), y16.stride(0), y16.stride(1), _fmt16(out16)
         if self._lp_eligible(d, w, work):
             prec = self._to_lp(d, w, work)
-            if x16 is not None and prec == _fmt16(x16.dtype):
+            # x16 in this mode's format (bf16x3: a SPLIT16 tensor, recognised by its doubled rows)
+            if x16 is not None and ((prec == PREC_BF16X3 and x16.dtype == torch.bfloat16 and x16.shape[-1] == 2 * ((d.c_in + 7) // 8 * 8))
+                                    or (prec != PREC_BF16X3 and prec == _fmt16(x16.dtype))):
                 self._chk(x16)
-                prec += 2                                      # SVCMI_PREC_BF16_A16 / _F16_A16: natural-order weight image
+                prec = {PREC_BF16: _lib.PREC_BF16_A16, PREC_F16: _lib.PREC_F16_A16, PREC_BF16X3: _lib.PREC_BF16X3_A16}[prec]   # natural-order weight image
                 img = self.lp_weight(w, prec)
-                d.x, d.w = x16.data_ptr(), img.data_ptr()
+                d.x, d.w, d.ldx, d.x_bstride = x16.data_ptr(), img.data_ptr(), x16.stride(1), x16.stride(0)
             self._call("svcmi_conv_gemm_lp", ctypes.byref(d), prec, self._stream(), work=work)
         else:
             self._call("svcmi_conv_gemm_f32", ctypes.byref(d), self._stream(), work=work)
@@ -374,16 +394,16 @@ class Ops:
 
     # ------------------------------------------------------------------ norm / attention
     def layernorm(self, x, gamma=None, beta=None, *, res=None, eps=1e-5, per_batch_affine=False, out=None, out16=None):
-        """``out16`` = torch.bfloat16 | torch.float16: also return the rows rounded to that type (a following GEMM's 16-bit A operand)."""
+        """``out16`` = torch.bfloat16 | torch.float16 | SPLIT16: also return the rows rounded to that format (a following GEMM's 16-bit A operand)."""
         self._chk(x, gamma, beta, res, out)
         B, T, Cc = x.shape
         if out is None:
             out = torch.empty_like(x)
-        y16 = torch.empty(B, T, Cc, dtype=out16, device=x.device) if out16 is not None else None
+        y16 = _alloc16((B, T), Cc, out16, x.device) if out16 is not None else None
         self._call("svcmi_layernorm_f32", _ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(out), B, T, Cc,
                    x.stride(1), res.stride(1) if res is not None else 0, out.stride(1),
                    (gamma.stride(0) if gamma is not None else beta.stride(0)) if per_batch_affine else 0, eps,
-                   _ptr(y16), Cc, _fmt16(out16) if out16 is not None else 0, self._stream())
+                   _ptr(y16), y16.stride(1) if y16 is not None else 0, _fmt16(out16) if out16 is not None else 0, self._stream())
         return out if out16 is None else (out, y16)
 
     def channel_norm_gelu(self, x, gamma, beta, eps=1e-5, out=None):
@@ -403,9 +423,10 @@ class Ops:
         B, S, T, Cc = partials.shape
         if out is None:
             out = torch.empty_like(x)
-        y16 = torch.empty(B, T, Cc, dtype=out16, device=x.device) if out16 is not None else None
+        y16 = _alloc16((B, T), Cc, out16, x.device) if out16 is not None else None
         self._call("svcmi_splitk_layernorm_f32", _ptr(partials), S, _ptr(bias), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(out),
-                   B, T, Cc, x.stride(1), out.stride(1), eps, _ptr(y16), Cc, _fmt16(out16) if out16 is not None else 0, self._stream())
+                   B, T, Cc, x.stride(1), out.stride(1), eps, _ptr(y16), y16.stride(1) if y16 is not None else 0,
+                   _fmt16(out16) if out16 is not None else 0, self._stream())
         return out if out16 is None else (out, y16)
 
     def attention(self, qkv, heads, scale, *, rel_k=None, rel_v=None, window=0, lengths=None, out=None, out16=None):
@@ -417,10 +438,11 @@ class Ops:
             out = torch.empty(B, T, Cc, dtype=torch.float32, device=qkv.device)
         base = qkv.data_ptr()
         bs = qkv.stride(0)
-        o16 = torch.empty(B, T, Cc, dtype=out16, device=qkv.device) if out16 is not None else None
+        o16 = _alloc16((B, T), Cc, out16, qkv.device) if out16 is not None else None
         self._call("svcmi_attention_f32", base, base + 4 * Cc, base + 8 * Cc, _ptr(out), C3, C3, C3, out.stride(1),
                    bs, bs, bs, out.stride(0), B, T, heads, Cc // heads, scale, _ptr(rel_k), _ptr(rel_v), window,
-                   _ptr(lengths), _ptr(o16), Cc, T * Cc, _fmt16(out16) if out16 is not None else 0, self._stream(),
+                   _ptr(lengths), _ptr(o16), o16.stride(1) if o16 is not None else 0, o16.stride(0) if o16 is not None else 0,
+                   _fmt16(out16) if out16 is not None else 0, self._stream(),
                    work={"flops": 4.0 * B * T * T * Cc})
         return out if out16 is None else (out, o16)
 
@@ -455,8 +477,10 @@ class Ops:
         B, L, Cc = xs[0].shape
         arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
         if outs[0].dtype != torch.float32:      # bf16 / float16 outputs: the 16-bit rows a following _A16 GEMM reads
+            split = outs[0].dtype == torch.bfloat16 and outs[0].shape[-1] == 2 * xs[0].stride(1)      # SPLIT16 rows [hi: ld | lo: ld]
             self._call("svcmi_snake_alias_group_f32", arr(xs), None, arr(alpha_logs), arr(beta_logs), _ptr(filt), n,
-                       B, L, Cc, xs[0].stride(1), arr(outs), _fmt16(outs[0].dtype), self._stream(), work={"bytes": 6.0 * n * B * L * Cc})
+                       B, L, Cc, xs[0].stride(1), arr(outs), _fmt16(SPLIT16 if split else outs[0].dtype), self._stream(),
+                       work={"bytes": (8.0 if split else 6.0) * n * B * L * Cc})
             return outs
         self._call("svcmi_snake_alias_group_f32", arr(xs), arr(outs), arr(alpha_logs), arr(beta_logs), _ptr(filt), n,
                    B, L, Cc, xs[0].stride(1), None, 0, self._stream(), work={"bytes": 8.0 * n * B * L * Cc})
@@ -580,14 +604,21 @@ class Ops:
         self._call("svcmi_crepe_frames_f32", _ptr(audio), audio.numel(), hop, frame0, frames, _ptr(out), ld, self._stream())
         return out
 
-    def bn_maxpool2(self, x, scale, shift):
-        """x [B, T, C] (T even) -> max over row pairs of x*scale + shift: [B, T/2, C] (crepe/model.py:128-134)."""
+    def bn_maxpool2(self, x, scale, shift, out16=None):
+        """x [B, T, C] (T even) -> max over row pairs of x*scale + shift: [B, T/2, C] (crepe/model.py:128-134).  ``out16``: also return
+        the 16-bit copy (torch.bfloat16 | torch.float16 | SPLIT16) the next layer's GEMM reads."""
         self._chk(x, scale, shift)
         B, T, Cc = x.shape
         y = torch.empty(B, T // 2, Cc, dtype=torch.float32, device=x.device)
+        y16 = _alloc16((B, T // 2), Cc, out16, x.device) if out16 is not None else None
         self._call("svcmi_bn_maxpool2_f32", _ptr(x), _ptr(scale), _ptr(shift), _ptr(y), B * (T // 2), Cc, x.stride(1), y.stride(1),
+                   _ptr(y16), y16.stride(1) if y16 is not None else 0, _fmt16(out16) if out16 is not None else 0,
                    self._stream(), work={"bytes": 6.0 * B * T * Cc})
-        return y
+        return y if out16 is None else (y, y16)
+
+    def act16_format(self):
+        """The 16-bit activation format of the current precision mode (``out16`` of the producers), None in fp32."""
+        return {PREC_BF16: torch.bfloat16, PREC_F16: torch.float16, PREC_BF16X3: SPLIT16}.get(self.precision)
 
     def viterbi_decode(self, prob, log_trans, batch_frames, minidx, maxidx, band=0):
         """prob [frames, 360] (sigmoid outputs), log_trans [360, 360] float64 -> decoded bins int32 [frames].

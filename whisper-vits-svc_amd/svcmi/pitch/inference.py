@@ -16,6 +16,7 @@ import numpy as np
 import torch
 
 from .. import weights as PW
+from .._lib import PREC_BF16X3
 from ..ops import ACT_RELU, ACT_SIGMOID, Ops
 
 CENTS_PER_BIN, PITCH_BINS, SAMPLE_RATE, WINDOW_SIZE = 20, 360, 16000, 1024
@@ -46,12 +47,19 @@ class Crepe:
         for f0 in range(0, total, batch_size):
             nf = min(batch_size, total - f0)
             x = ops.crepe_frames(audio, hop, f0, nf, FRAME_LD).view(nf, FRAME_LD // 4, 4)
+            # bf16 / f16 modes: the pooling kernel also writes the 16-bit rows the next layer's GEMM takes as its A operand (the _A16
+            # kernels: nothing rounded in the GEMM's registers, K-steps of 64).  Not in bf16x3: on these long-K layers split rows + the
+            # _BF16X3_A16 kernel are slower than the in-register split (layer 2: 3.6 vs 3.4 ms, profiles/r03p_microbench_x3a.log)
+            fmt16, x16 = (None if ops.precision == PREC_BF16X3 else ops.act16_format()), None
             for i, L in enumerate(w.layers):
                 if i == 0:      # 512 taps, stride 4, pad 254/254 == 128 taps, stride 1 over rows of 4 samples
                     x = ops.conv(x, L["w"], L["b"], ksize=128, pad=0, t_out=256, act=ACT_RELU)
                 else:           # 64 taps, pad 31/32 (the right pad is the kernel's out-of-range zero fill)
-                    x = ops.conv(x, L["w"], L["b"], ksize=64, pad=31, t_out=x.shape[1], act=ACT_RELU)
-                x = ops.bn_maxpool2(x, L["scale"], L["shift"])
+                    x = ops.conv(x, L["w"], L["b"], ksize=64, pad=31, t_out=x.shape[1], act=ACT_RELU, x16=x16)
+                if fmt16 is not None and i + 1 < len(w.layers):
+                    x, x16 = ops.bn_maxpool2(x, L["scale"], L["shift"], out16=fmt16)
+                else:
+                    x = ops.bn_maxpool2(x, L["scale"], L["shift"])
             feat = x.reshape(1, nf, -1)                     # [F, 4, 512] -> 2048 = h * 512 + c, model.py:112
             ops.conv(feat, w.fc_w, w.fc_b, act=ACT_SIGMOID, out=out[f0:f0 + nf].view(1, nf, PITCH_BINS))
         return out
