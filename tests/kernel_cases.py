@@ -410,6 +410,11 @@ ATTN_CASES_LDS = [
     dict(id="lds44_d64_T300", B=1, T=300, H=1, D=64, lds=44),
     dict(id="lds81_d64_T150", B=1, T=150, H=2, D=64, lds=81),
     dict(id="lds82_d64_ragged_T260", B=2, T=260, H=1, D=64, lengths=[200, 260], lds=82),
+    # the key-split kernel forced (no LDS staging) at every split of the head width Whisper uses
+    dict(id="ks_d64_T130_ns1", B=1, T=130, H=2, D=64, lds=-1, ns=1),
+    dict(id="ks_d64_ragged_T257_ns2", B=2, T=257, H=2, D=64, lengths=[257, 140], lds=-1, ns=2),
+    dict(id="ks_d64_T300_ns4_short_last_range", B=1, T=300, H=1, D=64, lds=-1, ns=4),
+    dict(id="ks_d64_T33_ns8_empty_ranges", B=1, T=33, H=1, D=64, lds=-1, ns=8),
 ]
 # the same kernel at the sizes it is selected for (GPU only)
 ATTN_CASES_LDS_LARGE = [
@@ -469,6 +474,8 @@ def check_attention(ops, c, device):
         assert ops.lib.svcmi_tune_set(b"attn_q32", 1) == 0 and ops.lib.svcmi_tune_set(b"attn_ns", c.get("ns", 0)) == 0
     if c.get("lds"):        # the LDS-staged kernel, forced to one of its compiled shapes
         assert ops.lib.svcmi_tune_set(b"attn_lds", int(c["lds"])) == 0
+    if c.get("lds") == -1:
+        assert ops.lib.svcmi_tune_set(b"attn_ns", c.get("ns", 0)) == 0
     try:
         got = ops.attention(dev(qkv), H, scale, rel_k=dev(rel_k), rel_v=dev(rel_v), window=c.get("W", 0), lengths=dev(lengths))
     finally:

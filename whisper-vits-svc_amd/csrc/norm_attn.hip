@@ -339,12 +339,52 @@ __global__ __launch_bounds__(64 * NS) void attention_kernel(AttnArgs p) {
     float mrun = NEG_BIG, lrun = 0.f;
 
     const float* kb = p.k + (long long)b * p.k_bs + h * D + 4 * g4;
-    const float* vb = p.v + (long long)b * p.v_bs + h * D + lq;
+    // V^T tiles: row i of tile dt is channel d = DS*i + dt, so a lane's DS A-operand values of a key are CONTIGUOUS in memory (one
+    // 16-byte load at D = 64 where per-channel tiles took four 4-byte ones; a wave instruction fetches 4 whole head rows)
+    const float* vb = p.v + (long long)b * p.v_bs + h * D + DS * lq;
     const int per = ((T + NS - 1) / NS + 31) / 32 * 32;     // keys per wave, a multiple of the 32-key step
     const int jbeg = w * per;
     const int jend = (jbeg + per) < T ? (jbeg + per) : T;
 
+    // (Requesting the next step's K fragments / this step's V values ahead of the MFMAs -- explicit software pipelining -- was measured
+    // and not kept: +32 / +64 VGPRs take the kernel from 4 to 3 / 2 waves per SIMD and one T = 500 window stays at 26-27 us,
+    // profiles/r03q_attnpf.log; with 4 waves per SIMD the other waves already cover a wave's load latency.)
+    auto load_k = [&](int kt, float4 (&ka)[2][DS]) {
+        const int k0 = kt + lq, k1 = kt + 16 + lq;
+        const float* kr0 = kb + (long long)(k0 < T ? k0 : T - 1) * p.ldk;
+        const float* kr1 = kb + (long long)(k1 < T ? k1 : T - 1) * p.ldk;
+#pragma unroll
+        for (int s = 0; s < DS; ++s) {
+            ka[0][s] = *reinterpret_cast<const float4*>(kr0 + 16 * s);
+            ka[1][s] = *reinterpret_cast<const float4*>(kr1 + 16 * s);
+        }
+    };
+    auto load_v = [&](int kt, float (&vv)[2][4][DS]) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt + 16 * u + 4 * g4 + r;
+                const float* vr = vb + (long long)(key < T ? key : T - 1) * p.ldv;
+                if constexpr (DS == 4) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(vr);
+                    vv[u][r][0] = t4.x; vv[u][r][1] = t4.y; vv[u][r][2] = t4.z; vv[u][r][3] = t4.w;
+                } else if constexpr (DS % 2 == 0) {
+#pragma unroll
+                    for (int e = 0; e < DS; e += 2) {
+                        const float2 t2 = *reinterpret_cast<const float2*>(vr + e);
+                        vv[u][r][e] = t2.x; vv[u][r][e + 1] = t2.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < DS; ++e) vv[u][r][e] = vr[e];
+                }
+            }
+    };
     for (int kt = jbeg; kt < jend; kt += 32) {
+        float vv[2][4][DS];
+        float4 kc[2][DS];
+        load_k(kt, kc);
         // ---- S^T = K Q^T for two 16-key tiles (two independent accumulators hide the 40-cycle MFMA latency)
         svcmi_f32x4 sacc[2];
 #pragma unroll
@@ -352,13 +392,10 @@ __global__ __launch_bounds__(64 * NS) void attention_kernel(AttnArgs p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) sacc[u][r] = 0.f;
         {
-            const int k0 = kt + lq, k1 = kt + 16 + lq;
-            const float* kr0 = kb + (long long)(k0 < T ? k0 : T - 1) * p.ldk;
-            const float* kr1 = kb + (long long)(k1 < T ? k1 : T - 1) * p.ldk;
 #pragma unroll
             for (int s = 0; s < DS; ++s) {
-                const float4 a0 = *reinterpret_cast<const float4*>(kr0 + 16 * s);
-                const float4 a1 = *reinterpret_cast<const float4*>(kr1 + 16 * s);
+                const float4 a0 = kc[0][s];
+                const float4 a1 = kc[1][s];
                 sacc[0] = svcmi_mfma_16x16x4(a0.x, qf[s][0], sacc[0]);
                 sacc[1] = svcmi_mfma_16x16x4(a1.x, qf[s][0], sacc[1]);
                 sacc[0] = svcmi_mfma_16x16x4(a0.y, qf[s][1], sacc[0]);
@@ -429,15 +466,13 @@ __global__ __launch_bounds__(64 * NS) void attention_kernel(AttnArgs p) {
             for (int e = 0; e < NREL; ++e) Pb[e] *= corr;
         }
         // ---- O^T += V^T P^T : step (u, r) contracts keys kt + 16u + {r, 4+r, 8+r, 12+r}
+        load_v(kt, vv);
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt + 16 * u + 4 * g4 + r;
-                const float* vr = vb + (long long)(key < T ? key : T - 1) * p.ldv;
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int dt = 0; dt < DS; ++dt) oacc[dt] = svcmi_mfma_16x16x4(vr[16 * dt], pv[u][r], oacc[dt]);
-            }
+                for (int dt = 0; dt < DS; ++dt) oacc[dt] = svcmi_mfma_16x16x4(vv[u][r][dt], pv[u][r], oacc[dt]);
     }
 
     // ---- publish this wave's state: O^T columns become rows of Opart
@@ -447,10 +482,20 @@ __global__ __launch_bounds__(64 * NS) void attention_kernel(AttnArgs p) {
         for (int e = 0; e < NREL; ++e) Pb[e] = quarter_sum(Pb[e]);
     }
     {
-        float* orow = Opart + (w * 16 + lq) * OLD + 4 * g4;
+        // oacc[dt][r] is channel d = DS * (4*g4 + r) + dt of query lq
+        float* orow = Opart + (w * 16 + lq) * OLD + DS * 4 * g4;
 #pragma unroll
-        for (int dt = 0; dt < DS; ++dt)
-            *reinterpret_cast<float4*>(orow + 16 * dt) = make_float4(oacc[dt][0], oacc[dt][1], oacc[dt][2], oacc[dt][3]);
+        for (int r = 0; r < 4; ++r) {
+            if constexpr (DS == 4) {
+                *reinterpret_cast<float4*>(orow + 4 * r) = make_float4(oacc[0][r], oacc[1][r], oacc[2][r], oacc[3][r]);
+            } else if constexpr (DS % 2 == 0) {
+#pragma unroll
+                for (int e = 0; e < DS; e += 2) *reinterpret_cast<float2*>(orow + DS * r + e) = make_float2(oacc[e][r], oacc[e + 1][r]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < DS; ++e) orow[DS * r + e] = oacc[e][r];
+            }
+        }
         if (g4 == 0) {
             Mpart[w * 16 + lq] = mrun;
             Lpart[w * 16 + lq] = lrun;
