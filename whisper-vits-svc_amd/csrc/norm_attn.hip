@@ -268,6 +268,44 @@ __device__ __forceinline__ float quarter_sum(float v) {    // sum over the 4 lan
     return v;
 }
 
+// V^T tiles of the second product: row i of tile dt is channel d = DS*i + dt, so the DS A-operand values a lane needs of one key are
+// CONTIGUOUS in memory (one 16-byte load at D = 64 where per-channel tiles took four 4-byte ones; a wave instruction then fetches 4
+// whole head rows).  `vr` = the key's row + DS * (lane & 15).
+template <int DS>
+__device__ __forceinline__ void load_vrow(const float* vr, float (&v)[DS]) {
+    if constexpr (DS == 4) {
+        const float4 t4 = *reinterpret_cast<const float4*>(vr);
+        v[0] = t4.x; v[1] = t4.y; v[2] = t4.z; v[3] = t4.w;
+    } else if constexpr (DS % 2 == 0) {
+#pragma unroll
+        for (int e = 0; e < DS; e += 2) {
+            const float2 t2 = *reinterpret_cast<const float2*>(vr + e);
+            v[e] = t2.x; v[e + 1] = t2.y;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < DS; ++e) v[e] = vr[e];
+    }
+}
+// ... and the accumulators back into channel order: oacc[dt][r] of lane (lq, g4) is channel DS * (4*g4 + r) + dt of query lq.
+// `orow` = the query's row of the partial-O tile.
+template <int DS>
+__device__ __forceinline__ void store_orow(float* orow, int g4, const svcmi_f32x4 (&oacc)[DS]) {
+    float* o = orow + DS * 4 * g4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if constexpr (DS == 4) {
+            *reinterpret_cast<float4*>(o + 4 * r) = make_float4(oacc[0][r], oacc[1][r], oacc[2][r], oacc[3][r]);
+        } else if constexpr (DS % 2 == 0) {
+#pragma unroll
+            for (int e = 0; e < DS; e += 2) *reinterpret_cast<float2*>(o + DS * r + e) = make_float2(oacc[e][r], oacc[e + 1][r]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < DS; ++e) o[DS * r + e] = oacc[e][r];
+        }
+    }
+}
+
 template <int D, int NS>
 __global__ __launch_bounds__(64 * NS) void attention_kernel(AttnArgs p) {
     constexpr int DS = D / 16;         // 16-wide d groups: float4 K/Q fragments per row and 16-row tiles of O^T
@@ -339,8 +377,6 @@ __global__ __launch_bounds__(64 * NS) void attention_kernel(AttnArgs p) {
     float mrun = NEG_BIG, lrun = 0.f;
 
     const float* kb = p.k + (long long)b * p.k_bs + h * D + 4 * g4;
-    // V^T tiles: row i of tile dt is channel d = DS*i + dt, so a lane's DS A-operand values of a key are CONTIGUOUS in memory (one
-    // 16-byte load at D = 64 where per-channel tiles took four 4-byte ones; a wave instruction fetches 4 whole head rows)
     const float* vb = p.v + (long long)b * p.v_bs + h * D + DS * lq;
     const int per = ((T + NS - 1) / NS + 31) / 32 * 32;     // keys per wave, a multiple of the 32-key step
     const int jbeg = w * per;
@@ -366,19 +402,7 @@ __global__ __launch_bounds__(64 * NS) void attention_kernel(AttnArgs p) {
             for (int r = 0; r < 4; ++r) {
                 const int key = kt + 16 * u + 4 * g4 + r;
                 const float* vr = vb + (long long)(key < T ? key : T - 1) * p.ldv;
-                if constexpr (DS == 4) {
-                    const float4 t4 = *reinterpret_cast<const float4*>(vr);
-                    vv[u][r][0] = t4.x; vv[u][r][1] = t4.y; vv[u][r][2] = t4.z; vv[u][r][3] = t4.w;
-                } else if constexpr (DS % 2 == 0) {
-#pragma unroll
-                    for (int e = 0; e < DS; e += 2) {
-                        const float2 t2 = *reinterpret_cast<const float2*>(vr + e);
-                        vv[u][r][e] = t2.x; vv[u][r][e + 1] = t2.y;
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < DS; ++e) vv[u][r][e] = vr[e];
-                }
+                load_vrow<DS>(vr, vv[u][r]);
             }
     };
     for (int kt = jbeg; kt < jend; kt += 32) {
@@ -482,20 +506,7 @@ __global__ __launch_bounds__(64 * NS) void attention_kernel(AttnArgs p) {
         for (int e = 0; e < NREL; ++e) Pb[e] = quarter_sum(Pb[e]);
     }
     {
-        // oacc[dt][r] is channel d = DS * (4*g4 + r) + dt of query lq
-        float* orow = Opart + (w * 16 + lq) * OLD + DS * 4 * g4;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if constexpr (DS == 4) {
-                *reinterpret_cast<float4*>(orow + 4 * r) = make_float4(oacc[0][r], oacc[1][r], oacc[2][r], oacc[3][r]);
-            } else if constexpr (DS % 2 == 0) {
-#pragma unroll
-                for (int e = 0; e < DS; e += 2) *reinterpret_cast<float2*>(orow + DS * r + e) = make_float2(oacc[e][r], oacc[e + 1][r]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < DS; ++e) orow[DS * r + e] = oacc[e][r];
-            }
-        }
+        store_orow<DS>(Opart + (w * 16 + lq) * OLD, g4, oacc);
         if (g4 == 0) {
             Mpart[w * 16 + lq] = mrun;
             Lpart[w * 16 + lq] = lrun;
@@ -600,7 +611,7 @@ __global__ __launch_bounds__(64 * NS) void attention_q32_kernel(AttnArgs p) {
     }
 
     const float* kb = p.k + (long long)b * p.k_bs + h * D + 4 * g4;
-    const float* vb = p.v + (long long)b * p.v_bs + h * D + lq;
+    const float* vb = p.v + (long long)b * p.v_bs + h * D + DS * lq;      // (channel order of the V^T tiles: load_vrow)
     const int per = ((T + NS - 1) / NS + 31) / 32 * 32;
     const int jbeg = w * per;
     const int jend = (jbeg + per) < T ? (jbeg + per) : T;
@@ -674,23 +685,19 @@ __global__ __launch_bounds__(64 * NS) void attention_q32_kernel(AttnArgs p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = kt + 16 * u + 4 * g4 + r;
-                const float* vr = vb + (long long)(key < T ? key : T - 1) * p.ldv;
+                float vv[DS];
+                load_vrow<DS>(vb + (long long)(key < T ? key : T - 1) * p.ldv, vv);
 #pragma unroll
-                for (int dt = 0; dt < DS; ++dt) {
-                    const float vv = vr[16 * dt];
+                for (int dt = 0; dt < DS; ++dt)
 #pragma unroll
-                    for (int a = 0; a < QT; ++a) oacc[a][dt] = svcmi_mfma_16x16x4(vv, pv[a][u][r], oacc[a][dt]);
-                }
+                    for (int a = 0; a < QT; ++a) oacc[a][dt] = svcmi_mfma_16x16x4(vv[dt], pv[a][u][r], oacc[a][dt]);
             }
     }
 
 #pragma unroll
     for (int a = 0; a < QT; ++a) {
         const float lsum = quarter_sum(lrun[a]);
-        float* orow = Opart + (w * QB + 16 * a + lq) * OLD + 4 * g4;
-#pragma unroll
-        for (int dt = 0; dt < DS; ++dt)
-            *reinterpret_cast<float4*>(orow + 16 * dt) = make_float4(oacc[a][dt][0], oacc[a][dt][1], oacc[a][dt][2], oacc[a][dt][3]);
+        store_orow<DS>(Opart + (w * QB + 16 * a + lq) * OLD, g4, oacc[a]);
         if (g4 == 0) {
             Mpart[w * QB + 16 * a + lq] = mrun[a];
             Lpart[w * QB + 16 * a + lq] = lsum;
