@@ -335,15 +335,16 @@ void whisper_fwd(Ctx& c, const svcmi_whisper_model& m, const float* mel, const f
     // bf16 / f16 modes: every GEMM's A operand is written as a 16-bit tensor by its producer (LayerNorm -> QKV and MLP-up, attention ->
     // out-projection, MLP-up's GELU epilogue -> MLP-down), so the GEMMs take the _A16 kernels: half the LDS bytes per MFMA, no rounding
     // in registers.  (The fp32 copies stay: LayerNorm output and residual stream are fp32 in every mode.)
-    // bf16x3: split rows [hi | lo] and the _BF16X3_A16 kernel for the QKV projection and MLP-down only -- the two launches it measurably
-    // speeds up (T = 500: 30.5 -> 23.9 us, 36.0 -> 31.9 us; the out-projection's short K slices and MLP-up are no faster or slower:
-    // profiles/r03p_microbench_x3a.log); the attention stays on the fp32 matrix cores.
+    // bf16x3: split rows [hi | lo] from the LayerNorms and the _BF16X3_A16 kernel for the QKV projection only -- the one launch it speeds up
+    // in place (T = 500: 30.5 -> 23.9 us).  MLP-down gains alone (36.0 -> 31.9 us) but only at the 64x64 tile with 8 K slices, which the
+    // split-K LayerNorm behind it and the split rows out of MLP-up's GELU epilogue give back; the out-projection's short K slices and
+    // MLP-up are no faster or slower (profiles/r03p_microbench_x3a.log); the attention stays on the fp32 matrix cores.
     const bool x3 = c.prec == SVCMI_PREC_BF16X3;
     const bool a16 = act16(c.prec) && S % 8 == 0 && F % 8 == 0;
     const int64_t e16 = 2 * w16(c.prec, 1);           // bytes per channel of a 16-bit row
     void* h16 = a16 ? c.ar.take((int64_t)B * tw * S * e16) : nullptr;
     void* at16 = a16 && !x3 ? c.ar.take((int64_t)B * tw * S * e16) : nullptr;
-    void* mm16 = a16 ? c.ar.take((int64_t)B * tw * F * e16) : nullptr;
+    void* mm16 = a16 && !x3 ? c.ar.take((int64_t)B * tw * F * e16) : nullptr;
     // ... and the attention itself runs on the 16-bit matrix cores from the QKV projection's 16-bit output copy (svcmi_attention16)
     const bool att16 = a16 && mode16(c.prec) && (S / H == 64 || S / H == 32);
     void* qkv16 = att16 ? c.ar.take((int64_t)B * tw * 3 * S * 2) : nullptr;

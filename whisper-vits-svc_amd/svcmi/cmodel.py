@@ -38,7 +38,7 @@ def whisper_cmodel(w, ops, prec=PREC_F32):
         raise _lib.SvcmiError(f"{w.n_layers} encoder blocks > {_lib.MAX_WHISPER_BLOCKS}")
     m.n_state, m.n_heads, m.n_layers, m.n_mels = w.S, w.heads, w.n_layers, w.n_mels
     m.n_ctx, m.precision = int(w.pos.shape[0]), prec
-    x3 = prec == PREC_BF16X3         # split-bf16: only the QKV projection and MLP-down take 16-bit (split) activation rows (host_stages.hip)
+    x3 = prec == PREC_BF16X3         # split-bf16: only the QKV projection takes 16-bit (split) activation rows (host_stages.hip)
     _weight(m.conv1, ops, w.conv1_w, w.conv1_b, prec, keep)
     _weight(m.conv2, ops, w.conv2_w, w.conv2_b, prec, keep)
     m.pos, m.lnp_g, m.lnp_b = w.pos.data_ptr(), w.lnp_g.data_ptr(), w.lnp_b.data_ptr()
@@ -48,7 +48,7 @@ def whisper_cmodel(w, ops, prec=PREC_F32):
         _weight(cb.qkv, ops, b["qkv_w"], b["qkv_b"], prec, keep, a16=True)
         _weight(cb.o, ops, b["o_w"], b["o_b"], prec, keep, a16=not x3)
         _weight(cb.m1, ops, b["m1_w"], b["m1_b"], prec, keep, a16=not x3)
-        _weight(cb.m2, ops, b["m2_w"], b["m2_b"], prec, keep, a16=True)
+        _weight(cb.m2, ops, b["m2_w"], b["m2_b"], prec, keep, a16=not x3)
     return CModel(m, keep)
 
 
