@@ -90,6 +90,12 @@ def main():
                 gemm(ops, "whisper_mlp1", T, 1280, 5120, tiles=(1, 9, 3), splits=(1,), prec="f16", a16=a16)
                 gemm(ops, "whisper_o", T, 1280, 1280, tiles=(1, 9), splits=(1, 2, 4), prec="f16", partials=True, a16=a16)
                 gemm(ops, "whisper_mlp2", T, 5120, 1280, tiles=(1, 9), splits=(1, 2, 4, 8), prec="f16", partials=True, a16=a16)
+    if "biggemm" in what:     # chip-filling GEMMs, one tile policy per kernel family (for PMC runs: scripts/pmc_cmd.sh)
+        gemm(ops, "square4096", 4096, 4096, 4096, tiles=(3,), splits=(1,))
+        gemm(ops, "square4096", 4096, 4096, 4096, tiles=(3,), splits=(1,), prec="bf16x3")
+        gemm(ops, "square4096", 4096, 4096, 4096, tiles=(3,), splits=(1,), prec="bf16")
+        gemm(ops, "square4096", 4096, 4096, 4096, tiles=(3,), splits=(1,), prec="bf16", a16=True)
+        gemm(ops, "crepe_l2_B512", 128, 1024, 128, k=64, tiles=(3,), splits=(1,), B=512, prec="bf16x3")
     if "x3a" in what:         # split-bf16 products: in-register split (K-step 32) vs split activation rows from the producer (K-step 64)
         for T in (500, 750):
             for a16 in (False, True):
