@@ -16,6 +16,7 @@ for C in 2 3 4; do timeout 900 python bench.py --config $C > $OUT/bench_c$C.json
 timeout 600 python bench.py --config 2 --precision f16 > $OUT/bench_c2_f16.json 2>/dev/null; show $OUT/bench_c2_f16.json
 timeout 600 python bench.py --config 3 --precision bf16x3 --no-roofline > $OUT/bench_c3_bf16x3.json 2>/dev/null; show $OUT/bench_c3_bf16x3.json
 timeout 600 python scripts/dropin_times.py 10 bf16x3 > $OUT/dropin_times.log 2>&1; tail -9 $OUT/dropin_times.log
+timeout 600 python scripts/dropin_times.py 10 f16 > $OUT/dropin_times_f0_f16.log 2>&1; tail -3 $OUT/dropin_times_f0_f16.log      # --f0-precision f16 (CREPE on the 16-bit-activation kernels)
 # two ranks on the one GPU (gloo: RCCL refuses duplicate devices): the N > 1 code path of bench.py (packed broadcast -> views -> C model structs)
 SVCMI_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 6 --warmup 2 --no-roofline > $OUT/bench_2ranks_1gpu.json 2> $OUT/bench_2ranks_1gpu.err; echo "2 ranks rc=$?"; show $OUT/bench_2ranks_1gpu.json
 # rocprofv3 kernel stats + PMC of the f16 line (16-bit activations, f16 attention)

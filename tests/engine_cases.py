@@ -271,10 +271,21 @@ def check_crepe_precision(ops, device, capacity, n, precision, tol):
         want = CO.network(sd, CO.preprocess(audio[None], 320))
     err = maxerr(got, want)
     code = PRECISIONS[precision] + 2
-    for L in m.w.layers[1:]:
-        assert getattr(L["w"], "_svcmi_lp", {}).get(code) is not None, "the 16-bit-activation kernel did not run"
+    for L in m.w.layers[1:]:          # (the short layers run as dense GEMMs over the frames: weights.CrepeWeights)
+        assert getattr(L.get("dense_w", L["w"]), "_svcmi_lp", {}).get(code) is not None, "the 16-bit-activation kernel did not run"
     assert 0.0 < err <= tol, err
-    return err
+    # what the path consumes is the decoded F0 track (Viterbi over the 360 bins): the share of frames whose Hz value is the oracle's
+    from svcmi.pitch import compute_f0_sing
+    g = torch.Generator().manual_seed(9)
+    noise = torch.randn(n, generator=g)
+    dither = (torch.rand(1 + n // 320, generator=g) * 2 - 1).numpy() * 20.0
+    ops.lp_min_flops = 0.0
+    f0 = compute_f0_sing(audio, device, model=m, noise=noise, dither=dither)
+    ops.lp_min_flops = saved
+    with torch.no_grad():
+        f0_ref = CO.compute_f0_sing(sd, audio, noise, dither).numpy()
+    same = float(np.isclose(f0, f0_ref, rtol=1e-5, atol=1e-3, equal_nan=True).mean())
+    return err, same
 
 
 def check_crepe_golden(ops, device, tol=2e-5, precision=None):

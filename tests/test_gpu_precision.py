@@ -174,7 +174,8 @@ def test_extractors_in_bf16x3_match_the_reference_goldens(ops):
 def test_crepe_full_16bit_activation_chain(ops, mode, tol):
     """CREPE `full` on 3 s: layers 2-6 take the pooling kernel's 16-bit rows through the _A16 GEMM kernels; posterior error against
     the fp32 oracle inside the mode's class."""
-    err = E.check_crepe_precision(ops, "cuda", "full", 48000, mode, tol)
-    REPORT.setdefault("crepe_a16", {})[mode] = err
-    print(f"crepe full {mode} (16-bit activation chain): posterior err {err:.2e}")
+    err, same = E.check_crepe_precision(ops, "cuda", "full", 48000, mode, tol)
+    REPORT.setdefault("crepe_a16", {})[mode] = dict(posterior_max_abs=err, f0_frames_equal_to_fp32_oracle=same)
+    print(f"crepe full {mode} (16-bit activation chain): posterior err {err:.2e}, decoded F0 equal to the fp32 oracle's on {same:.4f} of the frames")
+    assert same >= (0.97 if mode == "f16" else 0.90)
 

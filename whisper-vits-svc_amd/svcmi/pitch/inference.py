@@ -54,6 +54,10 @@ class Crepe:
             for i, L in enumerate(w.layers):
                 if i == 0:      # 512 taps, stride 4, pad 254/254 == 128 taps, stride 1 over rows of 4 samples
                     x = ops.conv(x, L["w"], L["b"], ksize=128, pad=0, t_out=256, act=ACT_RELU)
+                elif "dense_w" in L and x.shape[1] == L["t_in"]:     # short layers: one dense GEMM with the frames as rows (weights.CrepeWeights)
+                    t_in, c_in = x.shape[1], x.shape[2]
+                    x = ops.conv(x.view(1, nf, t_in * c_in), L["dense_w"], L["dense_b"], act=ACT_RELU,
+                                 x16=None if x16 is None else x16.view(1, nf, t_in * c_in)).view(nf, t_in, -1)
                 else:           # 64 taps, pad 31/32 (the right pad is the kernel's out-of-range zero fill)
                     x = ops.conv(x, L["w"], L["b"], ksize=64, pad=31, t_out=x.shape[1], act=ACT_RELU, x16=x16)
                 if fmt16 is not None and i + 1 < len(w.layers):

@@ -160,7 +160,7 @@ def build_parser():
     p.add_argument("--crepe", type=str, default=os.path.join("crepe", "assets", "full.pth"))
     p.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16", "f16"],
                    help="GEMM operand precision of Whisper / HuBERT / synthesizer (see svc_inference); f32 = parity default")
-    p.add_argument("--f0-precision", default="bf16x3", choices=["f32", "bf16x3"], help="GEMM operand precision of the CREPE F0 extractor (see svc_inference)")
+    p.add_argument("--f0-precision", default="bf16x3", choices=["f32", "bf16x3", "f16", "bf16"], help="GEMM operand precision of the CREPE F0 extractor (see svc_inference)")
     p.add_argument("--workers", type=int, default=3,
                    help="files in flight per GPU: worker threads, each converting its files on its own HIP stream (1 = the reference's order)")
     return p

@@ -239,6 +239,10 @@ class HubertWeights:
         self.proj_w, self.proj_b = f(pack_conv(sd["proj.weight"].unsqueeze(-1))), f(sd["proj.bias"])
 
 
+CREPE_FRAME_ROWS = 256          # rows out of the first CREPE layer for a 1024-sample frame (stride 4)
+CREPE_DENSE_MAX_ROWS = 32       # layers with at most this many input rows run as one dense GEMM over the frames (CrepeWeights)
+
+
 class CrepeWeights:
     """Packed ``crepe.Crepe`` parameters (crepe/model.py state-dict keys): Conv2d [out, in, k, 1] -> implicit-GEMM
     operand [out, k*in]; eval-mode BatchNorm2d (eps 0.0010000000474974513) -> per-channel scale / shift."""
@@ -256,7 +260,21 @@ class CrepeWeights:
             g, b = sd[f"conv{i}_BN.weight"].float(), sd[f"conv{i}_BN.bias"].float()
             mu, var = sd[f"conv{i}_BN.running_mean"].float(), sd[f"conv{i}_BN.running_var"].float()
             scale = g / torch.sqrt(var + eps)
-            self.layers.append(dict(w=f(packed), b=f(sd[f"conv{i}.bias"]), scale=f(scale), shift=f(b - mu * scale)))
+            layer = dict(w=f(packed), b=f(sd[f"conv{i}.bias"]), scale=f(scale), shift=f(b - mu * scale))
+            # Short layers as ONE dense GEMM over the frames.  A 1024-sample frame leaves t_in = 256 / 2^(i-1) rows for layer i; at
+            # t_in <= 32 every output row sees every input row (64 taps, pad 31 / 32), so the layer is the linear map
+            #     y[f, (t_out, n)] = sum_{t_in, c} x[f, (t_in, c)] * w[n, c, t_in - t_out + 31]
+            # with the frames as GEMM rows: no 64-row tile padded from 8-32 time steps and no taps that only ever meet the zero
+            # padding (64x / 16x / 4x less matrix work than the implicit convolution for t_in = 8 / 16 / 32).
+            t_in = CREPE_FRAME_ROWS >> (i - 1)
+            if i > 1 and t_in <= CREPE_DENSE_MAX_ROWS:
+                n_out, c_in, taps = w.shape
+                ti = torch.arange(t_in)
+                k = ti[None, :] - ti[:, None] + (taps // 2 - 1)                       # [t_out, t_in] tap index, always inside 0..taps-1 here
+                assert int(k.min()) >= 0 and int(k.max()) < taps
+                dense = w[:, :, k].permute(2, 0, 3, 1).reshape(t_in * n_out, t_in * c_in)      # [(t_out, n), (t_in, c)]
+                layer.update(dense_w=f(dense), dense_b=f(sd[f"conv{i}.bias"].float().repeat(t_in)), t_in=t_in)
+            self.layers.append(layer)
             i += 1
         self.fc_w = f(pack_conv(sd["classifier.weight"].float().unsqueeze(-1)))
         self.fc_b = f(sd["classifier.bias"])
