@@ -538,7 +538,8 @@ typedef struct svcmi_synth_io {
     const float* noise;      /* [batch][inter][t]: the randn_like(m) of vits/models.py:51 in the reference's layout */
     int64_t ppg_bstride;     /* floats; 0 = dense */
     int32_t ppg_row_shift, batch, t;
-    int32_t stream_frames;   /* 0 = the generator sees the whole chunk; N = time tiles of N frames + 32-frame halos (bit-identical) */
+    int32_t stream_frames;   /* 0 = the generator sees the whole chunk; N = time tiles of N frames + 32-frame halos (bit-identical for every N: */
+                             /* the kernels' per-row arithmetic does not depend on the launch size, tile policies are pinned by stage width) */
     int32_t stop_after;      /* enum svcmi_synth_stop: timing aid (scripts/stage_times.py): the pipeline stops there, `wave` is not written */
     int32_t reserved;
     /* outputs */

@@ -186,7 +186,7 @@ def test_streaming_decoder_is_bit_identical_and_matches_oracle_on_30s_chunk(ops)
     clip run through svc_infer WITH tiling matches the oracle like the untiled path does."""
     from svcmi import DummyRetrieval, svc_infer
     hp = C.base_hp()
-    print("tiled vs default path:", E.check_streaming_decoder(ops, "cuda", hp, T=1300, tiles=(256, 500, 1000), B=2))
+    print("tiled vs default path:", E.check_streaming_decoder(ops, "cuda", hp, T=1300, tiles=(256, 500, 1000, 17), B=2))      # 17: tiles of 49-81 frames, below every row-count threshold of the tile heuristics
     m, sd = E.make_model(hp, ops, "cuda")
     T, hop = 3000, 320
     d = I.synth_clip(T=T, hp=hp, seed=31, B=1)

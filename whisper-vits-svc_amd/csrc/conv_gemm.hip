@@ -13,6 +13,7 @@ extern "C" int svcmi_conv_gemm_f32(const svcmi_conv_desc* d, void* stream) {
     int p16_nt = 0, p16_wm = 1;
     const int n16 = (d->n_out + 15) / 16;
     const bool p16_ok = mode == MODE_CHUNK || mode == MODE_VEC;
+    if (tile > SVCMI_CONV_TILE_P16_64x160) return SVCMI_EUNSUPPORTED;      // (64x128 exists on the reduced-precision kernels only)
     if (tile >= SVCMI_CONV_TILE_P16_64x48) {                       // explicit override (tuning / tests)
         if (!p16_ok) return SVCMI_EUNSUPPORTED;
         p16_nt = tile == SVCMI_CONV_TILE_P16_64x160 ? 10 : (tile >= SVCMI_CONV_TILE_P16_64x80 ? 5 : 3);

@@ -125,6 +125,11 @@ int a16_code(int prec) { return prec == SVCMI_PREC_BF16X3 ? SVCMI_PREC_BF16X3_A1
 
 int conv_t_out(const CV& v) { return v.t_out >= 0 ? v.t_out : (v.t_in + 2 * v.pad - v.dil * (v.ksize - 1) - 1) / v.stride + 1; }
 
+// Tile of the AMP convolutions by stage width alone: the library's own choice also looks at the row count (the 16x16x4 policy from 1024
+// rows up), and the two policies sum K in different orders -- a streamed tile shorter than that would then differ from the whole-chunk run
+// in the last bit.  Pinned, every tile size gives the same bits.
+int amp_tile(int cp) { const int n16 = (cp + 15) / 16; return n16 == 3 ? 4 : (n16 == 5 ? 6 : 0); }      // SVCMI_CONV_TILE_P16_64x48 / _64x80 >> 8
+
 bool lp_tile_ok(int tile) { return tile == 0 || tile == 1 || tile == 3 || tile == 4 || tile == 6 || tile == 9; }
 
 // fills the descriptor; returns the precision code of the launch (SVCMI_PREC_F32 = the fp32 kernel)
@@ -565,7 +570,7 @@ void amp_block_seq(Ctx& c, const svcmi_synth_model& m, const svcmi_gen_stage& st
             });
         } else {
             snake_alias(c, m, xc, tmp, Snk{blk.a1_alpha[q], blk.a1_beta[q]}, B, L, cp, cp);
-            CV v; v.B = B; v.t_in = (int)L; v.c_in = v.ldx = cp; v.x_bs = bs; v.y_bs = bs; v.ldy = cp; v.ksize = k;
+            CV v; v.B = B; v.t_in = (int)L; v.c_in = v.ldx = cp; v.x_bs = bs; v.y_bs = bs; v.ldy = cp; v.ksize = k; v.tile = amp_tile(cp);
             { CV a = v; a.x = tmp; a.w = &blk.c1[q]; a.dil = d; a.pad = (k * d - d) / 2; a.y = tmp2; conv(c, a); }
             snake_alias(c, m, tmp2, tmp, Snk{blk.a2_alpha[q], blk.a2_beta[q]}, B, L, cp, cp);
             {
@@ -645,6 +650,7 @@ bool amp_stage_grouped(Ctx& c, const svcmi_synth_model& m, const svcmi_gen_stage
                 const svcmi_amp_block& b = st.blocks[j];
                 CV& v = vs[j]; v = CV();
                 v.x = t1[j]; v.x16 = t1h[j]; v.x_bs = bs; v.B = B; v.t_in = (int)L; v.c_in = v.ldx = cp; v.w = &b.c1[q]; v.ksize = b.k; v.dil = b.dil[q];
+                v.tile = amp_tile(cp);
                 v.pad = (b.k * b.dil[q] - b.dil[q]) / 2; v.y = t2[j]; v.y_bs = bs; v.ldy = cp;
             }
             snake(false);
@@ -653,6 +659,7 @@ bool amp_stage_grouped(Ctx& c, const svcmi_synth_model& m, const svcmi_gen_stage
                 const svcmi_amp_block& b = st.blocks[j];
                 CV& v = vs[j]; v = CV();
                 v.x = t1[j]; v.x16 = t1h[j]; v.x_bs = bs; v.B = B; v.t_in = (int)L; v.c_in = v.ldx = cp; v.w = &b.c2[q]; v.ksize = b.k; v.pad = (b.k - 1) / 2;
+                v.tile = amp_tile(cp);
                 v.res = xc[j]; v.res_bs = bs; v.ldr = cp; v.y = outs[j]; v.y_bs = bs; v.ldy = cp;
             }
             snake(true);

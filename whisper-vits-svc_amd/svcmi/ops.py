@@ -361,6 +361,8 @@ class Ops:
                 d.x, d.w, d.ldx, d.x_bstride = x16.data_ptr(), img.data_ptr(), x16.stride(1), x16.stride(0)
             self._call("svcmi_conv_gemm_lp", ctypes.byref(d), prec, self._stream(), work=work)
         else:
+            if (d.flags >> 8) & 15 == 9:          # SVCMI_CONV_TILE_64x128 is a reduced-precision tile: on the fp32 kernel the library chooses
+                d.flags &= ~0xF00
             self._call("svcmi_conv_gemm_f32", ctypes.byref(d), self._stream(), work=work)
         if kw.get("partials"):      # [B, split, t_out, N] view of this stream's workspace; valid until the next split-K launch on it
             return ws[0][:B * d.split_k * t_out * N].view(B, d.split_k, t_out, N)
