@@ -173,23 +173,31 @@ __global__ __launch_bounds__(256) void splitk_layernorm_kernel(const float* part
     float* xr = x + (long long)row * ldx;
     const float* pr = part + ((long long)b * split * rows_per_batch + t) * c;
     const long long sstride = (long long)rows_per_batch * c;
-    float4 v[SKV];
+    float4 v[SKV], gv[SKV], bv[SKV];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < SKV; ++i) {
         const int q = threadIdx.x + 256 * i;
         v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (q < nv) {
+        if (q < nv) {       // (the affine parameters too: behind the two block reductions their latency would be exposed once more)
+            gv[i] = gamma ? *reinterpret_cast<const float4*>(gamma + 4 * q) : make_float4(1.f, 1.f, 1.f, 1.f);
+            bv[i] = beta ? *reinterpret_cast<const float4*>(beta + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            // every operand of this item is requested before the first add: the slabs of up to 4 slices at a time (a run-time trip count
+            // made the loop wait for each slice in turn: 4 dependent L2 round trips per row at MLP-down), the bias and the residual row;
+            // the slices are still added in slice order
             float4 acc = *reinterpret_cast<const float4*>(pr + 4 * q);
-            for (int sl = 1; sl < split; ++sl) {
-                const float4 u = *reinterpret_cast<const float4*>(pr + sl * sstride + 4 * q);
-                acc.x += u.x; acc.y += u.y; acc.z += u.z; acc.w += u.w;
-            }
-            if (bias) {
-                const float4 bb = *reinterpret_cast<const float4*>(bias + 4 * q);
-                acc.x += bb.x; acc.y += bb.y; acc.z += bb.z; acc.w += bb.w;
-            }
             const float4 xo = *reinterpret_cast<const float4*>(xr + 4 * q);
+            const float4 bb = bias ? *reinterpret_cast<const float4*>(bias + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int sl0 = 1; sl0 < split; sl0 += 4) {
+                float4 u[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    u[e] = sl0 + e < split ? *reinterpret_cast<const float4*>(pr + (sl0 + e) * sstride + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (sl0 + e < split) { acc.x += u[e].x; acc.y += u[e].y; acc.z += u[e].z; acc.w += u[e].w; }
+            }
+            if (bias) { acc.x += bb.x; acc.y += bb.y; acc.z += bb.z; acc.w += bb.w; }
             acc.x += xo.x; acc.y += xo.y; acc.z += xo.z; acc.w += xo.w;      // epilogue order of the GEMM: (sum + bias) + res
             *reinterpret_cast<float4*>(xr + 4 * q) = acc;
             v[i] = acc;
@@ -211,8 +219,7 @@ __global__ __launch_bounds__(256) void splitk_layernorm_kernel(const float* part
     for (int i = 0; i < SKV; ++i) {
         const int q = threadIdx.x + 256 * i;
         if (q < nv) {
-            const float4 g = gamma ? *reinterpret_cast<const float4*>(gamma + 4 * q) : make_float4(1.f, 1.f, 1.f, 1.f);
-            const float4 bb = beta ? *reinterpret_cast<const float4*>(beta + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 g = gv[i], bb = bv[i];
             float4 o;
             o.x = (v[i].x - mean) * rstd * g.x + bb.x;
             o.y = (v[i].y - mean) * rstd * g.y + bb.y;
@@ -268,41 +275,39 @@ __device__ __forceinline__ float quarter_sum(float v) {    // sum over the 4 lan
     return v;
 }
 
-// V^T tiles of the second product: row i of tile dt is channel d = DS*i + dt, so the DS A-operand values a lane needs of one key are
-// CONTIGUOUS in memory (one 16-byte load at D = 64 where per-channel tiles took four 4-byte ones; a wave instruction then fetches 4
-// whole head rows).  `vr` = the key's row + DS * (lane & 15).
+// V^T tiles of the second product.  Head widths 32 / 64 (DS = 2 / 4): row i of tile dt is channel d = DS*i + dt, so the DS A-operand
+// values a lane needs of one key are CONTIGUOUS in memory (one 16-byte load at D = 64 where per-channel tiles took four 4-byte ones; a
+// wave instruction then fetches 4 whole head rows).  Other widths keep row i of tile dt = channel 16*dt + i (at D = 96 three 8-byte loads
+// per key measured SLOWER than six 4-byte ones: 40.2 vs 31.7 us for the T = 1000 prior-encoder launch, profiles/r03x_kernel_stats.csv).
+// `vrow` = the key's row of this head; lq = lane & 15.
 template <int DS>
-__device__ __forceinline__ void load_vrow(const float* vr, float (&v)[DS]) {
+__device__ __forceinline__ void load_vrow(const float* vrow, int lq, float (&v)[DS]) {
     if constexpr (DS == 4) {
-        const float4 t4 = *reinterpret_cast<const float4*>(vr);
+        const float4 t4 = *reinterpret_cast<const float4*>(vrow + 4 * lq);
         v[0] = t4.x; v[1] = t4.y; v[2] = t4.z; v[3] = t4.w;
-    } else if constexpr (DS % 2 == 0) {
-#pragma unroll
-        for (int e = 0; e < DS; e += 2) {
-            const float2 t2 = *reinterpret_cast<const float2*>(vr + e);
-            v[e] = t2.x; v[e + 1] = t2.y;
-        }
+    } else if constexpr (DS == 2) {
+        const float2 t2 = *reinterpret_cast<const float2*>(vrow + 2 * lq);
+        v[0] = t2.x; v[1] = t2.y;
     } else {
 #pragma unroll
-        for (int e = 0; e < DS; ++e) v[e] = vr[e];
+        for (int e = 0; e < DS; ++e) v[e] = vrow[16 * e + lq];
     }
 }
-// ... and the accumulators back into channel order: oacc[dt][r] of lane (lq, g4) is channel DS * (4*g4 + r) + dt of query lq.
-// `orow` = the query's row of the partial-O tile.
+// ... and the accumulators back into channel order: oacc[dt][r] of lane (lq, g4) is channel DS * (4*g4 + r) + dt (contiguous form) or
+// 16*dt + 4*g4 + r of query lq.  `orow` = the query's row of the partial-O tile.
 template <int DS>
 __device__ __forceinline__ void store_orow(float* orow, int g4, const svcmi_f32x4 (&oacc)[DS]) {
-    float* o = orow + DS * 4 * g4;
+    if constexpr (DS == 4) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        if constexpr (DS == 4) {
-            *reinterpret_cast<float4*>(o + 4 * r) = make_float4(oacc[0][r], oacc[1][r], oacc[2][r], oacc[3][r]);
-        } else if constexpr (DS % 2 == 0) {
+        for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<float4*>(orow + 16 * g4 + 4 * r) = make_float4(oacc[0][r], oacc[1][r], oacc[2][r], oacc[3][r]);
+    } else if constexpr (DS == 2) {
 #pragma unroll
-            for (int e = 0; e < DS; e += 2) *reinterpret_cast<float2*>(o + DS * r + e) = make_float2(oacc[e][r], oacc[e + 1][r]);
-        } else {
+        for (int r = 0; r < 4; ++r) *reinterpret_cast<float2*>(orow + 8 * g4 + 2 * r) = make_float2(oacc[0][r], oacc[1][r]);
+    } else {
 #pragma unroll
-            for (int e = 0; e < DS; ++e) o[DS * r + e] = oacc[e][r];
-        }
+        for (int dt = 0; dt < DS; ++dt)
+            *reinterpret_cast<float4*>(orow + 16 * dt + 4 * g4) = make_float4(oacc[dt][0], oacc[dt][1], oacc[dt][2], oacc[dt][3]);
     }
 }
 
@@ -377,7 +382,7 @@ __global__ __launch_bounds__(64 * NS) void attention_kernel(AttnArgs p) {
     float mrun = NEG_BIG, lrun = 0.f;
 
     const float* kb = p.k + (long long)b * p.k_bs + h * D + 4 * g4;
-    const float* vb = p.v + (long long)b * p.v_bs + h * D + DS * lq;
+    const float* vb = p.v + (long long)b * p.v_bs + h * D;
     const int per = ((T + NS - 1) / NS + 31) / 32 * 32;     // keys per wave, a multiple of the 32-key step
     const int jbeg = w * per;
     const int jend = (jbeg + per) < T ? (jbeg + per) : T;
@@ -395,18 +400,7 @@ __global__ __launch_bounds__(64 * NS) void attention_kernel(AttnArgs p) {
             ka[1][s] = *reinterpret_cast<const float4*>(kr1 + 16 * s);
         }
     };
-    auto load_v = [&](int kt, float (&vv)[2][4][DS]) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt + 16 * u + 4 * g4 + r;
-                const float* vr = vb + (long long)(key < T ? key : T - 1) * p.ldv;
-                load_vrow<DS>(vr, vv[u][r]);
-            }
-    };
     for (int kt = jbeg; kt < jend; kt += 32) {
-        float vv[2][4][DS];
         float4 kc[2][DS];
         load_k(kt, kc);
         // ---- S^T = K Q^T for two 16-key tiles (two independent accumulators hide the 40-cycle MFMA latency)
@@ -490,13 +484,16 @@ __global__ __launch_bounds__(64 * NS) void attention_kernel(AttnArgs p) {
             for (int e = 0; e < NREL; ++e) Pb[e] *= corr;
         }
         // ---- O^T += V^T P^T : step (u, r) contracts keys kt + 16u + {r, 4+r, 8+r, 12+r}
-        load_v(kt, vv);
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt + 16 * u + 4 * g4 + r;
+                float vv[DS];
+                load_vrow<DS>(vb + (long long)(key < T ? key : T - 1) * p.ldv, lq, vv);
 #pragma unroll
-                for (int dt = 0; dt < DS; ++dt) oacc[dt] = svcmi_mfma_16x16x4(vv[u][r][dt], pv[u][r], oacc[dt]);
+                for (int dt = 0; dt < DS; ++dt) oacc[dt] = svcmi_mfma_16x16x4(vv[dt], pv[u][r], oacc[dt]);
+            }
     }
 
     // ---- publish this wave's state: O^T columns become rows of Opart
@@ -611,7 +608,7 @@ __global__ __launch_bounds__(64 * NS) void attention_q32_kernel(AttnArgs p) {
     }
 
     const float* kb = p.k + (long long)b * p.k_bs + h * D + 4 * g4;
-    const float* vb = p.v + (long long)b * p.v_bs + h * D + DS * lq;      // (channel order of the V^T tiles: load_vrow)
+    const float* vb = p.v + (long long)b * p.v_bs + h * D;
     const int per = ((T + NS - 1) / NS + 31) / 32 * 32;
     const int jbeg = w * per;
     const int jend = (jbeg + per) < T ? (jbeg + per) : T;
@@ -686,7 +683,7 @@ __global__ __launch_bounds__(64 * NS) void attention_q32_kernel(AttnArgs p) {
             for (int r = 0; r < 4; ++r) {
                 const int key = kt + 16 * u + 4 * g4 + r;
                 float vv[DS];
-                load_vrow<DS>(vb + (long long)(key < T ? key : T - 1) * p.ldv, vv);
+                load_vrow<DS>(vb + (long long)(key < T ? key : T - 1) * p.ldv, lq, vv);
 #pragma unroll
                 for (int dt = 0; dt < DS; ++dt)
 #pragma unroll

@@ -24,11 +24,20 @@ __global__ __launch_bounds__(TPB) void wn_gate_kernel(const float* a, const floa
         const float* ap = a + (long long)b * a_bs + (long long)tt * lda + c;
         float4 ta = *reinterpret_cast<const float4*>(ap);
         float4 sa = *reinterpret_cast<const float4*>(ap + h);
-        for (int s = 1; s < splits; ++s) {       // fixed slab order: deterministic
-            const float4 t2 = *reinterpret_cast<const float4*>(ap + s * slab_stride);
-            const float4 s2 = *reinterpret_cast<const float4*>(ap + s * slab_stride + h);
-            ta.x += t2.x; ta.y += t2.y; ta.z += t2.z; ta.w += t2.w;
-            sa.x += s2.x; sa.y += s2.y; sa.z += s2.z; sa.w += s2.w;
+        for (int s0 = 1; s0 < splits; s0 += 3) {       // fixed slab order: deterministic; up to 3 slabs requested before the first add
+            float4 t2[3], s2[3];
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                const bool on = s0 + e < splits;
+                t2[e] = on ? *reinterpret_cast<const float4*>(ap + (s0 + e) * slab_stride) : make_float4(0.f, 0.f, 0.f, 0.f);
+                s2[e] = on ? *reinterpret_cast<const float4*>(ap + (s0 + e) * slab_stride + h) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int e = 0; e < 3; ++e)
+                if (s0 + e < splits) {
+                    ta.x += t2[e].x; ta.y += t2[e].y; ta.z += t2[e].z; ta.w += t2[e].w;
+                    sa.x += s2[e].x; sa.y += s2[e].y; sa.z += s2[e].z; sa.w += s2[e].w;
+                }
         }
         if (bias) {
             const float4 tb = *reinterpret_cast<const float4*>(bias + c);
