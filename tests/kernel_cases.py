@@ -787,6 +787,13 @@ def check_outputs16(ops, device):
         assert torch.equal(o16.cpu(), want(o))
     y, y16 = ops.layernorm(d(x[..., :36].contiguous()), out16=SPLIT16)                      # a row length with pad columns (Cp = 40)
     assert y16.shape[-1] == 80 and torch.equal(y16.cpu(), _split16(y.cpu()))
+    # CREPE's BatchNorm + max-pool (svcmi_bn_maxpool2_f32) with its 16-bit second output
+    xb, sc, sh = torch.randn(3, 10, 24, generator=g), torch.rand(24, generator=g) + 0.5, torch.randn(24, generator=g)
+    want = torch.maximum(xb[:, 0::2] * sc + sh, xb[:, 1::2] * sc + sh)
+    for dt in (torch.float16, torch.bfloat16, SPLIT16):
+        yb, yb16 = ops.bn_maxpool2(d(xb), d(sc), d(sh), out16=dt)
+        _close(yb, want, 1e-6, "bn_maxpool2")
+        assert torch.equal(yb16.cpu(), _split16(yb.cpu()) if dt == SPLIT16 else yb.cpu().to(dt)), dt
 
 
 # attention on the 16-bit matrix cores (svcmi_attention16): every block shape, ragged lengths, key ranges past T, both formats
