@@ -426,3 +426,36 @@ def test_cpp_host_without_python_matches_the_facade(ops, tmp_path):
     print(r.stdout.strip())
     got = np.fromfile(tmp_path / "wave.bin", dtype=np.float32).reshape(B, -1)
     assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_cpp_host_runs_the_whisper_stage(ops, tmp_path):
+    """The same C++ host on a packed Whisper encoder (kind 2): svcmi_whisper_encoder_fwd on mel + 0.1 * noise, two 7 s windows of the
+    large-v2 architecture (4 blocks kept to keep the file small) -- the PPG equals the Python facade's bit for bit."""
+    import os
+    import struct
+    import subprocess
+    import numpy as np
+    from svcmi import packed
+    from svcmi.whisper.inference import load_model
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "whisper-vits-svc_amd", "examples", "stage_host")
+    assert os.path.exists(exe), "examples/stage_host is built by whisper-vits-svc_amd/build.py"
+    dims = dict(C.WHISPER_LARGE_V2)
+    dims["n_audio_layer"] = 4
+    wm = load_model(W.make_whisper_state(dims), "cuda", ops=ops)
+    g = torch.Generator().manual_seed(5)
+    B, n = 2, 700
+    mel = (torch.randn(B, 80, n, generator=g) * 0.5).clamp(-1, 1.5)
+    nz = torch.randn(B, 80, n, generator=g)
+    want = wm.encoder(mel, nz, 0.1).cpu().numpy()
+    (tmp_path / "whisper.svcmi").write_bytes(packed.pack_model(wm.weights))
+    with open(tmp_path / "mel.bin", "wb") as f:
+        f.write(struct.pack("<ii", B, n))
+        f.write(mel.contiguous().numpy().tobytes())
+        f.write(nz.contiguous().numpy().tobytes())
+    r = subprocess.run([exe, str(tmp_path / "whisper.svcmi"), str(tmp_path / "mel.bin"), str(tmp_path / "ppg.bin")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    print(r.stdout.strip())
+    got = np.fromfile(tmp_path / "ppg.bin", dtype=np.float32).reshape(want.shape)
+    assert np.array_equal(got, want)
+

@@ -29,9 +29,12 @@ def build_hip(force=False, verbose=False):
     """One hipcc -c per kernel file, in parallel, then one link: ~25 s instead of ~75 s for the eight translation units."""
     from concurrent.futures import ThreadPoolExecutor
     srcs = sources()
-    if not force and not needs_build(OUT, srcs):
-        return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not force and not needs_build(OUT, srcs):
+        ex_src, ex = os.path.join(HERE, "examples", "stage_host.cpp"), os.path.join(HERE, "examples", "stage_host")
+        if not os.path.exists(ex) or max(os.path.getmtime(ex_src), os.path.getmtime(OUT)) > os.path.getmtime(ex):      # the example has its own source
+            build_example(hipcc, verbose)
+        return OUT
     objdir = os.path.join(HERE, "_obj")
     os.makedirs(objdir, exist_ok=True)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]

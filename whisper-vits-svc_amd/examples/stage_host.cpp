@@ -7,6 +7,10 @@
 // inputs.bin: int32 B, T, then float32 ppg[B][T][ppg_dim], vec[B][T][vec_dim], pit[B][T], spk[B][spk_dim], int32 lengths[B],
 //             float32 rand_ini[B][11], src_noise[B][T*hop][11], enc_noise[B][inter][T]      (the explicit draws of the path)
 // wave_out.bin: float32 [B][T*hop]
+// With a packed Whisper encoder (python -m svcmi.tools pack --whisper ...; kind 2) the same binary runs AudioEncoder.forward
+// (whisper/model.py:147-163 with the `mel + 0.1 * noise` of whisper/inference.py:46):
+//   stage_host <whisper.svcmi> <mel.bin> <ppg_out.bin>
+// mel.bin: int32 B, n_frames, then float32 mel[B][n_mels][n_frames], noise[B][n_mels][n_frames];  ppg_out.bin: float32 [B][tw][n_state]
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -41,6 +45,38 @@ static T* upload(const char*& p, size_t count) {
     return d;
 }
 
+// the Whisper stage: mel (+ noise) -> PPG through svcmi_whisper_encoder_fwd
+static int run_whisper(const std::vector<char>& file, const void* arena, const std::vector<char>& in, const char* out_path) {
+    static svcmi_whisper_model model;       // (a few KB of block descriptors)
+    CHECK_SV(svcmi_packed_model_bind(file.data(), (int64_t)file.size(), arena, &model, sizeof(model)));
+    const char* p = in.data();
+    const int32_t B = reinterpret_cast<const int32_t*>(p)[0], n = reinterpret_cast<const int32_t*>(p)[1];
+    p += 8;
+    const size_t mel_count = (size_t)B * model.n_mels * n;
+    if (B <= 0 || n <= 0 || in.size() != 8 + 2 * mel_count * sizeof(float)) { fprintf(stderr, "mel.bin does not match B = %d, n_frames = %d\n", B, n); return 1; }
+    float* mel = upload<float>(p, mel_count);
+    float* noise = upload<float>(p, mel_count);
+    if (!mel || !noise) return 2;
+    const int tw = (n - 1) / 2 + 1;
+    float* ppg = nullptr;
+    CHECK_HIP(hipMalloc(&ppg, (size_t)B * tw * model.n_state * sizeof(float)));
+    const int64_t ws_bytes = svcmi_whisper_workspace_bytes(&model, B, n);
+    if (ws_bytes < 0) { fprintf(stderr, "svcmi_whisper_workspace_bytes -> %lld\n", (long long)ws_bytes); return 3; }
+    void* ws = nullptr;
+    CHECK_HIP(hipMalloc(&ws, ws_bytes));
+    hipStream_t stream;
+    CHECK_HIP(hipStreamCreate(&stream));
+    CHECK_SV(svcmi_whisper_encoder_fwd(&model, mel, noise, 0.1f, B, n, ppg, ws, ws_bytes, stream));
+    CHECK_HIP(hipStreamSynchronize(stream));
+    std::vector<float> out((size_t)B * tw * model.n_state);
+    CHECK_HIP(hipMemcpy(out.data(), ppg, out.size() * sizeof(float), hipMemcpyDeviceToHost));
+    FILE* f = fopen(out_path, "wb");
+    if (!f || fwrite(out.data(), sizeof(float), out.size(), f) != out.size()) { fprintf(stderr, "cannot write %s\n", out_path); return 1; }
+    fclose(f);
+    printf("stage_host: Whisper encoder, B = %d, %d mel frames -> [%d][%d][%d], workspace %.1f MB\n", B, n, B, tw, model.n_state, ws_bytes / 1e6);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc != 4) { fprintf(stderr, "usage: %s model.svcmi inputs.bin wave_out.bin\n", argv[0]); return 1; }
     if (svcmi_abi_version() != SVCMI_ABI_VERSION) { fprintf(stderr, "ABI mismatch\n"); return 1; }
@@ -49,10 +85,11 @@ int main(int argc, char** argv) {
     int32_t kind = 0;
     int64_t arena_off = 0, arena_bytes = 0;
     CHECK_SV(svcmi_packed_model_info(file.data(), (int64_t)file.size(), &kind, &arena_off, &arena_bytes));
-    if (kind != 1) { fprintf(stderr, "not a synthesizer model\n"); return 1; }
+    if (kind != 1 && kind != 2) { fprintf(stderr, "unknown model kind %d\n", kind); return 1; }
     void* arena = nullptr;
     CHECK_HIP(hipMalloc(&arena, arena_bytes));
     CHECK_HIP(hipMemcpy(arena, file.data() + arena_off, arena_bytes, hipMemcpyHostToDevice));
+    if (kind == 2) return run_whisper(file, arena, in, argv[3]);
     svcmi_synth_model model;
     CHECK_SV(svcmi_packed_model_bind(file.data(), (int64_t)file.size(), arena, &model, sizeof(model)));
 
