@@ -215,17 +215,23 @@ __global__ __launch_bounds__(384) void viterbi_dp_kernel(const float* lp, const 
 // frames of a 10 s clip.  Candidates are visited in ascending predecessor order with strict >, so ties resolve to the
 // lowest index exactly like the dense loop (sums that only become equal through rounding of `+ constant` excepted).
 constexpr int VBAND_MAX = 15;
+constexpr int VBT_THREADS = 512;  // banded kernel: 2 scanning waves + 6 waves of states
 constexpr int VBT = 64;             // frames per backtracking chunk (64 x 360 back-pointers = 45 KB of LDS)
 constexpr double VNEG = -1.0e300;
 
-__global__ __launch_bounds__(384) void viterbi_dp_banded_kernel(const float* lp, const double* log_trans, short* ptr, int* path,
+__global__ __launch_bounds__(VBT_THREADS) void viterbi_dp_banded_kernel(const float* lp, const double* log_trans, short* ptr, int* path,
                                                                 int t_total, int batch_frames, int band) {
     __shared__ double val[2][VS];
     __shared__ double pm_v[VS], sm_v[VS];
     __shared__ short pm_i[VS], sm_i[VS];
     __shared__ short pbuf[VBT][VS];          // back-pointer rows of one backtracking chunk
     __shared__ int cur_s;
-    const int k = threadIdx.x, lane = k & 63, wave = k >> 6;
+    // 8 waves: waves 0 and 1 run the prefix / suffix max-scans of a step, waves 2-7 own the 360 states (thread 128 + k = state k) and
+    // compute their in-band maxima BESIDE the scans; after the barrier a state only compares its in-band result with the two out-of-band
+    // candidates.  (With 6 waves the two scanning waves also owned states: scan + in-band + combine were one serial chain per step --
+    // 1.43 -> 1.00 ms for the 501 frames of a 10 s clip, profiles/r03c_crepe_kernel_stats.log.)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k = tid >= 128 ? tid - 128 : VS;             // the state this thread owns (VS = none)
     const int f0 = blockIdx.x * batch_frames;
     const int T = (t_total - f0) < batch_frames ? (t_total - f0) : batch_frames;
     const float* lpb = lp + (long long)f0 * VS;
@@ -239,13 +245,14 @@ __global__ __launch_bounds__(384) void viterbi_dp_banded_kernel(const float* lp,
     }
     if (k < VS) val[0][k] = (double)lpb[k] + log(1.0 / VS + 2.2250738585072014e-308);
     // (the log-likelihood of step t is requested one step ahead instead of as a dependent global load inside the step; with the LDS-staged
-    //  backtracking below: 1.59 -> 1.50 ms for 501 frames -- a step is ~3 us and most of it is the two 64-lane fp64 max-scans)
+    //  backtracking below: 1.59 -> 1.50 ms for 501 frames -- most of a step is the two 64-lane fp64 max-scans)
     float lp_next = (k < VS && T > 1) ? lpb[VS + k] : 0.f;
     __syncthreads();
     for (int t = 1; t < T; ++t) {
         const double* prev = val[(t - 1) & 1];
         const float lp_t = lp_next;
         if (k < VS && t + 1 < T) lp_next = lpb[(long long)(t + 1) * VS + k];
+        double bv_in = VNEG; int bj_in = 0;     // best in-band predecessor of state k (lowest index on ties)
         if (wave == 0) {                 // prefix maxima: pm[j] = max prev[0..j], lowest index on ties
             const int j0 = 6 * lane;
             double v = VNEG; int vi = 0;
@@ -287,18 +294,21 @@ __global__ __launch_bounds__(384) void viterbi_dp_banded_kernel(const float* lp,
                     sm_v[j0 + e] = xv; sm_i[j0 + e] = (short)xi;
                 }
         }
-        __syncthreads();
-        if (k < VS) {
-            double bv = VNEG; int bj = 0;
-            if (k - band - 1 >= 0) { bv = pm_v[k - band - 1] + c_out; bj = pm_i[k - band - 1]; }
+        else if (k < VS) {
 #pragma unroll
             for (int e = 0; e < 2 * VBAND_MAX + 1; ++e) {
                 const int j = k - band + e;
                 if (e <= 2 * band && j >= 0 && j < VS) {
                     const double c = prev[j] + ltb[e];
-                    if (c > bv) { bv = c; bj = j; }
+                    if (c > bv_in) { bv_in = c; bj_in = j; }
                 }
             }
+        }
+        __syncthreads();
+        if (k < VS) {       // candidates in increasing predecessor order, strict '>' : the lowest predecessor index wins ties
+            double bv = VNEG; int bj = 0;
+            if (k - band - 1 >= 0) { bv = pm_v[k - band - 1] + c_out; bj = pm_i[k - band - 1]; }
+            if (bv_in > bv) { bv = bv_in; bj = bj_in; }
             if (k + band + 1 < VS) {
                 const double c = sm_v[k + band + 1] + c_out;
                 if (c > bv) { bv = c; bj = sm_i[k + band + 1]; }
@@ -308,7 +318,7 @@ __global__ __launch_bounds__(384) void viterbi_dp_banded_kernel(const float* lp,
         }
         __syncthreads();
     }
-    if (k == 0) {
+    if (tid == 0) {
         const double* last = val[(T - 1) & 1];
         int bj = 0;
         for (int j = 1; j < VS; ++j)
@@ -324,9 +334,9 @@ __global__ __launch_bounds__(384) void viterbi_dp_banded_kernel(const float* lp,
         const int n = (t_hi - t_lo + 1) * VS;
         const short* src = pb + (long long)t_lo * VS;
         short* dst = &pbuf[0][0];
-        for (int i = k; i < n; i += 384) dst[i] = src[i];
+        for (int i = tid; i < n; i += VBT_THREADS) dst[i] = src[i];
         __syncthreads();
-        if (k == 0) {
+        if (tid == 0) {
             int cur = cur_s;
             for (int t = t_hi; t >= t_lo; --t) {
                 cur = pbuf[t - t_lo][cur];
@@ -350,7 +360,7 @@ extern "C" int svcmi_viterbi_decode(const float* prob, const double* log_trans, 
     if (rc) return rc;
     const dim3 grid((unsigned)((frames + batch_frames - 1) / batch_frames));
     if (band > 0 && 2 * band + 1 < VS)
-        SVCMI_LAUNCH(viterbi_dp_banded_kernel, grid, dim3(384), 0, stream, (const float*)lp_scratch, log_trans, (short*)ptr_scratch, path,
+        SVCMI_LAUNCH(viterbi_dp_banded_kernel, grid, dim3(VBT_THREADS), 0, stream, (const float*)lp_scratch, log_trans, (short*)ptr_scratch, path,
                      frames, batch_frames, band);
     else
         SVCMI_LAUNCH(viterbi_dp_kernel, grid, dim3(384), 0, stream, (const float*)lp_scratch, log_trans, (short*)ptr_scratch, path, frames,
