@@ -229,7 +229,8 @@ __global__ __launch_bounds__(VBT_THREADS) void viterbi_dp_banded_kernel(const fl
     // 8 waves: waves 0 and 1 run the prefix / suffix max-scans of a step, waves 2-7 own the 360 states (thread 128 + k = state k) and
     // compute their in-band maxima BESIDE the scans; after the barrier a state only compares its in-band result with the two out-of-band
     // candidates.  (With 6 waves the two scanning waves also owned states: scan + in-band + combine were one serial chain per step --
-    // 1.43 -> 1.00 ms for the 501 frames of a 10 s clip, profiles/r03c_crepe_kernel_stats.log.)
+    // 1.43 -> 1.00 ms for the 501 frames of a 10 s clip; the lane scans on DPP row moves instead of ds_bpermute shuffles: 0.93 ms,
+    // profiles/r03c_crepe_kernel_stats.log.)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k = tid >= 128 ? tid - 128 : VS;             // the state this thread owns (VS = none)
     const int f0 = blockIdx.x * batch_frames;
@@ -259,13 +260,18 @@ __global__ __launch_bounds__(VBT_THREADS) void viterbi_dp_banded_kernel(const fl
 #pragma unroll
             for (int e = 0; e < 6; ++e)
                 if (j0 + e < VS && prev[j0 + e] > v) { v = prev[j0 + e]; vi = j0 + e; }
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const double ov = __shfl_up(v, d);
-                const int oi = __shfl_up(vi, d);
-                if (lane >= d && !(v > ov)) { v = ov; vi = oi; }       // the earlier range wins ties
+            // inclusive scan over the lanes on DPP row moves (svcmi_rt.h); the moved value is the EARLIER range, which wins ties
+#define VSCAN_STEP(MOVE)                                                                   \
+            {                                                                              \
+                const double ov = svcmi_dpp_f64(v, [](int q) { return MOVE(q); });         \
+                const int oi = MOVE(vi);                                                   \
+                if (!(v > ov)) { v = ov; vi = oi; }                                        \
             }
-            double xv = __shfl_up(v, 1); int xi = __shfl_up(vi, 1);     // exclusive prefix of this lane
+            VSCAN_STEP(svcmi_dpp_row_shr<1>) VSCAN_STEP(svcmi_dpp_row_shr<2>) VSCAN_STEP(svcmi_dpp_row_shr<4>) VSCAN_STEP(svcmi_dpp_row_shr<8>)
+            VSCAN_STEP(svcmi_dpp_row_bcast15) VSCAN_STEP(svcmi_dpp_row_bcast31)
+#undef VSCAN_STEP
+            double xv = svcmi_dpp_f64(v, [](int q) { return svcmi_dpp_wave_shr1(q); });     // exclusive prefix of this lane
+            int xi = svcmi_dpp_wave_shr1(vi);
             if (lane == 0) { xv = VNEG; xi = 0; }
 #pragma unroll
             for (int e = 0; e < 6; ++e)
@@ -274,22 +280,29 @@ __global__ __launch_bounds__(VBT_THREADS) void viterbi_dp_banded_kernel(const fl
                     pm_v[j0 + e] = xv; pm_i[j0 + e] = (short)xi;
                 }
         } else if (wave == 1) {          // suffix maxima: sm[j] = max prev[j..VS-1], lowest index on ties
-            const int j0 = 6 * lane;
+            // lane l owns the 6 states of block 59 - l, so that a scan towards HIGHER lanes walks towards LOWER states: the suffix scan
+            // becomes the same forward lane scan as above (lanes 60-63 own nothing and come last)
+            const int j0 = 6 * (59 - lane);
             double v = VNEG; int vi = VS - 1;
 #pragma unroll
             for (int e = 5; e >= 0; --e)
-                if (j0 + e < VS && prev[j0 + e] >= v) { v = prev[j0 + e]; vi = j0 + e; }
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const double ov = __shfl_down(v, d);
-                const int oi = __shfl_down(vi, d);
-                if (lane + d < 64 && ov > v) { v = ov; vi = oi; }      // the earlier range (this lane) wins ties
+                if (j0 >= 0 && prev[j0 + e] >= v) { v = prev[j0 + e]; vi = j0 + e; }
+            // the moved value is the range of HIGHER states: this lane's (lower) states win ties
+#define VSCAN_STEP(MOVE)                                                                   \
+            {                                                                              \
+                const double ov = svcmi_dpp_f64(v, [](int q) { return MOVE(q); });         \
+                const int oi = MOVE(vi);                                                   \
+                if (ov > v) { v = ov; vi = oi; }                                           \
             }
-            double xv = __shfl_down(v, 1); int xi = __shfl_down(vi, 1);
-            if (lane == 63) { xv = VNEG; xi = VS - 1; }
+            VSCAN_STEP(svcmi_dpp_row_shr<1>) VSCAN_STEP(svcmi_dpp_row_shr<2>) VSCAN_STEP(svcmi_dpp_row_shr<4>) VSCAN_STEP(svcmi_dpp_row_shr<8>)
+            VSCAN_STEP(svcmi_dpp_row_bcast15) VSCAN_STEP(svcmi_dpp_row_bcast31)
+#undef VSCAN_STEP
+            double xv = svcmi_dpp_f64(v, [](int q) { return svcmi_dpp_wave_shr1(q); });     // maximum over the states above this lane's block
+            int xi = svcmi_dpp_wave_shr1(vi);
+            if (lane == 0) { xv = VNEG; xi = VS - 1; }
 #pragma unroll
             for (int e = 5; e >= 0; --e)
-                if (j0 + e < VS) {
+                if (j0 >= 0) {
                     if (prev[j0 + e] >= xv) { xv = prev[j0 + e]; xi = j0 + e; }
                     sm_v[j0 + e] = xv; sm_i[j0 + e] = (short)xi;
                 }

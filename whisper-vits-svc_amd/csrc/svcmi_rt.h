@@ -192,3 +192,33 @@ void svcmi_store4_16(unsigned short* dst, int lo_off, float a, float b, float c,
 // BF16X3 = 1 -> 2 = split rows); -1 = not an activation format.  Row check: `ld` 16-bit values hold n outputs (split: two planes of ld/2).
 static inline int svcmi_fmt16(int format) { return format == 2 ? 0 : format == 3 ? 1 : format == 1 ? 2 : -1; }
 static inline bool svcmi_fmt16_row_ok(int format, int ld, int n) { return format == 1 ? (ld % 8 == 0 && ld / 2 >= n) : (ld % 4 == 0 && ld >= n); }
+
+// Lane movement for wave scans on the DPP row operations of gfx9 (no LDS crossbar: ~8 cycles where a ds_bpermute shuffle takes ~100).
+// Every function returns the moved value where a source lane exists and the lane's OWN value elsewhere, so `x = op(x, moved(x))` is a
+// no-op there.  row_shr<N>: lane l - N inside the lane's row of 16;  row_bcast15: rows 1 and 3 receive lane 15 of the row before;
+// row_bcast31: rows 2 and 3 receive lane 31;  wave_shr1: lane l - 1 (lane 0 keeps its own).  The classic inclusive scan is
+// row_shr 1, 2, 4, 8, then row_bcast15, then row_bcast31.
+#ifdef SVCMI_EMU
+template <int N> static inline int svcmi_dpp_row_shr(int x) { const int l = threadIdx.x & 63; return __shfl(x, (l & 15) >= N ? l - N : l); }
+static inline int svcmi_dpp_row_bcast15(int x) { const int l = threadIdx.x & 63, r = l >> 4; return __shfl(x, (r == 1 || r == 3) ? 16 * r - 1 : l); }
+static inline int svcmi_dpp_row_bcast31(int x) { const int l = threadIdx.x & 63; return __shfl(x, l >= 32 ? 31 : l); }
+static inline int svcmi_dpp_wave_shr1(int x) { const int l = threadIdx.x & 63; return __shfl(x, l > 0 ? l - 1 : l); }
+#define SVCMI_DEV static inline
+#else
+template <int N> __device__ __forceinline__ int svcmi_dpp_row_shr(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x110 + N, 0xf, 0xf, false); }
+__device__ __forceinline__ int svcmi_dpp_row_bcast15(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x142, 0xa, 0xf, false); }
+__device__ __forceinline__ int svcmi_dpp_row_bcast31(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x143, 0xc, 0xf, false); }
+__device__ __forceinline__ int svcmi_dpp_wave_shr1(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x138, 0xf, 0xf, false); }
+#define SVCMI_DEV __device__ __forceinline__
+#endif
+// the same moves on a double (two 32-bit halves)
+template <class F>
+SVCMI_DEV double svcmi_dpp_f64(double v, F move) {
+    unsigned long long u;
+    memcpy(&u, &v, 8);
+    const unsigned lo = (unsigned)move((int)(unsigned)u), hi = (unsigned)move((int)(unsigned)(u >> 32));
+    u = ((unsigned long long)hi << 32) | lo;
+    memcpy(&v, &u, 8);
+    return v;
+}
+
