@@ -388,6 +388,34 @@ def cpu_baseline(wl, wsd, vsd, hp):
     return info, err
 
 
+def respawn_under_launcher(n):
+    """Run THIS command line as n ranks: python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <same args>.
+    Returns the launcher's exit code (non-zero if fewer than n GPUs are visible: nothing is measured, nothing is printed)."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n and os.environ.get("SVCMI_DIST_BACKEND") != "gloo":
+        log(f"bench.py --gpus {n}: {have} GPU(s) visible and no WORLD_SIZE in the environment -- not measuring a smaller job under this flag")
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("bench.py: no WORLD_SIZE in the environment, re-launching as " + " ".join(cmd))
+    return subprocess.call(cmd)
+
+
+def ranks_seen(world, device):
+    """Every rank contributes a one: what an all-reduce over the job's backend (nccl = RCCL) returns is the number of ranks it carried."""
+    import torch.distributed as dist
+    if world == 1:
+        return 1
+    t = torch.ones(1, dtype=torch.float32, device=device if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t)
+    return int(t.item())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -423,9 +451,18 @@ def main():
     from svcmi.whisper.inference import WhisperEncoderModel
     import torch.distributed as dist
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: never print an N = 1 line under an N > 1 flag.  Re-exec the same command as N
+        # ranks (one per GPU) under torch.distributed.run -- the launch line the driver itself uses -- and hand its exit code back.
+        sys.exit(respawn_under_launcher(args.gpus))
     rank, local_rank, world = D.init_from_env()
-    assert world == args.gpus or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    if world != args.gpus:
+        log(f"bench.py: WORLD_SIZE {world} != --gpus {args.gpus}: refusing to print a line for a job of another size")
+        sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs a GPU (svcmi has no CPU path)"
+    if world > 1 and dist.get_backend() == "nccl" and torch.cuda.device_count() < min(world, int(os.environ.get("LOCAL_WORLD_SIZE", world))):
+        log(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPUs visible (RCCL wants one device per rank)")
+        sys.exit(2)
     device = torch.device("cuda", local_rank % torch.cuda.device_count())     # (> 1 rank per device only under SVCMI_DIST_BACKEND=gloo)
     torch.cuda.set_device(device)
     ops = Ops()
@@ -534,6 +571,7 @@ def main():
                               f"{os.environ.get('GPU_MAX_HW_QUEUES')})" if inflight > 1 else ""),
                    "clips_in_flight": inflight,
                    "world_size": world, "dist_backend": (dist.get_backend() if world > 1 else None),
+                   "rccl_ranks_seen": ranks_seen(world, device),
                    "weights": ("rank 0 packs, one broadcast of the packed arena per model (" + str(dist.get_backend()) + ")") if world > 1 else "packed on this rank",
                    "per_gpu_value": round(value / world, 2), "realtime_factor": round(value / world, 2)},
     }

@@ -86,6 +86,10 @@ CONV_CASES_LP_SMALL = [
     dict(id="a16_x3_vec_c24_masks_ktail", B=2, T=37, cin=24, n=20, k=5, pad=2, lengths=[37, 20], mask_in=True, mask_out=True, prec="bf16x3", a16=True),
     dict(id="a16_x3_128x128_k1", B=1, T=150, cin=256, n=140, k=1, prec="bf16x3", a16=True, tile=3),
     dict(id="a16_x3_stride2_k3_splitk", B=1, T=81, cin=96, n=40, k=3, stride=2, pad=1, prec="bf16x3", a16=True, split_k=3),
+    # split_k = 0 (library heuristic) on long-K, few-tile shapes WITH the 16-bit output copy: the copy only comes out of the non-split
+    # epilogue, so the launchers must not split (y16 was left uninitialised)
+    dict(id="lp_f16_splitk_auto_out16", B=1, T=33, cin=16, n=8, k=63, pad=31, split_k=0, prec="f16", out16=True),
+    dict(id="a16_bf16_splitk_auto_out16", B=1, T=40, cin=64, n=16, k=21, pad=10, split_k=0, prec="bf16", a16=True, out16=True),
 ]
 CONV_CASES_LP_LARGE = [
     dict(id="lp_whisper_qkv_bf16x3", B=1, T=750, cin=1280, n=3840, k=1, prec="bf16x3"),

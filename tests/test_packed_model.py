@@ -35,6 +35,51 @@ def test_header_and_relocations_are_checked(ops):
     assert ops.lib.svcmi_packed_model_bind(buf, len(data), base, ctypes.byref(st), ctypes.sizeof(st)) == -1
 
 
+def test_mangled_header_and_relocation_table_are_rejected(ops):
+    """File-controlled 64-bit fields must not wrap the bounds checks: n_reloc = 2^61 makes 8 * n_reloc == 0, relocation
+    offsets near 2^64 wrap `offset + 8`, an arena past the end of the file must be refused -- all before anything is read or written."""
+    import struct
+    w = PW.WhisperWeights(W.make_whisper_state(C.WHISPER_TINY_TEST), "cpu")
+    data = bytearray(packed.pack_model(w))
+    kind, abi, struct_bytes, n_reloc, arena_off, arena_bytes = struct.unpack_from("<IIQQQQ", data, 8)
+    assert n_reloc > 0
+
+    def info(img):
+        buf = (ctypes.c_char * len(img)).from_buffer_copy(bytes(img))
+        return ops.lib.svcmi_packed_model_info(buf, len(img), None, None, None), buf
+
+    def header(**kw):
+        f = dict(struct_bytes=struct_bytes, n_reloc=n_reloc, arena_off=arena_off, arena_bytes=arena_bytes)
+        f.update(kw)
+        img = bytearray(data)
+        struct.pack_into("<IIQQQQ", img, 8, kind, abi, f["struct_bytes"], f["n_reloc"], f["arena_off"], f["arena_bytes"])
+        return img
+
+    assert info(data)[0] == 0
+    for bad in (header(n_reloc=1 << 61), header(n_reloc=(1 << 61) + n_reloc), header(arena_off=(1 << 64) - 256),
+                header(arena_bytes=(1 << 64) - arena_off + 16), header(arena_bytes=arena_bytes + 1), header(arena_off=40),
+                header(n_reloc=(arena_off - 48 - struct_bytes) // 8 + 1)):
+        assert info(bad)[0] == -1
+    # relocation entries: past the struct, wrapping, misaligned
+    st = _lib.WhisperModel()
+    arena = torch.empty(arena_bytes + 256, dtype=torch.uint8)
+    base = (arena.data_ptr() + 255) & ~255
+    guard = bytes(ctypes.string_at(ctypes.addressof(st), ctypes.sizeof(st)))
+    for v in ((1 << 64) - 4, (1 << 64) - 8, struct_bytes - 4, struct_bytes, 4):
+        img = bytearray(data)
+        struct.pack_into("<Q", img, 48, v)
+        rc, buf = info(img)
+        assert rc == 0                                        # the header itself is fine
+        assert ops.lib.svcmi_packed_model_bind(buf, len(img), base, ctypes.byref(st), ctypes.sizeof(st)) == -1
+    # an arena offset stored in a pointer field that lies outside the arena
+    img = bytearray(data)
+    (first,) = struct.unpack_from("<Q", img, 48)
+    struct.pack_into("<Q", img, 48 + 8 * n_reloc + first, arena_bytes + 1)
+    rc, buf = info(img)
+    assert rc == 0 and ops.lib.svcmi_packed_model_bind(buf, len(img), base, ctypes.byref(st), ctypes.sizeof(st)) == -1
+    del guard
+
+
 def test_packed_whisper_runs_like_the_facade(ops):
     from svcmi.whisper.inference import load_model
     ck = W.make_whisper_state(C.WHISPER_TINY_TEST)

@@ -58,7 +58,17 @@ def build_hip(force=False, verbose=False):
 
 
 def build_example(hipcc, verbose=False):
-    """examples/stage_host: the C++ host without Python (packed model -> svcmi_synth_infer_fwd), linked against the in-tree library."""
+    """examples/stage_host: the C++ host without Python (packed model -> svcmi_synth_infer_fwd), linked against the in-tree library.
+    Best effort: the library build every import and test depends on must not fail because the example does not compile or link
+    (the two GPU tests that run the example assert that the binary exists and say who builds it)."""
+    try:
+        return _build_example(hipcc, verbose)
+    except (subprocess.CalledProcessError, OSError) as e:
+        print(f"svcmi build: examples/stage_host not built ({e})", file=sys.stderr)
+        return None
+
+
+def _build_example(hipcc, verbose=False):
     src = os.path.join(HERE, "examples", "stage_host.cpp")
     exe = os.path.join(HERE, "examples", "stage_host")
     cmd = [hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", src, "-o", exe, "-L", os.path.dirname(OUT), "-lsvcmi",

@@ -39,7 +39,7 @@ extern "C" int svcmi_conv_gemm_f32(const svcmi_conv_desc* d, void* stream) {
         if (!d->workspace || d->split_k < 1 || d->split_k > nk) return SVCMI_EINVAL;
         if ((long long)d->batch * d->split_k * d->t_out * d->n_out > d->workspace_floats) return SVCMI_EINVAL;
         a.split = d->split_k;
-    } else if (tile == SVCMI_CONV_TILE_64x64 && d->workspace && d->split_k != 1) {
+    } else if (tile == SVCMI_CONV_TILE_64x64 && d->workspace && d->split_k != 1 && !d->y16) {      // (the 16-bit output copy comes out of the non-split epilogue only)
         int s = d->split_k;
         if (s == 0) {   // heuristic fitted to sweeps on MI355X (scripts/microbench.py gemm / small): aim at ~5 blocks per CU, keep
                         // >= 10 K-steps per slice (shorter slices are all prologue), and leave grids of >= 1.5 blocks per CU alone --

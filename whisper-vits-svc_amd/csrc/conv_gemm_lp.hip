@@ -106,7 +106,7 @@ extern "C" int svcmi_conv_gemm_lp(const svcmi_conv_desc* d, int32_t precision, v
         if (!d->workspace || d->split_k < 1 || d->split_k > nk) return SVCMI_EINVAL;
         if ((long long)d->batch * d->split_k * d->t_out * d->n_out > d->workspace_floats) return SVCMI_EINVAL;
         a.split = d->split_k;
-    } else if (t.wm == 1 && !t.p16 && d->workspace && d->split_k != 1) {
+    } else if (t.wm == 1 && !t.p16 && d->workspace && d->split_k != 1 && !d->y16) {      // (the 16-bit output copy comes out of the non-split epilogue only)
         int s = d->split_k;
         if (s == 0) {       // a K-step is ~5x shorter than the fp32 kernel's: keep >= 16 of them per slice, aim at ~2 blocks per CU
             s = blocks >= 256 ? 1 : (int)(512 / blocks);

@@ -956,7 +956,11 @@ const PackedHeader* packed_header(const void* file, int64_t file_bytes) {
     if (memcmp(h->magic, "SVCMIPK1", 8) != 0 || h->abi != SVCMI_ABI_VERSION) return nullptr;
     const uint64_t want = h->kind == 1 ? sizeof(svcmi_synth_model) : (h->kind == 2 ? sizeof(svcmi_whisper_model) : 0);
     if (!want || h->struct_bytes != want) return nullptr;
-    if (sizeof(PackedHeader) + 8 * h->n_reloc + h->struct_bytes > h->arena_offset || h->arena_offset + h->arena_bytes > (uint64_t)file_bytes) return nullptr;
+    // every field below is file-controlled: compare by subtraction from a bound already established, never by a sum that can wrap
+    const uint64_t fb = (uint64_t)file_bytes, fixed = sizeof(PackedHeader) + h->struct_bytes;
+    if (h->arena_offset > fb || h->arena_offset < fixed) return nullptr;
+    if (h->n_reloc > (h->arena_offset - fixed) / 8) return nullptr;
+    if (h->arena_bytes > fb - h->arena_offset) return nullptr;
     return h;
 }
 }  // namespace
@@ -979,7 +983,7 @@ extern "C" int svcmi_packed_model_bind(const void* file, int64_t file_bytes, con
     char* out = static_cast<char*>(model_out);
     memcpy(out, image, h->struct_bytes);
     for (uint64_t i = 0; i < h->n_reloc; ++i) {
-        if (reloc[i] + sizeof(void*) > h->struct_bytes) return SVCMI_EINVAL;
+        if (reloc[i] > h->struct_bytes - sizeof(void*) || reloc[i] % sizeof(void*)) return SVCMI_EINVAL;
         uint64_t v;
         memcpy(&v, out + reloc[i], 8);
         const void* ptr = nullptr;

@@ -97,6 +97,16 @@ int main(int argc, char** argv) {
     const int32_t B = reinterpret_cast<const int32_t*>(p)[0], T = reinterpret_cast<const int32_t*>(p)[1];
     p += 8;
     const int64_t L = (int64_t)T * model.hop;
+    {       // the whole expected size from B and T BEFORE any upload: a short inputs.bin must not be read past its end
+        if (B <= 0 || T <= 0 || B > (1 << 20) || T > (1 << 24)) { fprintf(stderr, "inputs.bin: bad B = %d, T = %d\n", B, T); return 1; }
+        const unsigned long long bt = (unsigned long long)B * T;
+        const unsigned long long want = 8ull + 4ull * (bt * model.ppg_dim + bt * model.vec_dim + bt + (unsigned long long)B * model.spk_dim +
+                                                       (unsigned long long)B + 11ull * B + 11ull * bt * model.hop + bt * model.inter);
+        if (want != (unsigned long long)in.size()) {
+            fprintf(stderr, "inputs.bin does not match B = %d, T = %d (%llu bytes expected, %zu found)\n", B, T, want, in.size());
+            return 1;
+        }
+    }
     float* ppg = upload<float>(p, (size_t)B * T * model.ppg_dim);
     float* vec = upload<float>(p, (size_t)B * T * model.vec_dim);
     float* pit = upload<float>(p, (size_t)B * T);

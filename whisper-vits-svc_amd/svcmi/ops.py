@@ -61,6 +61,7 @@ class Ops:
         self.workspaces = {}     # split-K scratch, one per (device, stream): launches on parallel streams must not share it
         self.workspace_floats = 16 * 1024 * 1024
         self._retired = []
+        self._graph_pinned = set()        # workspace keys a HIP graph capture has recorded pointers into: their outgrown buffers are kept
         # split-K slices combined inside the GEMM launch by the last-arriving block of each tile.  Correct (bit-identical to
         # the two-kernel reduction, tests/test_gpu_kernels.py) but SLOWER on MI355X at these slab sizes (64-128 KB per tile):
         # 10 s step 15.8 ms (write-through slabs) / 16.1 ms (release fence per block) vs 12.6 ms -> off by default.
@@ -166,12 +167,25 @@ class Ops:
         stream run one after the other, so they can share it; lanes / chunk streams each get their own."""
         key = (device, self._stream(), "stage")
         ws = self.workspaces.get(key)
+        capturing = self.on_gpu and torch.cuda.is_current_stream_capturing()
         if ws is None or ws.numel() < nbytes + 256:
+            grow = int(nbytes) + 512
             if ws is not None:
-                self._retired.append(ws)       # a captured HIP graph may still point into it
-            ws = self.workspaces[key] = torch.empty(int(nbytes) + 512, dtype=torch.uint8, device=device)
+                # geometric growth: a run whose clip lengths keep setting new maxima re-allocates O(log) times, not per clip.  The
+                # outgrown buffer is kept only if a HIP graph captured on this stream recorded pointers into it; otherwise it goes
+                # back to torch's allocator, which is stream-ordered: kernels already queued on this stream finish before any reuse.
+                grow = max(grow, ws.numel() + ws.numel() // 2)
+                if key in self._graph_pinned or capturing:
+                    self._retired.append(ws)
+            ws = self.workspaces[key] = torch.empty(grow, dtype=torch.uint8, device=device)
+        if capturing:
+            self._graph_pinned.add(key)
         base = (ws.data_ptr() + 255) & ~255            # the entry points want 256-byte alignment (CPU tensors of the emulator tests: 64)
         return base, ws.numel() - (base - ws.data_ptr())
+
+    def release_retired(self):
+        """Drop the outgrown stage workspaces kept for captured graphs (call after the graphs that may point into them are gone)."""
+        self._retired.clear()
 
     def _stage_call(self, name, *args):
         rc = getattr(self.lib, name)(*args)

@@ -215,7 +215,7 @@ def main(args):
     from .vits.models import SynthesizerInfer
     from .whisper import inference as whisper_inf
     device = "cuda"
-    f0_prec = None if getattr(args, "f0_precision", "bf16x3") == "f32" else getattr(args, "f0_precision", "bf16x3")
+    f0_prec = None if getattr(args, "f0_precision", "f32") == "f32" else getattr(args, "f0_precision", "f32")
     prec = None if getattr(args, "precision", "f32") == "f32" else args.precision
 
     def _with_prec(m):
@@ -289,7 +289,7 @@ def build_parser():
                    help="GEMM operand precision of the Whisper / HuBERT encoders and the synthesizer (fp32 accumulation, LayerNorm / softmax / "
                         "SnakeAlias in fp32 in every mode): f32 = the reference CPU path's arithmetic (parity default); bf16x3 = split-bf16, "
                         "waveform within 2e-5 of fp32; f16 = what the reference's .half() accelerator path does (waveform within 1e-3); bf16 (7e-3)")
-    p.add_argument("--f0-precision", default="bf16x3", choices=["f32", "bf16x3", "f16", "bf16"],
+    p.add_argument("--f0-precision", default="f32", choices=["f32", "bf16x3", "f16", "bf16"],
                    help="GEMM operand precision of the CREPE F0 extractor: bf16x3 = split-bf16 operands, fp32 accumulate (posteriors within 1e-5 "
                         "of fp32, decoded track identical on the golden clip: tests/test_gpu_engine.py), 2x faster; f32 = exact-fp32 matrix cores; "
                         "f16 = fp16 operands and activations (posteriors within 5e-4, decoded track identical on the test clip: "

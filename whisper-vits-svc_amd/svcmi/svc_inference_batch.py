@@ -50,7 +50,7 @@ class Converter:
         self.whisper = whisper_inf.load_model({"dims": dims[0], "model_state_dict": bc(wck["model_state_dict"] if rank == 0 else None)}, device)
         self.hubert = hubert_inf.load_model(bc(_load_on_rank0(args.hubert, rank)), device)
         self.crepe = pitch_inf.load_crepe(bc(_load_on_rank0(args.crepe, rank)), device)
-        self.crepe.precision = None if getattr(args, "f0_precision", "bf16x3") == "f32" else getattr(args, "f0_precision", "bf16x3")
+        self.crepe.precision = None if getattr(args, "f0_precision", "f32") == "f32" else getattr(args, "f0_precision", "f32")
         ck = _load_on_rank0(args.model, rank)
         self.model = SynthesizerInfer(self.hp.data.filter_length // 2 + 1, self.hp.data.segment_size // self.hp.data.hop_length, self.hp)
         want = self.model.state_dict()
@@ -160,7 +160,7 @@ def build_parser():
     p.add_argument("--crepe", type=str, default=os.path.join("crepe", "assets", "full.pth"))
     p.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16", "f16"],
                    help="GEMM operand precision of Whisper / HuBERT / synthesizer (see svc_inference); f32 = parity default")
-    p.add_argument("--f0-precision", default="bf16x3", choices=["f32", "bf16x3", "f16", "bf16"], help="GEMM operand precision of the CREPE F0 extractor (see svc_inference)")
+    p.add_argument("--f0-precision", default="f32", choices=["f32", "bf16x3", "f16", "bf16"], help="GEMM operand precision of the CREPE F0 extractor (see svc_inference)")
     p.add_argument("--workers", type=int, default=3,
                    help="files in flight per GPU: worker threads, each converting its files on its own HIP stream (1 = the reference's order)")
     return p
