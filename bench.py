@@ -240,7 +240,8 @@ WORKLOADS = {1: Workload, 2: FlowDecoderBatch, 3: ShardedUtterances, 4: LongForm
 # per-config defaults: (batch, seconds, whisper precision, synthesizer precision)
 # (configs[4] is "fp16 MFMA" in BASELINE.json: both networks in f16 since round 3 -- 9.4e-4 on the waveform, inside the 1e-3 bar
 #  (profiles/r03k_precision_report.json); `--precision` / the r02 lines used f16 Whisper + fp32 synthesizer)
-DEFAULTS = {1: (1, 10.0, "f32", "f32"), 2: (16, 10.0, None, "bf16"), 3: (16, 10.0, "f32", "f32"), 4: (1, 30.0, "f16", "f16")}
+#  round 4: configs[2] / [4] run the per-layer MIXED policy in the synthesizer (split-bf16 where the waveform error is made, fp16 elsewhere)
+DEFAULTS = {1: (1, 10.0, "f32", "f32"), 2: (16, 10.0, None, "mixed"), 3: (16, 10.0, "f32", "f32"), 4: (1, 30.0, "f16", "mixed")}
 
 
 def build_graph(fn, warm=2, stream=None):
@@ -296,6 +297,28 @@ def measured_precision_error(config, wprec, sprec):
                 "measured_on": key.split("_")[0], "source": os.path.relpath(files[-1], ROOT)}
     except Exception:       # noqa: BLE001
         return None
+
+
+def live_precision_error(step, whisper, model, wprec, sprec, seed=20240922):
+    """Max-abs waveform difference between the step in the line's precision and the same step in fp32, identical inputs and draws."""
+    def run(wp, sp):
+        saved = (whisper.encoder.precision if whisper is not None else None, model.precision)
+        if whisper is not None:
+            whisper.encoder.precision = wp
+        model.precision = sp
+        try:
+            torch.manual_seed(seed)
+            torch.cuda.manual_seed_all(seed)
+            out = step()
+            torch.cuda.synchronize()
+            return out.clone()
+        finally:
+            if whisper is not None:
+                whisper.encoder.precision = saved[0]
+            model.precision = saved[1]
+    ref, got = run(None, None), run(wprec, sprec)
+    err = float((got - ref).abs().max())
+    return {"live_max_abs_vs_fp32_engine": err, "live_within_1e-3": bool(err <= 1e-3), "live_wave_rms": float(ref.pow(2).mean().sqrt())}
 
 
 def measured_traffic(kernel="conv_gemm_kernel"):
@@ -433,9 +456,10 @@ def main():
                          "for config 1 (config.single_stream then reports the one-clip-at-a-time figure too), 1 otherwise")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-single-stream", action="store_true", help="skip the one-clip-at-a-time timing that accompanies --inflight > 1")
-    ap.add_argument("--precision", default=None, choices=["f32", "bf16x3", "bf16", "f16"],
-                    help="GEMM operand precision of BOTH networks (fp32 accumulate in every mode).  Default per config: 1 and 3 f32 "
-                         "(the parity default, the judged line), 2 bf16 (flow + decoder), 4 f16 Whisper + f32 synthesizer")
+    ap.add_argument("--precision", default=None,
+                    help="GEMM operand precision of BOTH networks (fp32 accumulate in every mode): f32 | bf16x3 | bf16 | f16 | mixed | "
+                         "mixed:<class>=<mode>,... (per-layer policy of the synthesizer, svcmi._lib.MIXED_DEFAULT; Whisper then runs f16).  "
+                         "Default per config: 1 and 3 f32 (the parity default, the judged line), 2 mixed (flow + decoder), 4 f16 Whisper + mixed synthesizer")
     args = ap.parse_args()
     d_batch, d_secs, d_wprec, d_sprec = DEFAULTS[args.config]
     args.batch = args.batch or d_batch
@@ -444,6 +468,8 @@ def main():
     args.inflight = args.inflight if args.inflight is not None else {1: 4, 2: 3, 3: 2, 4: 4}[args.config]
     args.warmup = args.warmup if args.warmup is not None else (1 if args.config == 3 else 3)
     wprec, sprec = (args.precision, args.precision) if args.precision else (d_wprec, d_sprec)
+    if wprec and wprec.startswith("mixed"):
+        wprec = "f16"                    # the policy classes are the synthesizer's; Whisper follows the reference's .half()
     norm = lambda p: None if p in (None, "f32") else p
 
     from workload import config as C, weights as W      # synthetic checkpoint factory + base.yaml values
@@ -556,7 +582,14 @@ def main():
     ms_per_step = 1000.0 * elapsed / args.steps
     audio_s = wl.total_audio_seconds if wl.scaling == "strong" else wl.audio_seconds_per_step * world
     value = audio_s / (ms_per_step / 1000.0)
-    prec_txt = ", ".join(f"{n} {'fp32' if norm(p) is None else p + ' GEMM operands / fp32 accumulate'}"
+    def spell(p):
+        if p and p.startswith("mixed"):
+            from svcmi import _lib
+            code, cls = _lib.parse_precision(p)
+            names = {v: k for k, v in _lib.PRECISIONS.items() if k in ("f32", "bf16x3", "bf16", "f16")}
+            return "mixed per-layer policy (" + ", ".join(f"{k}={names[cls[i]]}" for k, i in sorted(_lib.CLASS_NAMES.items(), key=lambda kv: kv[1]) if i < 6) + ")"
+        return p
+    prec_txt = ", ".join(f"{n} {'fp32' if norm(p) is None else spell(p) + ' GEMM operands / fp32 accumulate'}"
                          for n, p in (("Whisper", wprec), ("synthesizer", sprec)) if not (n == "Whisper" and not need_whisper))
     dtype = (norm(sprec) or "f32") if (not need_whisper or norm(wprec) == norm(sprec)) else f"{norm(wprec) or 'f32'} (Whisper) + {norm(sprec) or 'f32'} (synthesizer)"
 
@@ -578,6 +611,11 @@ def main():
     if single is not None:
         out["config"]["single_stream"] = single
     perr = measured_precision_error(args.config, wprec, sprec)
+    if norm(wprec) or norm(sprec):
+        # measured HERE, on this run's inputs: the same step (same device RNG seed => same stochastic draws) in the line's mode and in
+        # fp32 (the fp32 engine is pinned to the oracle at 2e-6: tests/test_gpu_engine.py), eager, outside the timed region
+        live = live_precision_error(wl.one_batch if args.config == 3 else wl.step, whisper, model, norm(wprec), norm(sprec))
+        perr = dict(perr or {"mode": norm(sprec) or norm(wprec)}, **live)
     if perr is not None:
         out["config"]["precision_error"] = perr
     if rank == 0 and not args.no_roofline:

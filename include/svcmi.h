@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SVCMI_ABI_VERSION 18
+#define SVCMI_ABI_VERSION 19
 
 enum svcmi_status { SVCMI_OK = 0, SVCMI_EINVAL = -1, SVCMI_EUNSUPPORTED = -2, SVCMI_EALIGN = -3 };
 
@@ -141,7 +141,10 @@ enum svcmi_precision { SVCMI_PREC_F32 = 0, SVCMI_PREC_BF16X3 = 1, SVCMI_PREC_BF1
                         * SVCMI_PREC_BF16X3_A16: the split-bf16 products of SVCMI_PREC_BF16X3 on 16-bit activations: a row of d->x is [hi: ldx/2 values |
                         * lo: ldx/2 values] (what the producers write for y16_format = SVCMI_PREC_BF16X3; ldx % 16 == 0, c_in <= ldx/2), the weight image
                         * [hi row | lo row] in natural k order. */
-                       SVCMI_PREC_BF16_A16 = 4, SVCMI_PREC_F16_A16 = 5, SVCMI_PREC_BF16X3_A16 = 6 };
+                       SVCMI_PREC_BF16_A16 = 4, SVCMI_PREC_F16_A16 = 5, SVCMI_PREC_BF16X3_A16 = 6,
+                       /* model-level only (svcmi_synth_model.precision): every layer CLASS of the synthesizer runs in its own mode,
+                        * svcmi_synth_model.class_prec[] -- the per-layer mixed policy that keeps the 16-bit waveform error inside the parity bar */
+                       SVCMI_PREC_MIXED = 7 };
 int svcmi_pack_weights_lp(const float* w, int32_t n, int32_t ldw, int32_t precision, void* out, int32_t ldw16, void* stream);
 int svcmi_conv_gemm_lp(const svcmi_conv_desc* d, int32_t precision, void* stream);
 int svcmi_conv_gemm_group_lp(const svcmi_conv_desc* descs, int32_t count, int32_t precision, void* stream);
@@ -447,7 +450,9 @@ typedef struct svcmi_weight {
     const float* bias;
     const void* w16;
     const void* w16a;     /* the natural-k-order image of the SVCMI_PREC_*_A16 kernels (same ldw16), or NULL: 16-bit activations are not used here */
-    int32_t n, ldw, ldw16, reserved;
+    int32_t n, ldw, ldw16;
+    int32_t prec16;       /* enum svcmi_precision the w16 / w16a images were packed for (0 = unknown: trusted to match the model's mode); a launch
+                           * whose mode differs runs on the fp32 operand instead of misreading the image */
 } svcmi_weight;
 
 /* ---- Whisper audio encoder, truncated as whisper/inference.py:11-29 does (n_layers = the kept blocks) */
@@ -479,6 +484,11 @@ int svcmi_whisper_encoder_fwd(const svcmi_whisper_model* m, const float* mel, co
                               int32_t batch, int32_t n_frames, float* out, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- SynthesizerInfer (vits/models.py:211-256) */
+/* layer classes of the per-layer mixed-precision policy: prior encoder (enc_p: pre / hub / attention + FFN layers / proj, and its attention
+ * kernel), flow (pre / in / res_skip / post of every coupling layer), the generator's trunk (conv_pre + every ups[i]), and the AMP-block
+ * convolutions of generator stage i (SVCMI_CLASS_AMP0 + i; stages on the fused vector-ALU kernels compute in fp32 whatever this says) */
+enum svcmi_prec_class { SVCMI_CLASS_ENC = 0, SVCMI_CLASS_FLOW = 1, SVCMI_CLASS_UPS = 2, SVCMI_CLASS_AMP0 = 3 };
+#define SVCMI_PREC_CLASSES 8
 typedef struct svcmi_enc_layer {                    /* attentions.Encoder layer i, vits/attentions.py:36-72 */
     svcmi_weight qkv, o, f1, f2;                    /* conv_q|k|v fused, conv_o, FFN conv_1 / conv_2 */
     const float *rel_k, *rel_v;                     /* emb_rel_k / emb_rel_v [2*window+1][H/heads] */
@@ -511,9 +521,12 @@ typedef struct svcmi_gen_stage {                    /* ups[i] + noise_convs[i] +
 typedef struct svcmi_synth_model {
     int32_t hidden, inter, n_heads, enc_window, enc_ffn_kernel, flow_kernel, n_enc, n_flow, n_stages;
     int32_t ppg_dim, vec_dim, spk_dim, upsample_input, hop;
-    int32_t precision;                              /* enum svcmi_precision of prior encoder / flow / generator GEMMs */
+    int32_t precision;                              /* enum svcmi_precision of prior encoder / flow / generator GEMMs, or SVCMI_PREC_MIXED */
     float lp_min_flops;                             /* 0 = 1.5e9 */
     float sampling_rate, merge_b;
+    /* SVCMI_PREC_MIXED: the mode (SVCMI_PREC_F32 / _BF16X3 / _BF16 / _F16) of each layer class -- enum svcmi_prec_class; the w16 images of a
+     * class's weights must be packed for its mode.  Ignored in every other `precision`. */
+    int32_t class_prec[SVCMI_PREC_CLASSES];
     svcmi_weight pre, hub, proj;                    /* enc_p.pre / hub / proj (vits/models.py:26-37) */
     const float* pit_emb;                           /* enc_p.pit [256][hidden] */
     svcmi_enc_layer enc[SVCMI_MAX_ENC_LAYERS];

@@ -3,6 +3,7 @@ against the oracle; shared by the emulator tests (tiny shapes, CPU) and the GPU 
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from workload import config as C
@@ -93,6 +94,46 @@ def check_generator_widths_against_oracle(ops, device, T=5, B=2, tol=TIGHT, prec
             assert trace["svcmi_conv_gemm_group_lp"]["a16_launches"] >= 6, trace["svcmi_conv_gemm_group_lp"]
     assert errs["source"] <= 5e-5 and errs["wave"] <= min(tol * 5, WAVE_TOL), errs
     return errs
+
+
+def check_mixed_precision_policy(ops, device, T=3, B=1):
+    """The per-class precision switch of the stage host (svcmi_synth_model.class_prec): a policy that names ONE mode for every class must
+    reproduce that mode's waveform bit for bit (same kernels, same images per launch); the default policy uses split-bf16 AND fp16
+    launches in one pass and lands between fp32 and plain fp16; class names / modes are validated."""
+    from svcmi import _lib
+    hp = C.tiny_hp()
+    hp["gen"] = dict(hp["gen"], upsample_initial_channel=320)
+    m, sd = make_model(hp, ops, device)
+    d = I.synth_clip(T=T, hp=hp, seed=23, B=B)
+    src = m.pitch2source(d["pit"], noise=(d["rand_ini"], d["src_noise"]))
+    saved = ops.lp_min_flops
+    ops.lp_min_flops = 0.0
+    outs, traces = {}, {}
+    try:
+        for pol in (None, "f16", "mixed:" + ",".join(f"{k}=f16" for k in _lib.CLASS_NAMES), "bf16x3",
+                    "mixed:" + ",".join(f"{k}=bf16x3" for k in _lib.CLASS_NAMES), "mixed", "mixed:enc=f32,flow=f32,ups=f32,amp0=f32,amp1=f32,amp2=f32"):
+            m.precision = pol
+            ops.trace_begin()
+            outs[pol] = m.inference(d["ppg"], d["vec"], d["pit"], d["spk"], d["lengths"], src, noise=d["enc_noise"]).clone()
+            traces[pol] = ops.trace_end()
+    finally:
+        m.precision, ops.lp_min_flops = None, saved
+    keys = list(outs)
+    assert torch.equal(outs[keys[1]], outs[keys[2]]) and torch.equal(outs[keys[3]], outs[keys[4]])
+    assert torch.equal(outs[None], outs[keys[6]])                            # every class fp32 == the fp32 model
+    with torch.no_grad():
+        o_src = O.pitch2source(sd, hp, d["pit"], d["rand_ini"], d["src_noise"])
+        o_wav = O.synth_inference(sd, hp, d["ppg"], d["vec"], d["pit"], d["spk"], d["lengths"], o_src, d["enc_noise"])
+    errs = {str(k): maxerr(v, o_wav) for k, v in outs.items()}
+    precs = lambda tr: sorted({r for name in ("svcmi_conv_gemm_lp", "svcmi_conv_gemm_group_lp") for r in tr.get(name, {}).get("precisions", [])})
+    assert errs["None"] <= TIGHT * 5 and errs["bf16x3"] <= 2e-4 and errs["mixed"] <= 4e-3 and errs["f16"] <= 4e-3, errs
+    assert not torch.equal(outs["mixed"], outs["f16"]) and not torch.equal(outs["mixed"], outs["bf16x3"])
+    ran = precs(traces["mixed"])
+    assert _lib.PREC_BF16X3 in ran and (_lib.PREC_F16 in ran or _lib.PREC_F16_A16 in ran), ran      # both families in ONE pass
+    for bad in ("mixed:decoder=f16", "mixed:enc=int8", "fp8"):
+        with pytest.raises(_lib.SvcmiError):
+            _lib.parse_precision(bad)
+    return errs, {str(k): precs(v) for k, v in traces.items()}
 
 
 def check_whisper_golden(ops, device, tag, dims, tol=TIGHT, precision=None):

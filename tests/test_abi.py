@@ -32,7 +32,8 @@ def test_library_exports_every_declared_symbol(hip_so):
         assert hasattr(lib, s), f"{s} declared in include/svcmi.h but not exported"
     lib.svcmi_build_info.restype = ctypes.c_char_p
     assert lib.svcmi_build_info() == b"hip:gfx950"
-    assert lib.svcmi_abi_version() == 18
+    from svcmi import _lib
+    assert lib.svcmi_abi_version() == _lib.ABI_VERSION == 19
 
 
 def test_binding_table_matches_header():

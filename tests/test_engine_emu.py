@@ -58,6 +58,10 @@ def test_generator_base_widths_f16_with_16bit_activations(ops):
     print(E.check_generator_widths_against_oracle(ops, "cpu", T=3, B=1, tol=4e-3, precision="f16"))
 
 
+def test_mixed_precision_policy_switches_modes_per_layer_class(ops):
+    print(E.check_mixed_precision_policy(ops, "cpu"))
+
+
 def test_whisper_tiny_f16_operands(ops):
     """fp16 operands (what the reference's `.half()` accelerator path uses, whisper/inference.py:22-23) on the tiny encoder:
     error in the fp16 class, far from fp32's 1e-6 but bounded."""

@@ -105,6 +105,24 @@ def test_configs1_end_to_end(ops, whisper, clip10, mode):
     assert e_ppg <= PPG_REL_BOUND[mode] and e_wav <= WAVE_BOUND[mode]
 
 
+def test_configs1_f16_whisper_mixed_synthesizer(ops, whisper, clip10):
+    """configs[1] / [4] style end to end: Whisper in fp16 (the reference's .half()), the synthesizer under the default mixed policy."""
+    _, wm = whisper
+    c, d, m = clip10, clip10["d"], clip10["m"]
+    wm.encoder.precision, m.precision = "f16", "mixed"
+    try:
+        ppg50 = wm.encoder(d["mel"], d["mel_noise"], 0.1)[:, :500]
+        src = m.pitch2source(d["pit"], noise=(d["rand_ini"], d["src_noise"]))
+        wav = m.inference_ppg50(ppg50, d["vec"].cuda(), d["pit"].cuda(), d["spk"].cuda(), d["lengths"].to("cuda", torch.int32), src,
+                                noise=d["enc_noise"].cuda())
+    finally:
+        wm.encoder.precision = m.precision = None
+    e_wav = E.maxerr(wav, c["wav"])
+    REPORT["configs1_mixed"] = dict(wave_max_abs_err=e_wav, ppg_rel_err=E.maxerr(ppg50, c["ppg50"]) / float(c["ppg50"].abs().max()))
+    print(f"configs[1] f16 Whisper + mixed synthesizer: waveform max-abs err {e_wav:.2e}")
+    assert e_wav <= 1e-3
+
+
 @pytest.mark.parametrize("mode", MODES)
 def test_configs2_batch16_flow_decoder(ops, clip10, mode):
     """configs[2]: 16 x 10 s clips, flow + decoder only (pre-extracted PPG / F0).  Item 0 is the configs[1] clip (its PPG
@@ -132,6 +150,90 @@ def test_configs2_batch16_flow_decoder(ops, clip10, mode):
     assert n_lp >= 40 and wav.shape == (B, 1, 320000) and bool(torch.isfinite(wav).all())
     assert E.maxerr(ref32[:1], c["wav"]) <= E.WAVE_TOL
     assert e_item0 <= WAVE_BOUND[mode] and e_all <= 2 * WAVE_BOUND[mode]
+
+
+# Per-layer mixed precision: a mode per layer class (svcmi_synth_model.class_prec).  scripts/precision_sensitivity.py
+# (16-bit operand rounding emulated on the CPU oracle) ranks the classes: conv_pre + the transposed convolutions carry half of the
+# fp16 waveform error for 2 % of the FLOPs, the prior encoder a quarter (and all of it on outlier weights), the AMP convolutions and
+# the flow -- 90 % of the FLOPs -- the rest in equal small parts.  The sweep below measures candidate policies on configs[2]
+# (error of item 0 against the fp32 ORACLE, all 16 items against the fp32 engine, time per step) and on the outlier-stress weights.
+MIXED_POLICIES = ["mixed", "mixed:amp0=f16", "mixed:amp1=bf16x3", "mixed:amp1=bf16x3,amp2=bf16x3", "mixed:flow=bf16x3",
+                  "mixed:flow=bf16x3,amp1=bf16x3", "mixed:enc=f16,ups=f16,amp0=f16"]
+MIXED_BOUND = 5e-4          # waveform max-abs of the DEFAULT policy vs the fp32 oracle on configs[2] (north_star bar: 1e-3)
+
+
+def _time_ms(fn, n=4):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def test_mixed_precision_policies_configs2(ops, clip10):
+    """configs[2] (B = 16 x 10 s, flow + decoder) under the per-class policies; the default one is asserted inside MIXED_BOUND."""
+    c, m, hp = clip10, clip10["m"], clip10["hp"]
+    B = 16
+    items = [c["d"]] + [I.synth_clip(T=1000, hp=hp, seed=s, B=1, ppg=False) for s in range(1, B)]
+    g = torch.Generator().manual_seed(5)
+    ppgs = [c["ppg50"]] + [torch.randn(1, 500, hp.vits.ppg_dim, generator=g) * float(c["ppg50"].std()) for _ in range(1, B)]
+    d = {k: torch.cat([it[k] for it in items], 0) for k in ("vec", "pit", "spk", "enc_noise", "rand_ini", "src_noise", "lengths")}
+    ppg50 = torch.cat(ppgs, 0).cuda()
+    src = m.pitch2source(d["pit"], noise=(d["rand_ini"], d["src_noise"]))
+    args = (ppg50, d["vec"].cuda(), d["pit"].cuda(), d["spk"].cuda(), d["lengths"].to("cuda", torch.int32), src)
+    nz = d["enc_noise"].cuda()
+    saved = ops.lp_min_flops
+    ops.lp_min_flops = 1.5e9          # the product's own threshold (the fixture forces every launch into the mode): this is the configs[2] line as bench.py runs it
+    try:
+        ref32 = m.inference_ppg50(*args, noise=nz).clone()
+        t32 = _time_ms(lambda: m.inference_ppg50(*args, noise=nz))
+        rows = {}
+        for pol in ["f16", "bf16x3"] + MIXED_POLICIES:
+            m.precision = pol
+            try:
+                wav, n_lp = _count_lp(ops, lambda: m.inference_ppg50(*args, noise=nz))
+                ms = _time_ms(lambda: m.inference_ppg50(*args, noise=nz))
+            finally:
+                m.precision = None
+            rows[pol] = dict(item0_vs_oracle=E.maxerr(wav[:1], c["wav"]), all_vs_fp32_engine=E.maxerr(wav, ref32), ms_per_step=ms, lp_launches=n_lp)
+            print(f"configs[2] {pol}: item 0 vs oracle {rows[pol]['item0_vs_oracle']:.2e}, 16 items vs fp32 engine {rows[pol]['all_vs_fp32_engine']:.2e}, "
+                  f"{ms:.2f} ms / step (fp32 {t32:.2f}), {n_lp} lp launches")
+            assert bool(torch.isfinite(wav).all())
+    finally:
+        ops.lp_min_flops = saved
+    REPORT["configs2_mixed_policies"] = dict(fp32_ms_per_step=t32, policies=rows)
+    REPORT["configs2_mixed"] = rows["mixed"]
+    assert rows["mixed"]["item0_vs_oracle"] <= MIXED_BOUND and rows["mixed"]["all_vs_fp32_engine"] <= 1.5 * MIXED_BOUND, rows["mixed"]
+    assert rows["mixed"]["lp_launches"] >= 40
+
+
+def test_mixed_precision_on_outlier_stress_weights(ops):
+    """The same policies on workload.weights.stress_vits_state (x50 channels at conv_pre, LayerNorm gains up to 30, SnakeBeta frequencies
+    up to e): plain fp16 loses the prior encoder there (emulated: 5e-2); the default mixed policy keeps it in split-bf16."""
+    hp = C.base_hp()
+    m, sd = E.make_model(hp, ops, "cuda", stress=True)
+    d = I.synth_clip(T=1000, hp=hp, seed=2, B=1)
+    with torch.no_grad():
+        src_o = O.pitch2source(sd, hp, d["pit"], d["rand_ini"], d["src_noise"])
+        wav_o = O.synth_inference(sd, hp, d["ppg"], d["vec"], d["pit"], d["spk"], d["lengths"], src_o, d["enc_noise"])
+    src = m.pitch2source(d["pit"], noise=(d["rand_ini"], d["src_noise"]))
+    run = lambda: m.inference(d["ppg"], d["vec"], d["pit"], d["spk"], d["lengths"], src, noise=d["enc_noise"])
+    rms = float(wav_o.pow(2).mean().sqrt())
+    rows = {"f32": E.maxerr(run(), wav_o)}
+    for pol in ["f16", "bf16x3", "mixed", "mixed:flow=bf16x3,amp1=bf16x3", "mixed:amp1=bf16x3,amp2=bf16x3"]:
+        m.precision = pol
+        try:
+            rows[pol] = E.maxerr(run(), wav_o)
+        finally:
+            m.precision = None
+    REPORT["stress_mixed_policies"] = dict(wave_rms=rms, wave_max_abs_err=rows)
+    print("stress weights (rms %.3f): " % rms + ", ".join(f"{k} {v:.2e}" for k, v in rows.items()))
+    assert rows["f32"] <= E.WAVE_TOL
+    assert rows["mixed"] <= 4e-3 and rows["mixed"] < rows["f16"]        # (measured numbers: profiles/r04*_precision_report.json)
 
 
 def test_whisper_15s_window_modes(ops, whisper):

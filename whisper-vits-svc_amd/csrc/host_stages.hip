@@ -117,6 +117,13 @@ struct CV {
     void* y16 = nullptr;            // 16-bit copy of the output for the NEXT launch (written only in the bf16 / f16 modes)
 };
 
+// Per-layer mixed precision (SVCMI_PREC_MIXED): every section of the synthesizer sets c.prec to its class's mode before it launches.
+int class_prec(const svcmi_synth_model& m, int cls) {
+    if (m.precision != SVCMI_PREC_MIXED) return m.precision;
+    const int p = cls >= 0 && cls < SVCMI_PREC_CLASSES ? m.class_prec[cls] : SVCMI_PREC_F32;
+    return p >= SVCMI_PREC_F32 && p <= SVCMI_PREC_F16 ? p : SVCMI_PREC_F32;
+}
+
 bool mode16(int prec) { return prec == SVCMI_PREC_BF16 || prec == SVCMI_PREC_F16; }
 // Modes whose GEMM chains hand 16-bit activations from producer to consumer: bf16 / f16 rows, or (bf16x3) split rows [hi: C | lo: C].
 bool act16(int prec) { return mode16(prec) || prec == SVCMI_PREC_BF16X3; }
@@ -150,6 +157,7 @@ int conv_desc(const Ctx& c, const CV& v, svcmi_conv_desc& d, double& flops, doub
                    (double)v.B * t_out * N * (1 + (v.res != nullptr) + (v.accumulate ? 1 : 0)));
     const int tile_lp = v.tile_lp >= 0 ? v.tile_lp : v.tile;
     const bool lp = c.prec != SVCMI_PREC_F32 && (lp_flops >= 0.0 ? lp_flops : flops) >= c.lp_min_flops && v.w->w16 != nullptr &&
+                    (v.w->prec16 == 0 || v.w->prec16 == c.prec) &&      // (an image packed for another mode is never misread: fp32 operand instead)
                     v.c_in % 4 == 0 && v.ldx % 4 == 0 && v.x_bs % 4 == 0 && ((uintptr_t)v.x & 15) == 0 &&
                     (!v.rshift || v.c_in % 32 == 0) && lp_tile_ok(tile_lp);
     const int tile = lp ? tile_lp : (v.tile == 9 ? 0 : v.tile);      // 64x128 exists on the 16-bit kernels only
@@ -390,6 +398,7 @@ void whisper_fwd(Ctx& c, const svcmi_whisper_model& m, const float* mel, const f
 void prior_fwd(Ctx& c, const svcmi_synth_model& m, const svcmi_synth_io& io, float* z_p) {
     const int B = io.batch, T = io.t, H = m.hidden, I = m.inter, sh = io.ppg_row_shift;
     const int64_t mark = c.ar.mark();
+    c.prec = class_prec(m, SVCMI_CLASS_ENC);
     float* xa = c.ar.f((int64_t)B * T * H);
     float* xb = c.ar.f((int64_t)B * T * H);
     const int ppg_rows = (T + (1 << sh) - 1) >> sh;
@@ -480,6 +489,7 @@ void prior_fwd(Ctx& c, const svcmi_synth_model& m, const svcmi_synth_io& io, flo
 void flow_fwd(Ctx& c, const svcmi_synth_model& m, const svcmi_synth_io& io, float* x) {
     const int B = io.batch, T = io.t, H = m.hidden, I = m.inter, half = I / 2, kf = m.flow_kernel;
     const int64_t mark = c.ar.mark();
+    c.prec = class_prec(m, SVCMI_CLASS_FLOW);
     float* hs = c.ar.f((int64_t)B * T * 2 * H);
     float* skip = hs + H;
     const int nk = (kf * H + 31) / 32;
@@ -678,6 +688,7 @@ void generator_tile(Ctx& c, const svcmi_synth_model& m, const float* z, const fl
                     int split_k, int stop_after) {
     const int U = m.upsample_input;
     const int64_t mark = c.ar.mark();
+    c.prec = class_prec(m, SVCMI_CLASS_UPS);
     float* sb = c.ar.f((int64_t)B * 2 * U);
     {
         CV v; v.x = spk; v.x_bs = m.spk_dim; v.B = B; v.t_in = 1; v.c_in = v.ldx = m.spk_dim; v.w = &m.adapter; v.y = sb; v.y_bs = 2 * U; v.ldy = 2 * U;
@@ -702,6 +713,7 @@ void generator_tile(Ctx& c, const svcmi_synth_model& m, const float* z, const fl
         float* y = c.ar.f((int64_t)B * L * cp);
         float* acc = c.ar.f((int64_t)B * L * cp);
         const int64_t smark = c.ar.mark();
+        c.prec = class_prec(m, SVCMI_CLASS_UPS);
         CV up; up.x = x; up.x_bs = t_in * cin; up.B = B; up.t_in = (int)t_in; up.t_out = (int)t_in; up.c_in = up.ldx = cin; up.w = &st.up;
         up.ksize = st.up_taps; up.pad = st.up_pad; up.split_k = split_k; up.y = y; up.y_bs = L * cp; up.ldy = u * cp;
         if (svcmi_upsample_noise_supported(u, cp, cin)) {
@@ -721,6 +733,7 @@ void generator_tile(Ctx& c, const svcmi_synth_model& m, const float* z, const fl
             nz.y = y; nz.y_bs = L * cp; nz.ldy = cp;
             conv(c, nz);
         }
+        c.prec = class_prec(m, SVCMI_CLASS_AMP0 + i);
         if (!amp_stage_grouped(c, m, st, y, acc, B, L)) {
             c.ar.release(smark);
             float* xj = c.ar.f((int64_t)B * L * cp);
@@ -734,6 +747,7 @@ void generator_tile(Ctx& c, const svcmi_synth_model& m, const float* z, const fl
         if (stop_after == SVCMI_STOP_STAGE0 + i) { c.ar.release(mark); return; }
     }
     const svcmi_gen_stage& last = m.stages[m.n_stages - 1];
+    c.prec = class_prec(m, SVCMI_CLASS_UPS);
     if (svcmi_snake_post_supported(last.c, cin, 7) && m.post.ldw >= 7 * cin) {
         run(c, OP_SNAKE_POST, 2.0 * B * t_in * last.c * 7, 4.0 * B * t_in * (last.c + 1), [&] {
             return svcmi_snake_post_f32(x, m.post.w, wave, m.post_alpha, m.post_beta, m.filt, B, (int32_t)t_in, last.c, cin, 7, c.stream);
@@ -774,6 +788,10 @@ void generator_fwd(Ctx& c, const svcmi_synth_model& m, const svcmi_synth_io& io,
 }
 
 bool synth_shapes_ok(const svcmi_synth_model& m, const svcmi_synth_io& io) {
+    if (m.precision < SVCMI_PREC_F32 || (m.precision > SVCMI_PREC_F16 && m.precision != SVCMI_PREC_MIXED)) return false;
+    if (m.precision == SVCMI_PREC_MIXED)
+        for (int i = 0; i < SVCMI_PREC_CLASSES; ++i)
+            if (m.class_prec[i] < SVCMI_PREC_F32 || m.class_prec[i] > SVCMI_PREC_F16) return false;
     return io.batch > 0 && io.t > 0 && m.n_enc >= 1 && m.n_enc <= SVCMI_MAX_ENC_LAYERS && m.n_flow >= 0 && m.n_flow <= SVCMI_MAX_FLOWS &&
            m.n_stages >= 1 && m.n_stages <= SVCMI_MAX_STAGES && m.hidden % 4 == 0 && m.inter % 8 == 0 && 2 * m.inter <= 3 * m.hidden &&
            m.upsample_input % 4 == 0 && (io.ppg_row_shift == 0 || io.ppg_row_shift == 1) && io.ppg_bstride % 4 == 0;
@@ -782,7 +800,6 @@ bool synth_shapes_ok(const svcmi_synth_model& m, const svcmi_synth_io& io) {
 void synth_fwd(Ctx& c, const svcmi_synth_model& m, const svcmi_synth_io& io) {
     if (!synth_shapes_ok(m, io)) { c.rc = SVCMI_EINVAL; return; }
     const int B = io.batch, T = io.t, I = m.inter;
-    c.prec = m.precision;
     c.lp_min_flops = m.lp_min_flops > 0.f ? m.lp_min_flops : 1.5e9f;
     c.sk_ws = c.ar.f(SPLITK_FLOATS);
     float* zp = c.ar.f((int64_t)B * T * I);
@@ -854,8 +871,7 @@ int synth_entry(const svcmi_synth_model* m, const svcmi_synth_io* io, void* work
     if (!synth_shapes_ok(*m, *io)) return SVCMI_EINVAL;
     if (workspace_bytes < svcmi_synth_workspace_bytes(m, io->batch, io->t, io->stream_frames)) return SVCMI_EINVAL;
     Ctx c = make_ctx(workspace, workspace_bytes, stream, false);
-    c.prec = m->precision;
-    c.lp_min_flops = m->lp_min_flops > 0.f ? m->lp_min_flops : 1.5e9f;
+    c.lp_min_flops = m->lp_min_flops > 0.f ? m->lp_min_flops : 1.5e9f;       // (c.prec: set per layer class by the sections themselves)
     body(c);
     return finish(c);
 }

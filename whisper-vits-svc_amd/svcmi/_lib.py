@@ -8,9 +8,47 @@ DEFAULT_LIB = os.path.join(HERE, "libsvcmi.so")
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_MISH, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4, 5
 CONV_ACCUMULATE, CONV_MASK_IN, CONV_MASK_OUT, CONV_PARTIALS = 1, 2, 4, 8
-ABI_VERSION = 18
+ABI_VERSION = 19
 PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16, PREC_BF16_A16, PREC_F16_A16, PREC_BF16X3_A16 = 0, 1, 2, 3, 4, 5, 6
 PRECISIONS = {None: 0, "f32": 0, "fp32": 0, "bf16x3": 1, "bf16": 2, "f16": 3, "fp16": 3}
+PREC_MIXED = 7                     # svcmi_synth_model.precision only: per-class modes in class_prec[]
+PREC_CLASSES = 8
+CLASS_ENC, CLASS_FLOW, CLASS_UPS, CLASS_AMP0 = 0, 1, 2, 3
+CLASS_NAMES = {"enc": 0, "flow": 1, "ups": 2, "amp0": 3, "amp1": 4, "amp2": 5, "amp3": 6, "amp4": 7}
+# The default per-layer policy of the 16-bit synthesizer ("mixed"; scripts/precision_sensitivity.py + tests/test_gpu_precision.py): the
+# layers every sample passes through once with large fan-in -- conv_pre and the transposed convolutions (half of the fp16 waveform
+# error for 2 % of the FLOPs) -- and the prior encoder (LayerNorm gains / outlier channels land here) run in split-bf16 (bf16x3: fp32-class
+# products), stage 0 of the generator too; the flow and the remaining AMP convolutions -- three quarters of the FLOPs -- run in fp16 on
+# 16-bit activations.
+MIXED_DEFAULT = {"enc": "bf16x3", "ups": "bf16x3", "flow": "f16", "amp0": "bf16x3", "amp1": "f16", "amp2": "f16", "amp3": "f16", "amp4": "f16"}
+
+
+def parse_precision(p):
+    """Model-level precision spec -> (code, class tuple).  ``p``: None / "f32" / "bf16x3" / "bf16" / "f16" (one mode for every GEMM),
+    "mixed" (MIXED_DEFAULT), "mixed:enc=bf16x3,flow=f16,..." (unnamed classes keep their MIXED_DEFAULT mode), a dict of the same, an
+    int code, or an already parsed tuple."""
+    if isinstance(p, tuple):
+        return p
+    if isinstance(p, int):
+        return (p, None)
+    if p in PRECISIONS:
+        return (PRECISIONS[p], None)
+    pol = dict(MIXED_DEFAULT)
+    if isinstance(p, dict):
+        pol.update(p)
+    elif isinstance(p, str) and (p == "mixed" or p.startswith("mixed:")):
+        for item in filter(None, p[6:].split(",")):
+            k, _, v = item.partition("=")
+            pol[k.strip()] = v.strip()
+    else:
+        raise SvcmiError(f"unknown precision {p!r}")
+    bad = [k for k in pol if k not in CLASS_NAMES] + [v for v in pol.values() if v not in PRECISIONS]
+    if bad:
+        raise SvcmiError(f"mixed precision policy: unknown class / mode {bad}; classes {sorted(CLASS_NAMES)}, modes f32 / bf16x3 / bf16 / f16")
+    cls = [0] * PREC_CLASSES
+    for k, v in pol.items():
+        cls[CLASS_NAMES[k]] = PRECISIONS[v]
+    return (PREC_MIXED, tuple(cls))
 CONV_TILE_64x128 = 9
 
 
@@ -43,7 +81,7 @@ STOP_NONE, STOP_PRIOR, STOP_FLOW, STOP_GEN_PRE, STOP_STAGE0 = 0, 1, 2, 3, 4
 class Weight(Structure):
     """svcmi_weight"""
     _fields_ = [("w", c_void_p), ("bias", c_void_p), ("w16", c_void_p), ("w16a", c_void_p), ("n", c_int32), ("ldw", c_int32),
-                ("ldw16", c_int32), ("reserved", c_int32)]
+                ("ldw16", c_int32), ("prec16", c_int32)]
 
 
 class WhisperBlock(Structure):
@@ -91,6 +129,7 @@ class SynthModel(Structure):
                 ("flow_kernel", c_int32), ("n_enc", c_int32), ("n_flow", c_int32), ("n_stages", c_int32),
                 ("ppg_dim", c_int32), ("vec_dim", c_int32), ("spk_dim", c_int32), ("upsample_input", c_int32), ("hop", c_int32),
                 ("precision", c_int32), ("lp_min_flops", c_float), ("sampling_rate", c_float), ("merge_b", c_float),
+                ("class_prec", c_int32 * PREC_CLASSES),
                 ("pre", Weight), ("hub", Weight), ("proj", Weight), ("pit_emb", c_void_p),
                 ("enc", EncLayer * MAX_ENC_LAYERS), ("flow", FlowLayer * MAX_FLOWS),
                 ("adapter", Weight), ("conv_pre", Weight), ("post", Weight),

@@ -18,10 +18,10 @@ def _weight(cw, ops, w, bias, prec, keep, a16=False):
     """``a16``: also pack the natural-order image of the 16-bit-activation kernels."""
     cw.w, cw.bias = w.data_ptr(), (0 if bias is None else bias.data_ptr())
     cw.n, cw.ldw = int(w.shape[0]), int(w.shape[1])
-    cw.w16, cw.w16a, cw.ldw16 = 0, 0, 0
+    cw.w16, cw.w16a, cw.ldw16, cw.prec16 = 0, 0, 0, 0
     if prec != PREC_F32 and w.dim() == 2 and w.is_contiguous():
         img = ops.lp_weight(w, prec)
-        cw.w16, cw.ldw16 = img.data_ptr(), img.shape[1] // (2 if prec == PREC_BF16X3 else 1)
+        cw.w16, cw.ldw16, cw.prec16 = img.data_ptr(), img.shape[1] // (2 if prec == PREC_BF16X3 else 1), prec
         keep.append(img)
         if a16:
             img_a = ops.lp_weight(w, _lib.PREC_BF16X3_A16 if prec == PREC_BF16X3 else prec + 2)          # PREC_BF16_A16 / PREC_F16_A16 / PREC_BF16X3_A16
@@ -53,7 +53,9 @@ def whisper_cmodel(w, ops, prec=PREC_F32):
 
 
 def synth_cmodel(w, ops, prec=PREC_F32):
-    """``w``: svcmi.weights.VitsWeights."""
+    """``w``: svcmi.weights.VitsWeights.  ``prec``: one mode for every GEMM (an ``enum svcmi_precision`` code) or the
+    ``(PREC_MIXED, class modes)`` tuple of ``_lib.parse_precision``: every weight then gets the 16-bit images of ITS class's mode."""
+    code, classes = prec if isinstance(prec, tuple) else (prec, None)
     m, keep = _lib.SynthModel(), [w]
     hp = w.hp
     if len(w.enc) > _lib.MAX_ENC_LAYERS or len(w.flow) > _lib.MAX_FLOWS or len(w.stages) > _lib.MAX_STAGES:
@@ -63,9 +65,15 @@ def synth_cmodel(w, ops, prec=PREC_F32):
     m.n_enc, m.n_flow, m.n_stages = len(w.enc), len(w.flow), len(w.stages)
     m.ppg_dim, m.vec_dim, m.spk_dim = hp.vits.ppg_dim, hp.vits.vec_dim, hp.vits.spk_dim
     m.upsample_input, m.hop = w.U, w.hop
-    m.precision, m.lp_min_flops = prec, 0.0
+    m.precision, m.lp_min_flops = code, 0.0
+    for i in range(_lib.PREC_CLASSES):
+        m.class_prec[i] = classes[i] if classes else 0
     m.sampling_rate, m.merge_b = float(hp.data.sampling_rate), float(w.merge_b)
-    W = lambda cw, wt, b=None, a16=False: _weight(cw, ops, wt, b, prec, keep, a16=a16 and prec != PREC_BF16X3)     # 16-bit activation rows: bf16 / f16 modes
+    state = {"cls": _lib.CLASS_ENC}
+
+    def W(cw, wt, b=None, a16=False):
+        p = classes[state["cls"]] if classes else code
+        _weight(cw, ops, wt, b, p, keep, a16=a16 and p != PREC_BF16X3)     # 16-bit activation rows: bf16 / f16 modes
     W(m.pre, w.pre_w, w.pre_b)
     W(m.hub, w.hub_w, w.hub_b)
     W(m.proj, w.proj_w, w.proj_b)
@@ -78,6 +86,7 @@ def synth_cmodel(w, ops, prec=PREC_F32):
         W(e.f2, L["f2_w"], L["f2_b"], a16=True)
         e.rel_k, e.rel_v = L["rel_k"].data_ptr(), L["rel_v"].data_ptr()
         e.g1, e.b1, e.g2, e.b2 = (L[k].data_ptr() for k in ("g1", "b1", "g2", "b2"))
+    state["cls"] = _lib.CLASS_FLOW
     for i, L in enumerate(w.flow):
         f = m.flow[i]
         if len(L["wn"]) > _lib.MAX_WN_LAYERS:
@@ -89,6 +98,7 @@ def synth_cmodel(w, ops, prec=PREC_F32):
         for l, Wl in enumerate(L["wn"]):
             W(f.wn[l].in_, Wl["in_w"], Wl["in_b"])
             W(f.wn[l].rs, Wl["rs_w"], Wl["rs_b"])
+    state["cls"] = _lib.CLASS_UPS
     W(m.adapter, w.ad_w, w.ad_b)
     W(m.conv_pre, w.pre_conv_w, w.pre_conv_b)
     W(m.post, w.post_w, None)
@@ -100,8 +110,10 @@ def synth_cmodel(w, ops, prec=PREC_F32):
             raise _lib.SvcmiError("more AMP blocks per stage than svcmi_gen_stage holds")
         s.u, s.c, s.cp, s.up_taps, s.up_pad = st["u"], st["c"], st["cp"], st["up_taps"], st["up_pad"]
         s.nz_k, s.nz_stride, s.nz_pad, s.n_blocks = st["nz_k"], st["nz_stride"], st["nz_pad"], len(st["blocks"])
+        state["cls"] = _lib.CLASS_UPS
         W(s.up, st["up_w"], st["up_b"])
         W(s.nz, st["nz_w"], st["nz_b"])
+        state["cls"] = min(_lib.CLASS_AMP0 + i, _lib.PREC_CLASSES - 1)
         for j, blk in enumerate(st["blocks"]):
             b = s.blocks[j]
             if len(blk["d"]) > _lib.MAX_AMP_DILATIONS:

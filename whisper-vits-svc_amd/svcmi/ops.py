@@ -290,15 +290,18 @@ class Ops:
         tl, self.timeline = self.timeline or [], None
         agg = {}
 
-        def add(name, ms, flops, nbytes, a16=False):
-            a = agg.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "a16_launches": 0})
+        def add(name, ms, flops, nbytes, a16=False, prec=0):
+            a = agg.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "a16_launches": 0, "precisions": []})
+            if prec and prec not in a["precisions"]:
+                a["precisions"].append(prec)                   # enum svcmi_precision codes the reduced-precision launches of this op ran in
             a["launches"] += 1
             a["ms"] += ms
             a["flops"] += flops
             a["bytes"] += nbytes
             a["a16_launches"] += int(a16)         # GEMM launches that took 16-bit activations (SVCMI_PREC_*_A16)
         for i in range(n):
-            add(self.lib.svcmi_trace_op_name(recs[i].op).decode(), recs[i].ms, recs[i].flops, recs[i].bytes, (recs[i].op >> 8) >= _lib.PREC_BF16_A16)
+            add(self.lib.svcmi_trace_op_name(recs[i].op).decode(), recs[i].ms, recs[i].flops, recs[i].bytes, (recs[i].op >> 8) >= _lib.PREC_BF16_A16,
+                recs[i].op >> 8)
         if tl and self.on_gpu:
             torch.cuda.synchronize()
         for name, work, e0, e1 in tl:

@@ -218,8 +218,10 @@ def main(args):
     f0_prec = None if getattr(args, "f0_precision", "f32") == "f32" else getattr(args, "f0_precision", "f32")
     prec = None if getattr(args, "precision", "f32") == "f32" else args.precision
 
+    enc_prec = "f16" if prec == "mixed" else prec      # the mixed policy's classes are the synthesizer's; the extractors follow the reference's .half()
+
     def _with_prec(m):
-        (m.encoder if hasattr(m, "encoder") else m).precision = prec
+        (m.encoder if hasattr(m, "encoder") else m).precision = enc_prec
         return m
     if args.ppg is None and args.vec is None and args.pit is None:
         # all three features from the wav: the extractors run in flight together (extract_features); the intermediate files keep
@@ -285,7 +287,7 @@ def build_parser():
     p.add_argument("--hubert", type=str, default=os.path.join("hubert_pretrain", "hubert-soft-0d54a1f4.pt"))
     p.add_argument("--crepe", type=str, default=os.path.join("crepe", "assets", "full.pth"))
     p.add_argument("--debug", action="store_true")
-    p.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16", "f16"],
+    p.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16", "f16", "mixed"],
                    help="GEMM operand precision of the Whisper / HuBERT encoders and the synthesizer (fp32 accumulation, LayerNorm / softmax / "
                         "SnakeAlias in fp32 in every mode): f32 = the reference CPU path's arithmetic (parity default); bf16x3 = split-bf16, "
                         "waveform within 2e-5 of fp32; f16 = what the reference's .half() accelerator path does (waveform within 1e-3); bf16 (7e-3)")

@@ -63,7 +63,8 @@ class Converter:
         self.model.eval()
         self.model.to(device)
         prec = None if getattr(args, "precision", "f32") == "f32" else args.precision
-        self.whisper.encoder.precision = self.hubert.precision = self.model.precision = prec
+        self.whisper.encoder.precision = self.hubert.precision = "f16" if prec == "mixed" else prec     # (the mixed policy's classes are the synthesizer's)
+        self.model.precision = prec
         self.spk = torch.FloatTensor(np.load(args.spk))
         self.tmp = os.path.join(OUT_PATH, f".rank{rank}")
         # everything lazily built (packed synthesizer weights, C model structs) is built HERE, on the constructing thread, and the device
@@ -158,7 +159,7 @@ def build_parser():
     p.add_argument("--whisper", type=str, default=os.path.join("whisper_pretrain", "large-v2.pt"))
     p.add_argument("--hubert", type=str, default=os.path.join("hubert_pretrain", "hubert-soft-0d54a1f4.pt"))
     p.add_argument("--crepe", type=str, default=os.path.join("crepe", "assets", "full.pth"))
-    p.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16", "f16"],
+    p.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16", "f16", "mixed"],
                    help="GEMM operand precision of Whisper / HuBERT / synthesizer (see svc_inference); f32 = parity default")
     p.add_argument("--f0-precision", default="f32", choices=["f32", "bf16x3", "f16", "bf16"], help="GEMM operand precision of the CREPE F0 extractor (see svc_inference)")
     p.add_argument("--workers", type=int, default=3,

@@ -35,7 +35,8 @@ class SynthesizerInfer:
         self._cm = {}                    # C model structs (svcmi_synth_model), one per GEMM operand precision
         self._lock = threading.RLock()   # lazy weight packing / struct building may be reached from several worker threads
         # GEMM operand precision of prior encoder / flow / generator: None = fp32 (parity default), "bf16x3" / "bf16" /
-        # "f16" (Ops.use_precision).  Element-wise kernels, softmax, LayerNorm, SnakeAlias and accumulation stay fp32.
+        # "f16" (one mode for every GEMM), or "mixed" / "mixed:enc=bf16x3,flow=f16,..." = a mode per layer class
+        # (_lib.parse_precision, _lib.MIXED_DEFAULT).  Element-wise kernels, softmax, LayerNorm, SnakeAlias and accumulation stay fp32.
         self.precision = None
         # Streaming decoder (BASELINE.json configs[4]): None = the generator sees a whole synthesis chunk;
         # N = it runs over time tiles of N frames plus a STREAM_HALO-frame halo on each side that is computed and discarded.
@@ -121,7 +122,8 @@ class SynthesizerInfer:
         """The svcmi_synth_model struct for ``precision`` (None = self.precision): pointers into the packed weights (+ their 16-bit
         images, packed on first use)."""
         p = self.precision if precision is None else precision
-        prec = _lib.PRECISIONS.get(p, p)
+        prec = _lib.parse_precision(p)            # (code, None) or (PREC_MIXED, per-class modes): hashable, one struct per distinct policy
+        prec = prec[0] if prec[1] is None else prec
         cm = self._cm.get(prec)
         if cm is None:
             with self._lock:
