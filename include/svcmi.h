@@ -256,6 +256,25 @@ typedef struct svcmi_snake_conv_desc {
 int svcmi_snake_conv_group_f32(const svcmi_snake_conv_desc* descs, int32_t count, const float* filt, int32_t batch,
                                int32_t len, int32_t c, int32_t ld, void* stream);
 
+/* A WHOLE AMP block (vits_decoder/bigv.py:22-58, AMPBlock.forward :50-58) of a narrow stage as one launch, for up to 3 blocks of a stage
+ * (3 / 7 / 11 taps; blockIdx.z) that share the stage input x:
+ *     for q < n_dil:  x = x + conv2_q( SnakeAlias_{a2[q]}( conv1_q( SnakeAlias_{a1[q]}(x) ) ) ),   conv1_q dilated by dil[q], conv2_q by 1
+ * with the time tile resident in LDS across all 2 * n_dil half-steps (halo per side = sum_q 10 + (ksize-1)/2 * (dil[q] + 1) samples,
+ * recomputed per tile); y = the block's x after the last iteration (generator.py:188-194 then averages the blocks: svcmi_block_mean_f32).
+ * Results equal the chain of svcmi_snake_conv_f32 half-steps bit for bit.  Weights / activation parameters as svcmi_snake_conv_f32 takes
+ * them.  Supported: (c, ld) = (10, 12) and (20, 20), ksize in {3, 7, 11}, n_dil <= 3, dil <= 5 (svcmi_amp_block_group_supported).
+ * x and the y's must not overlap. */
+typedef struct svcmi_amp_block_desc {
+    const float* x; float* y;
+    const float* w1[3]; const float* b1[3]; const float* w2[3]; const float* b2[3];
+    const float* a1_alpha[3]; const float* a1_beta[3]; const float* a2_alpha[3]; const float* a2_beta[3];
+    int32_t ldw1[3], ldw2[3], dil[3];
+    int32_t ksize, n_dil, reserved;
+} svcmi_amp_block_desc;
+int svcmi_amp_block_group_supported(int32_t c, int32_t ld);
+int svcmi_amp_block_group_f32(const svcmi_amp_block_desc* descs, int32_t count, const float* filt, int32_t batch, int32_t len,
+                              int32_t c, int32_t ld, void* stream);
+
 /* Stage entry of the narrow generator stages in one launch (vits_decoder/generator.py:183-186):
  *   y[b, u*q + r, co] = b_up[r*cp+co] + sum_{k<taps} sum_{ci<c_in} x[b, q + k - pad, ci] * w_up[r*cp+co, k*c_in + ci]      (ups[i], polyphase)
  *                     + b_nz[co] + sum_{k<nz_k} src[b, (u*q+r)*nz_stride - nz_pad + k] * w_nz[co, k]                       (noise_convs[i])
@@ -598,7 +617,7 @@ int svcmi_packed_model_info(const void* file, int64_t file_bytes, int32_t* kind,
 int svcmi_packed_model_bind(const void* file, int64_t file_bytes, const void* device_arena, void* model_out, int64_t model_bytes);
 
 /* Layout check for FFI bindings: out[i] = sizeof of svcmi_weight, svcmi_whisper_model, svcmi_synth_model, svcmi_synth_io,
- * svcmi_trace_record, svcmi_conv_desc, svcmi_snake_conv_desc (in this order, up to `cap`); returns the count written.  A binding
+ * svcmi_trace_record, svcmi_conv_desc, svcmi_snake_conv_desc, svcmi_amp_block_desc (in this order, up to `cap`); returns the count written.  A binding
  * compares them with its own struct sizes before it trusts a filled struct (svcmi/_lib.py does at load). */
 int svcmi_struct_sizes(int64_t* out, int32_t cap);
 

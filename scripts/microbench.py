@@ -56,9 +56,64 @@ def gemm(ops, tag, T, cin, n, k=1, dil=1, res=False, tiles=(0, 1, 2, 3), splits=
                 print(f"gemm {tag} tile={tile} split={sk}: {e}")
 
 
+def ampblock(ops, c, ld, L, B):
+    """One narrow generator stage (3 AMP blocks, k = 3 / 7 / 11, dilations 1 / 3 / 5): six grouped half-step launches
+    (svcmi_snake_conv_group_f32) against one launch of the fused block kernel (svcmi_amp_block_group_f32), every tile variant."""
+    from workload import weights as W
+    g = torch.Generator().manual_seed(c)
+    filt = W.kaiser_sinc_filter().view(-1).cuda()
+    x = torch.zeros(B, L, ld)
+    x[..., :c] = torch.randn(B, L, c, generator=g)
+    x = x.cuda()
+    blocks = []
+    for k in (3, 7, 11):
+        blk = dict(ksize=k, dil=[1, 3, 5], c1=[], c2=[], a1=[], a2=[])
+        for _ in range(3):
+            for key in ("c1", "c2"):
+                blk[key].append((PW.pack_conv(torch.randn(c, c, k, generator=g) / math.sqrt(c * k), ld, ld).cuda(), PW.pad_vec(torch.randn(c, generator=g) * 0.1, ld).cuda()))
+            for key in ("a1", "a2"):
+                al, be = torch.zeros(ld), torch.zeros(ld)
+                al[:c], be[:c] = torch.randn(c, generator=g) * 0.3, torch.randn(c, generator=g) * 0.3
+                blk[key].append((al.cuda(), be.cuda()))
+        blocks.append(blk)
+    t1 = [torch.empty_like(x) for _ in range(3)]
+    xa = [torch.empty_like(x) for _ in range(3)]
+    xb = [torch.empty_like(x) for _ in range(3)]
+
+    def chain():
+        cur = [x, x, x]
+        for q in range(3):
+            nxt = xa if q % 2 == 0 else xb
+            ops.snake_conv_group([dict(x=cur[j], alpha_log=b["a1"][q][0], beta_log=b["a1"][q][1], w=b["c1"][q][0], bias=b["c1"][q][1], ksize=b["ksize"],
+                                       dilation=b["dil"][q], out=t1[j]) for j, b in enumerate(blocks)], filt, c=c)
+            ops.snake_conv_group([dict(x=t1[j], alpha_log=b["a2"][q][0], beta_log=b["a2"][q][1], w=b["c2"][q][0], bias=b["c2"][q][1], ksize=b["ksize"],
+                                       dilation=1, res=cur[j], out=nxt[j]) for j, b in enumerate(blocks)], filt, c=c)
+            cur = nxt
+        return cur
+    want = [t.clone() for t in chain()]
+    us0 = timeit(chain, iters=10, warm=2)
+    fl = sum(4.0 * 3 * B * L * c * c * b["ksize"] for b in blocks)
+    print(f"ampblock c={c} L={L} B={B}: six grouped half-step launches {us0:9.1f} us  ({fl / us0 / 1e6:5.1f} TFLOP/s conv work)", flush=True)
+    for v in (1, 2, 3, 4):
+        ops.lib.svcmi_tune_set(b"amp_block_variant", v)
+        try:
+            got = ops.amp_block_group(x, blocks, filt, c=c)
+            same = all(torch.equal(a, b) for a, b in zip(got, want))
+            us = timeit(lambda: ops.amp_block_group(x, blocks, filt, c=c), iters=10, warm=2)
+            print(f"ampblock c={c} L={L} B={B}: fused block kernel, variant {v}      {us:9.1f} us  ({fl / us / 1e6:5.1f} TFLOP/s)  bit-identical {same}  x{us0 / us:.2f}", flush=True)
+        except Exception as e:      # noqa: BLE001
+            print(f"ampblock c={c} variant {v}: {e}")
+        finally:
+            ops.lib.svcmi_tune_set(b"amp_block_variant", 0)
+
+
 def main():
     what = sys.argv[1:] or ["gemm", "snake", "dec", "attn"]
     ops = Ops()
+    if "ampblock" in what:
+        for B in (1, 4, 16):
+            ampblock(ops, 10, 12, 320000, B)
+            ampblock(ops, 20, 20, 160000, B)
     if "gemm" in what:
         gemm(ops, "whisper_qkv", 500, 1280, 3840)
         gemm(ops, "whisper_o", 500, 1280, 1280, res=True, splits=(1, 0, 2, 4))

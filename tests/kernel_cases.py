@@ -655,6 +655,44 @@ def check_snake_conv_group(ops, device, c=20, ld=20, B=2, n=300):
             ops.lib.svcmi_tune_set(b"amp_u", 0)
 
 
+def check_amp_block_group(ops, device, c=10, ld=12, B=2, n=700, variants=(0,), nblocks=3):
+    """A whole AMP block per launch (svcmi_amp_block_group_f32: the tile stays in LDS over the six half-steps, halos recomputed) equals
+    the chain of half-step launches (svcmi_snake_conv_f32) bit for bit -- every tile geometry of the kernel, sequence ends inside the
+    halo, tiles that end past the sequence, sequences shorter than one halo."""
+    g = _g(900 + 7 * c + n)
+    filt = W.kaiser_sinc_filter().view(-1).to(device)
+    x = torch.zeros(B, n, ld)
+    x[..., :c] = torch.randn(B, n, c, generator=g)
+    xd = x.to(device)
+    blocks, want = [], []
+    for k in (3, 11, 7)[:nblocks]:
+        blk = dict(ksize=k, dil=[1, 3, 5], c1=[], c2=[], a1=[], a2=[])
+        for _ in range(3):
+            for key in ("c1", "c2"):
+                w = PW.pack_conv(torch.randn(c, c, k, generator=g) / math.sqrt(c * k), ld, ld).to(device)
+                blk[key].append((w, PW.pad_vec(torch.randn(c, generator=g) * 0.1, ld).to(device)))
+            for key in ("a1", "a2"):
+                al, be = torch.zeros(ld), torch.zeros(ld)
+                al[:c], be[:c] = torch.randn(c, generator=g) * 0.3, torch.randn(c, generator=g) * 0.3
+                blk[key].append((al.to(device), be.to(device)))
+        blocks.append(blk)
+        cur = xd
+        for q, d in enumerate(blk["dil"]):           # the reference chain: xt = conv1(act1(x)); x = conv2(act2(xt)) + x
+            t = ops.snake_conv(cur, blk["a1"][q][0], blk["a1"][q][1], filt, blk["c1"][q][0], blk["c1"][q][1], c=c, ksize=k, dilation=d)
+            cur = ops.snake_conv(t, blk["a2"][q][0], blk["a2"][q][1], filt, blk["c2"][q][0], blk["c2"][q][1], c=c, ksize=k, dilation=1, res=cur)
+        want.append(cur)
+    assert ops.lib.svcmi_amp_block_group_supported(c, ld) == 1 and ops.lib.svcmi_amp_block_group_supported(40, 40) == 0
+    for v in variants:
+        assert ops.lib.svcmi_tune_set(b"amp_block_variant", v) == 0
+        try:
+            got = ops.amp_block_group(xd, blocks, filt, c=c)
+        finally:
+            ops.lib.svcmi_tune_set(b"amp_block_variant", 0)
+        for j in range(len(blocks)):
+            assert torch.equal(got[j], want[j]), (c, n, v, j, float((got[j] - want[j]).abs().max()))
+    return True
+
+
 def check_snake_post(ops, device, B=2, n=700):
     """Fused output layer (SnakeAlias -> conv_post 10 -> 1, k = 7, no bias -> tanh) vs oracle SnakeAlias + torch conv1d."""
     g = _g(4242 + n)

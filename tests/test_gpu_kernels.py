@@ -104,6 +104,12 @@ def test_snake_conv_group(ops, c, ld, n):
     K.check_snake_conv_group(ops, "cuda", c=c, ld=ld, B=1 if n > 1000 else 2, n=n)
 
 
+@pytest.mark.parametrize("c,ld,n,B", [(10, 12, 700, 2), (10, 12, 33, 2), (10, 12, 320000, 1), (20, 20, 600, 2), (20, 20, 1, 1), (20, 20, 160000, 1),
+                                      (10, 12, 40000, 4), (20, 20, 20000, 4)])
+def test_amp_block_group_equals_the_half_step_chain(ops, c, ld, n, B):
+    K.check_amp_block_group(ops, "cuda", c=c, ld=ld, B=B, n=n, variants=(0, 1, 2, 3, 4) if n < 100000 else (0, 2))
+
+
 @pytest.mark.parametrize("n", [5, 700, 320000])
 def test_snake_post(ops, n):
     K.check_snake_post(ops, "cuda", B=1 if n > 100000 else 2, n=n)

@@ -94,6 +94,11 @@ def test_snake_conv_group(ops, c, ld):
     K.check_snake_conv_group(ops, "cpu", c=c, ld=ld, B=2, n=150)
 
 
+@pytest.mark.parametrize("c,ld,n,variants,nblocks", [(10, 12, 700, (1, 3), 3), (10, 12, 40, (1,), 2), (20, 20, 600, (1, 4), 3), (20, 20, 1, (1,), 1)])
+def test_amp_block_group_equals_the_half_step_chain(ops, c, ld, n, variants, nblocks):
+    K.check_amp_block_group(ops, "cpu", c=c, ld=ld, B=2 if n < 100 else 1, n=n, variants=variants, nblocks=nblocks)
+
+
 @pytest.mark.parametrize("n", [5, 700])
 def test_snake_post(ops, n):
     K.check_snake_post(ops, "cpu", B=2, n=n)

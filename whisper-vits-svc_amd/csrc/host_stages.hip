@@ -18,19 +18,20 @@
 namespace {
 
 int g_amp_grouped = 1;     // tuning / test knob ("amp_grouped", 0 | 1): 0 forces the one-launch-per-block fallback of the generator stages
+int g_amp_block = 1;       // ("amp_block", 0 | 1): 1 = the narrow stages run each AMP block as ONE launch (svcmi_amp_block_group_f32), 0 = six half-step launches
 
 enum Op {
     OP_CONV_F32, OP_CONV_LP, OP_CONV_GROUP_F32, OP_CONV_GROUP_LP, OP_LAYERNORM, OP_SPLITK_LN, OP_ATTENTION, OP_SNAKE_ALIAS,
     OP_SNAKE_ALIAS_GROUP, OP_BLOCK_MEAN, OP_SNAKE_CONV, OP_SNAKE_CONV_GROUP, OP_UPSAMPLE_NOISE, OP_SNAKE_POST, OP_WN_GATE,
     OP_COUPLING_PRE, OP_COUPLING_POST, OP_EMBED_PITCH, OP_SAMPLE_PRIOR, OP_NCL_TO_NLC, OP_COPY2D, OP_PITCH_PREFIX, OP_PITCH_SOURCE,
-    OP_ATTENTION16, OP_COUNT
+    OP_ATTENTION16, OP_AMP_BLOCK_GROUP, OP_COUNT
 };
 const char* const OP_NAMES[OP_COUNT] = {
     "svcmi_conv_gemm_f32", "svcmi_conv_gemm_lp", "svcmi_conv_gemm_group_f32", "svcmi_conv_gemm_group_lp", "svcmi_layernorm_f32",
     "svcmi_splitk_layernorm_f32", "svcmi_attention_f32", "svcmi_snake_alias_f32", "svcmi_snake_alias_group_f32", "svcmi_block_mean_f32",
     "svcmi_snake_conv_f32", "svcmi_snake_conv_group_f32", "svcmi_upsample_noise_f32", "svcmi_snake_post_f32", "svcmi_wn_gate_f32",
     "svcmi_coupling_pre_f32", "svcmi_coupling_post_f32", "svcmi_embed_pitch_f32", "svcmi_sample_prior_f32", "svcmi_ncl_to_nlc_f32",
-    "svcmi_copy2d_f32", "svcmi_pitch_prefix_f64", "svcmi_pitch_source_f32", "svcmi_attention16"};
+    "svcmi_copy2d_f32", "svcmi_pitch_prefix_f64", "svcmi_pitch_source_f32", "svcmi_attention16", "svcmi_amp_block_group_f32"};
 
 // ------------------------------------------------------------------------------------------------ per-launch trace (bench.py)
 struct TraceRec {
@@ -608,6 +609,35 @@ bool amp_stage_grouped(Ctx& c, const svcmi_synth_model& m, const svcmi_gen_stage
     if (nf != 0 && nf != nall) return false;
     const bool fused = nf == nall;
     const int64_t n = (int64_t)B * L * cp, bs = L * cp;
+    if (fused && g_amp_block && svcmi_amp_block_group_supported(st.c, cp) && nd <= 3) {
+        // narrow stages: every AMP block as ONE launch with its tile resident in LDS over all 2 * nd half-steps (csrc/amp_block.hip);
+        // bit-identical to the half-step launches below
+        bool ok = true;
+        for (int j = 0; j < nb; ++j)
+            for (int q = 0; q < nd; ++q) ok = ok && st.blocks[j].dil[q] >= 1 && st.blocks[j].dil[q] <= 5;
+        if (ok) {
+            float* o[3];
+            for (int j = 0; j < nb; ++j) o[j] = c.ar.f(n);
+            svcmi_amp_block_desc d[3];
+            double fl = 0.0;
+            for (int j = 0; j < nb; ++j) {
+                const svcmi_amp_block& b = st.blocks[j];
+                memset(&d[j], 0, sizeof(d[j]));
+                d[j].x = y; d[j].y = o[j]; d[j].ksize = b.k; d[j].n_dil = nd;
+                for (int q = 0; q < nd; ++q) {
+                    d[j].w1[q] = b.c1[q].w; d[j].b1[q] = b.c1[q].bias; d[j].w2[q] = b.c2[q].w; d[j].b2[q] = b.c2[q].bias;
+                    d[j].a1_alpha[q] = b.a1_alpha[q]; d[j].a1_beta[q] = b.a1_beta[q]; d[j].a2_alpha[q] = b.a2_alpha[q]; d[j].a2_beta[q] = b.a2_beta[q];
+                    d[j].ldw1[q] = b.c1[q].ldw; d[j].ldw2[q] = b.c2[q].ldw; d[j].dil[q] = b.dil[q];
+                }
+                fl += 2.0 * 2 * nd * B * L * st.c * st.c * b.k;
+            }
+            run(c, OP_AMP_BLOCK_GROUP, fl, 4.0 * (1 + nb) * B * L * st.c,
+                [&] { return svcmi_amp_block_group_f32(d, nb, m.filt, B, (int32_t)L, st.c, cp, c.stream); });
+            const float* xc[3] = {o[0], o[1], o[2]};
+            run(c, OP_BLOCK_MEAN, 0.0, 4.0 * (nb + 1) * n, [&] { return svcmi_block_mean_f32(xc, nb, acc, n, c.stream); });
+            return true;
+        }
+    }
     float *xj[3], *t1[3], *t2[3];
     void* t1h[3] = {nullptr, nullptr, nullptr};
     for (int j = 0; j < nb; ++j) xj[j] = c.ar.f(n);
@@ -944,7 +974,7 @@ extern "C" const char* svcmi_trace_op_name(int32_t op) { return op >= 0 && (op &
 extern "C" int svcmi_struct_sizes(int64_t* out, int32_t cap) {
     const int64_t v[] = {(int64_t)sizeof(svcmi_weight), (int64_t)sizeof(svcmi_whisper_model), (int64_t)sizeof(svcmi_synth_model),
                          (int64_t)sizeof(svcmi_synth_io), (int64_t)sizeof(svcmi_trace_record), (int64_t)sizeof(svcmi_conv_desc),
-                         (int64_t)sizeof(svcmi_snake_conv_desc)};
+                         (int64_t)sizeof(svcmi_snake_conv_desc), (int64_t)sizeof(svcmi_amp_block_desc)};
     const int n = (int)(sizeof(v) / sizeof(v[0]));
     for (int i = 0; i < n && i < cap; ++i) out[i] = v[i];
     return n < cap ? n : cap;
@@ -952,6 +982,7 @@ extern "C" int svcmi_struct_sizes(int64_t* out, int32_t cap) {
 
 extern "C" int svcmi_host_tune_set(const char* name, int32_t value) {
     if (strcmp(name, "amp_grouped") == 0 && (value == 0 || value == 1)) { g_amp_grouped = value; return 0; }
+    if (strcmp(name, "amp_block") == 0 && (value == 0 || value == 1)) { g_amp_block = value; return 0; }
     return SVCMI_EINVAL;
 }
 

@@ -144,6 +144,13 @@ class SynthIO(Structure):
                 ("wave", c_void_p), ("z_p", c_void_p), ("z", c_void_p)]
 
 
+class AmpBlockDesc(Structure):
+    """svcmi_amp_block_desc"""
+    _fields_ = [("x", c_void_p), ("y", c_void_p), ("w1", c_void_p * 3), ("b1", c_void_p * 3), ("w2", c_void_p * 3), ("b2", c_void_p * 3),
+                ("a1_alpha", c_void_p * 3), ("a1_beta", c_void_p * 3), ("a2_alpha", c_void_p * 3), ("a2_beta", c_void_p * 3),
+                ("ldw1", c_int32 * 3), ("ldw2", c_int32 * 3), ("dil", c_int32 * 3), ("ksize", c_int32), ("n_dil", c_int32), ("reserved", c_int32)]
+
+
 class TraceRecord(Structure):
     _fields_ = [("op", c_int32), ("ms", c_float), ("flops", c_double), ("bytes", c_double)]
 
@@ -193,6 +200,8 @@ SIGNATURES = {
     "svcmi_snake_post_f32": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "svcmi_conv_gemm_group_f32": (c_int, [_P, _I, _P]),
     "svcmi_snake_conv_group_f32": (c_int, [_P, _I, _P, _I, _I, _I, _I, _P]),
+    "svcmi_amp_block_group_supported": (c_int, [_I, _I]),
+    "svcmi_amp_block_group_f32": (c_int, [_P, _I, _P, _I, _I, _I, _I, _P]),
     "svcmi_snake_alias_group_f32": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P]),
     "svcmi_block_mean_f32": (c_int, [_P, _I, _P, _L, _P]),
     "svcmi_source2wav_i16": (c_int, [_P, _P, _L, _P]),
@@ -237,7 +246,7 @@ def load_library(path=None):
     import ctypes as _c
     sizes = (c_int64 * 8)()
     n = lib.svcmi_struct_sizes(sizes, 8)
-    mine = [_c.sizeof(t) for t in (Weight, WhisperModel, SynthModel, SynthIO, TraceRecord, ConvDesc, SnakeConvDesc)]
+    mine = [_c.sizeof(t) for t in (Weight, WhisperModel, SynthModel, SynthIO, TraceRecord, ConvDesc, SnakeConvDesc, AmpBlockDesc)]
     if list(sizes[:n]) != mine:
         raise SvcmiError(f"struct layout mismatch: library {list(sizes[:n])} vs binding {mine}")
     return lib
