@@ -630,7 +630,8 @@ def main():
             gm = {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0}
             for name in names:
                 for k, v in agg.get(name, {}).items():
-                    gm[k] = gm.get(k, 0) + v
+                    if isinstance(v, (int, float)):
+                        gm[k] = gm.get(k, 0) + v
             part[key] = gm
         dom = "lp" if part["lp"]["flops"] > part["f32"]["flops"] else "f32"
         gm = part[dom]

@@ -1,0 +1,13 @@
+#!/bin/bash
+# Build an experimental variant of libsvcmi.so with extra -D flags: scripts/build_variant.sh <name> <flags...>  -> whisper-vits-svc_amd/svcmi/exp/libsvcmi_<name>.so
+# (SVCMI_LIB=<path> makes svcmi load it; A/B measurements on the GPU box without rebuilding there)
+set -e
+NAME=$1; shift
+cd "$(dirname "$0")/../whisper-vits-svc_amd"
+mkdir -p _obj/$NAME svcmi/exp
+for f in csrc/*.hip; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c $f -o _obj/$NAME/$(basename $f).o &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o svcmi/exp/libsvcmi_$NAME.so _obj/$NAME/*.o
+echo svcmi/exp/libsvcmi_$NAME.so

@@ -111,7 +111,7 @@ def main():
     what = sys.argv[1:] or ["gemm", "snake", "dec", "attn"]
     ops = Ops()
     if "ampblock" in what:
-        for B in (1, 4, 16):
+        for B in ((1, 16) if "quick" in what else (1, 4, 16)):
             ampblock(ops, 10, 12, 320000, B)
             ampblock(ops, 20, 20, 160000, B)
     if "gemm" in what:

@@ -40,6 +40,9 @@ static inline svcmi_f32x2 svcmi_fma2(svcmi_f32x2 a, svcmi_f32x2 b, svcmi_f32x2 c
 static inline svcmi_f32x2 svcmi_splat2(float v) { return svcmi_f32x2{v, v}; }
 static inline float svcmi_sgpr_const(float v) { return v; }
 static inline float svcmi_exp2(float x) { return exp2f(x); }
+static inline svcmi_f32x4 svcmi_load_uniform4(const float* p) { svcmi_f32x4 v; memcpy(&v, p, 16); return v; }
+static inline float svcmi_load_uniform1(const float* p) { return *p; }
+static inline const float* svcmi_opaque_uniform(const float* p) { return p; }
 
 typedef void* hipStream_t;
 
@@ -214,6 +217,7 @@ static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((un
 #define SVCMI_LAST_ERROR() (emu::g_last_error)
 #define SVCMI_UNIFORM(x) (x)
 #define SVCMI_SCHED_GROUP(mask, n) ((void)0)
+#define SVCMI_SCHED_BARRIER() ((void)0)
 #define SVCMI_RELEASE_AGENT() ((void)0)
 #define SVCMI_ACQUIRE_AGENT() ((void)0)
 static inline int svcmi_ticket(int* counter) { return (*counter)++; }   // blocks run one after another in the emulator

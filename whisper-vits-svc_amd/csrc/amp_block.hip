@@ -27,7 +27,7 @@
 
 namespace {
 
-constexpr int RT = 8;        // SnakeAlias outputs per work item (the half-step kernels' value: same recomputation pattern)
+constexpr int RT = 10;       // SnakeAlias outputs per work item: with one thread per tile row, (rows x channels) / RT items are 1 (10 channels) or 2 (20) full rounds of the workgroup
 constexpr int CO = 10;       // output channels per thread
 constexpr int GUARD = 28;    // rows before / after each LDS tile that out-of-range convolution taps of rows nobody uses may touch (>= 5 * 5, multiple of 4)
 constexpr int NBLK = 3;
@@ -93,7 +93,7 @@ __device__ __forceinline__ void conv_rows(const float* S, const float* w, const 
                                           const int (&row)[TT], float (&acc)[TT][CO]) {
 #pragma unroll
     for (int c = 0; c < CO; ++c) {
-        const float bv = (co0 + c < CR && bias) ? bias[co0 + c] : 0.f;
+        const float bv = (co0 + c < CR && bias) ? svcmi_load_uniform1(bias + co0 + c) : 0.f;
 #pragma unroll
         for (int j = 0; j < TT; ++j) acc[j][c] = bv;
     }
@@ -107,19 +107,25 @@ __device__ __forceinline__ void conv_rows(const float* S, const float* w, const 
             float4 xin[TT];
 #pragma unroll
             for (int j = 0; j < TT; ++j) xin[j] = *reinterpret_cast<const float4*>(S + row[j] * LS + off + 4 * c4);
+            // the quad's base address made opaque: knowing that the quads of a weight row are contiguous, the compiler merges them into
+            // s_load_dwordx16 per output channel (160-200 SGPRs per tap) and spills through v_writelane / v_readlane
+            const float* wq = svcmi_opaque_uniform(wt + 4 * c4);
 #pragma unroll
             for (int c = 0; c < CO; ++c) {
                 if (co0 + c < CR) {                    // wave-uniform
-                    const float4 wv = *reinterpret_cast<const float4*>(wt + (long long)c * ldw + 4 * c4);   // uniform address: scalar load
+                    const svcmi_f32x4 wv = svcmi_load_uniform4(wq + (long long)c * ldw);          // uniform address, read-only: scalar load
 #pragma unroll
                     for (int j = 0; j < TT; ++j) {
-                        acc[j][c] = fmaf(wv.x, xin[j].x, acc[j][c]);
-                        if (4 * c4 + 1 < CR) acc[j][c] = fmaf(wv.y, xin[j].y, acc[j][c]);
-                        if (4 * c4 + 2 < CR) acc[j][c] = fmaf(wv.z, xin[j].z, acc[j][c]);
-                        if (4 * c4 + 3 < CR) acc[j][c] = fmaf(wv.w, xin[j].w, acc[j][c]);
+                        acc[j][c] = fmaf(wv[0], xin[j].x, acc[j][c]);
+                        if (4 * c4 + 1 < CR) acc[j][c] = fmaf(wv[1], xin[j].y, acc[j][c]);
+                        if (4 * c4 + 2 < CR) acc[j][c] = fmaf(wv[2], xin[j].z, acc[j][c]);
+                        if (4 * c4 + 3 < CR) acc[j][c] = fmaf(wv[3], xin[j].w, acc[j][c]);
                     }
                 }
             }
+            // one input-channel quad at a time: 10 weight quads = 40 SGPRs in flight.  Left alone, the scheduler hoists the scalar loads of
+            // a whole tap (30 / 50 quads = 120 / 200 SGPRs) above the FMAs and spills them through v_writelane / v_readlane
+            SVCMI_SCHED_BARRIER();
         }
     }
 }
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(64 * NW) void amp_block_kernel(StageArgs a) {
         h += 5;
         snake_phase<CR, LS, NT>(A, S, p.a2a[q], p.a2b[q], f, n, t_lo, h, R - h, tid);
         __syncthreads();
-        // A = X = conv2(S) + X, dilation 1; the last iteration goes to HBM instead
+        // A = X = conv2(S) + X, dilation 1 (the last iteration's X is the block output: stored after the loop)
         h += hk;
         {
             const bool live = 64 * tsub + 64 > h && 64 * tsub < R - h;
@@ -217,22 +223,27 @@ __global__ __launch_bounds__(64 * NW) void amp_block_kernel(StageArgs a) {
 #pragma unroll
                         for (int c = 0; c < CO; c += 2)
                             if (co0 + c < CR) *reinterpret_cast<float2*>(A + row[j] * LS + co0 + c) = make_float2(X[j][c], X[j][c + 1]);
-                    } else {
-                        const int t = t_lo + row[j];
-                        if (row[j] >= H && row[j] < R - H && t < n) {
-                            float* yr = p.y + ((long long)b * n + t) * ld + co0;
-#pragma unroll
-                            for (int c = 0; c < CO; c += 2) *reinterpret_cast<float2*>(yr + c) = make_float2(X[j][c], X[j][c + 1]);
-                            if (g == G - 1) {              // pad channels [G*CO, CP) stay exactly zero
-#pragma unroll
-                                for (int c = G * CO; c < CP; c += 2) *reinterpret_cast<float2*>(p.y + ((long long)b * n + t) * ld + c) = make_float2(0.f, 0.f);
-                            }
-                        }
                     }
                 }
             }
         }
         if (q + 1 < p.n_dil) __syncthreads();
+    }
+    // ---- block output: the rows [H, R - H) of the tile.  The ONLY global store of the kernel, and it comes after every load: inside the
+    // loop it would make the compiler treat the (uniform) weight loads as clobberable and fetch them through the vector memory path
+    // (global_load + vmcnt(0) per tap: measured 2x slower than the half-step kernels) instead of the scalar cache.
+#pragma unroll
+    for (int j = 0; j < TT; ++j) {
+        const int t = t_lo + row[j];
+        if (row[j] >= H && row[j] < R - H && t < n) {
+            float* yr = p.y + ((long long)b * n + t) * ld + co0;
+#pragma unroll
+            for (int c = 0; c < CO; c += 2) *reinterpret_cast<float2*>(yr + c) = make_float2(X[j][c], X[j][c + 1]);
+            if (g == G - 1) {              // pad channels [G*CO, CP) stay exactly zero
+#pragma unroll
+                for (int c = G * CO; c < CP; c += 2) *reinterpret_cast<float2*>(p.y + ((long long)b * n + t) * ld + c) = make_float2(0.f, 0.f);
+            }
+        }
     }
 }
 

@@ -18,7 +18,11 @@
 namespace {
 
 int g_amp_grouped = 1;     // tuning / test knob ("amp_grouped", 0 | 1): 0 forces the one-launch-per-block fallback of the generator stages
-int g_amp_block = 1;       // ("amp_block", 0 | 1): 1 = the narrow stages run each AMP block as ONE launch (svcmi_amp_block_group_f32), 0 = six half-step launches
+// ("amp_block", 0 | 1): 1 = the narrow stages run each AMP block as ONE launch (svcmi_amp_block_group_f32, csrc/amp_block.hip), 0 = six
+// half-step launches per block.  OFF: measured on MI355X (profiles/r04c_ampblock_variants.log) the fused block is 0.67-0.92x the speed of
+// the half-step chain in every tile geometry (10 channels: 445 vs 411 us at B = 1, 5.96 vs 5.13 ms at B = 16; 20 channels: 659 vs 552 us,
+// 9.3 vs 6.2 ms) -- bit-identical, kept as a tested alternative
+int g_amp_block = 0;
 
 enum Op {
     OP_CONV_F32, OP_CONV_LP, OP_CONV_GROUP_F32, OP_CONV_GROUP_LP, OP_LAYERNORM, OP_SPLITK_LN, OP_ATTENTION, OP_SNAKE_ALIAS,

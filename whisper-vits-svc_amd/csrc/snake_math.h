@@ -68,6 +68,55 @@ __device__ __forceinline__ svcmi_f32x2 sin_sq2(svcmi_f32x2 x, const SnakeConsts&
 __device__ __forceinline__ svcmi_f32x2 snake_fn2(svcmi_f32x2 y, float a, float inv_b, const SnakeConsts& k) {
     return svcmi_fma2(svcmi_splat2(inv_b), sin_sq2(y * svcmi_splat2(a), k), y);
 }
+// sin_sq2 without the large-argument test: for the callers that test a whole work item at once (snake_fn2_all)
+__device__ __forceinline__ svcmi_f32x2 sin_sq2_nocheck(svcmi_f32x2 x, const SnakeConsts& k) {
+    const svcmi_f32x2 q = x * svcmi_splat2(k.inv_pi);
+    const svcmi_f32x2 n = {rintf(q[0]), rintf(q[1])};
+    svcmi_f32x2 r = svcmi_fma2(-n, svcmi_splat2(k.pi_hi), x);
+    r = svcmi_fma2(-n, svcmi_splat2(k.pi_lo), r);
+    const svcmi_f32x2 u = r * r;
+    svcmi_f32x2 p = svcmi_splat2(k.c0);
+    p = svcmi_fma2(p, u, svcmi_splat2(k.c1));
+    p = svcmi_fma2(p, u, svcmi_splat2(k.c2));
+    p = svcmi_fma2(p, u, svcmi_splat2(k.c3));
+    p = svcmi_fma2(p, u, svcmi_splat2(k.c4));
+    const svcmi_f32x2 sn = svcmi_fma2(r * u, p, r);
+    return sn * sn;
+}
+// s[m] = snake_fn2(y[m]) for the N pairs of a work item, with ONE large-argument test for all of them (round 4).  With the test inside
+// every pair (snake_fn2) each pair was its own basic block: a dependent chain of ~20 packed operations behind an exec-mask save / branch
+// / restore, 13 of them per work item, which the scheduler cannot interleave.  Here the N chains are straight-line code (independent:
+// the scheduler overlaps them) and the rare fix-up pass replaces only the components that needed libm.  Same value per component as
+// snake_fn2: (|x| <= 1e5) the polynomial path, else inv_b * sin^2_libm(x) + y.
+#ifndef SVCMI_SNAKE_CHUNK
+#define SVCMI_SNAKE_CHUNK 0          // build-time experiment knob: 0 = all chains of an item interleavable, n = at most n at a time, -1 = the round-3 per-pair form
+#endif
+template <int N>
+__device__ __forceinline__ void snake_fn2_all(const svcmi_f32x2 (&y)[N], float a, float inv_b, const SnakeConsts& k, svcmi_f32x2 (&s)[N]) {
+#if SVCMI_SNAKE_CHUNK < 0
+#pragma unroll
+    for (int m = 0; m < N; ++m) s[m] = snake_fn2(y[m], a, inv_b, k);
+    return;
+#endif
+    float mx = 0.f;
+#pragma unroll
+    for (int m = 0; m < N; ++m) {
+        const svcmi_f32x2 x = y[m] * svcmi_splat2(a);
+        mx = fmaxf(mx, fmaxf(fabsf(x[0]), fabsf(x[1])));
+        s[m] = svcmi_fma2(svcmi_splat2(inv_b), sin_sq2_nocheck(x, k), y[m]);
+#if SVCMI_SNAKE_CHUNK > 0
+        if ((m + 1) % SVCMI_SNAKE_CHUNK == 0) SVCMI_SCHED_BARRIER();      // bounds the registers the interleaved chains need
+#endif
+    }
+    if (__builtin_expect(mx > 1.0e5f, 0)) {               // never taken for audio-scale activations
+#pragma unroll
+        for (int m = 0; m < N; ++m) {
+            const svcmi_f32x2 x = y[m] * svcmi_splat2(a);
+            if (fmaxf(fabsf(x[0]), fabsf(x[1])) > 1.0e5f)  // (the pair as a whole, as sin_sq2 decides it)
+                s[m] = svcmi_fma2(svcmi_splat2(inv_b), svcmi_f32x2{sin_sq_huge(x[0]), sin_sq_huge(x[1])}, y[m]);
+        }
+    }
+}
 
 // s_up[u] for one up-sampled index 0 <= u < 2n straight from global memory; only the runs that touch a sequence end evaluate
 // it (once each), for the replicate padding of the low-pass input (filter.py:86-95).
@@ -90,14 +139,15 @@ __device__ __forceinline__ void snake_run(const float (&xw)[RT + 10], const floa
 #pragma unroll
     for (int j = 0; j < 6; ++j) f2[j] = svcmi_f32x2{f[2 * j], f[2 * j + 1]};
     // s2[m] = (s_up[2*t0 - 5 + 2m], s_up[2*t0 - 5 + 2m + 1]): polyphase up-sampler + SnakeBeta, each value computed once
-    svcmi_f32x2 s2[RT + 5];
+    svcmi_f32x2 s2[RT + 5], y2[RT + 5];
 #pragma unroll
     for (int m = 0; m < RT + 5; ++m) {
         svcmi_f32x2 y = svcmi_splat2(0.f);          // (odd phase: even taps, even phase: odd taps)
 #pragma unroll
         for (int j = 0; j < 6; ++j) y = svcmi_fma2(f2[j], svcmi_splat2(xw[5 - j + m]), y);
-        s2[m] = snake_fn2(y * svcmi_splat2(k.two), a, inv_b, k);
+        y2[m] = y * svcmi_splat2(k.two);
     }
+    snake_fn2_all<RT + 5>(y2, a, inv_b, k, s2);
     const int u0 = 2 * t0 - 5;
     if (u0 < 0 || u0 + 2 * RT + 9 > 2 * n - 1) {      // replicate padding of the low-pass input
         const float s_first = snake_s_at(xc, ld, n, 0, f, a, inv_b);
@@ -131,13 +181,15 @@ __device__ __forceinline__ void snake_pairs(const float (&xw)[NP + 5], const flo
     svcmi_f32x2 f2[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) f2[j] = svcmi_f32x2{f[2 * j], f[2 * j + 1]};
+    svcmi_f32x2 y2[NP];
 #pragma unroll
     for (int m = 0; m < NP; ++m) {
         svcmi_f32x2 y = svcmi_splat2(0.f);
 #pragma unroll
         for (int j = 0; j < 6; ++j) y = svcmi_fma2(f2[j], svcmi_splat2(xw[5 - j + m]), y);
-        s2[m] = snake_fn2(y * svcmi_splat2(k.two), a, inv_b, k);
+        y2[m] = y * svcmi_splat2(k.two);
     }
+    snake_fn2_all<NP>(y2, a, inv_b, k, s2);
     const int u0 = 2 * tq0 - 5;
     if (u0 < 0 || u0 + 2 * NP - 1 > 2 * n - 1) {      // replicate padding of the low-pass input (filter.py:86-95)
         const float s_first = snake_s_at(xc, ld, n, 0, f, a, inv_b);

@@ -28,6 +28,23 @@ __device__ __forceinline__ float svcmi_sgpr_const(float v) {
     return __builtin_bit_cast(float, i);
 }
 
+// 16 bytes from READ-ONLY memory at a wave-uniform address as a scalar load (s_load_dwordx4 -> SGPR operands of the FMAs that
+// follow).  A plain `*reinterpret_cast<const float4*>(p)` gets the scalar path only while the compiler can prove that nothing in the
+// kernel clobbers it (MemorySSA walk with a visit limit): in a kernel with a phase loop and hundreds of LDS stores the proof
+// times out and every weight fetch becomes global_load + s_waitcnt vmcnt(0) (measured: the fused AMP block 2x slower).  The
+// constant address space states the invariant instead.  Only for memory no kernel on the device writes while this one runs (weights).
+__device__ __forceinline__ svcmi_f32x4 svcmi_load_uniform4(const float* p) {
+    return *(const __attribute__((address_space(4))) svcmi_f32x4*)(p);
+}
+// a wave-uniform pointer the optimiser knows nothing about any more (stays in an SGPR pair)
+__device__ __forceinline__ const float* svcmi_opaque_uniform(const float* p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
+__device__ __forceinline__ float svcmi_load_uniform1(const float* p) { return *(const __attribute__((address_space(4))) float*)(p); }
+
+#define SVCMI_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)      // nothing is scheduled across this point
+
 // 2^x as ONE transcendental instruction (v_exp_f32, 1 ulp; inputs below -126 give 0).  libm's expf is ~15 instructions; a softmax
 // that keeps its scores in the log2 domain (scores * log2 e folded into the scale) needs nothing more.
 __device__ __forceinline__ float svcmi_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
