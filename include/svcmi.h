@@ -506,8 +506,11 @@ int svcmi_whisper_encoder_fwd(const svcmi_whisper_model* m, const float* mel, co
 /* layer classes of the per-layer mixed-precision policy: prior encoder (enc_p: pre / hub / attention + FFN layers / proj, and its attention
  * kernel), flow (pre / in / res_skip / post of every coupling layer), the generator's trunk (conv_pre + every ups[i]), and the AMP-block
  * convolutions of generator stage i (SVCMI_CLASS_AMP0 + i; stages on the fused vector-ALU kernels compute in fp32 whatever this says) */
-enum svcmi_prec_class { SVCMI_CLASS_ENC = 0, SVCMI_CLASS_FLOW = 1, SVCMI_CLASS_UPS = 2, SVCMI_CLASS_AMP0 = 3 };
-#define SVCMI_PREC_CLASSES 8
+enum svcmi_prec_class { SVCMI_CLASS_ENC = 0, SVCMI_CLASS_FLOW = 1, SVCMI_CLASS_UPS = 2, SVCMI_CLASS_AMP0 = 3 /* .. AMP0 + 4 */,
+                        /* the prior encoder's ATTENTION kernel: SVCMI_PREC_BF16 / _F16 = both products on the 16-bit matrix cores
+                         * (svcmi_attention16, from a 16-bit copy of the QKV projection's output), anything else = the fp32 kernel */
+                        SVCMI_CLASS_ENC_ATTN = 8 };
+#define SVCMI_PREC_CLASSES 12
 typedef struct svcmi_enc_layer {                    /* attentions.Encoder layer i, vits/attentions.py:36-72 */
     svcmi_weight qkv, o, f1, f2;                    /* conv_q|k|v fused, conv_o, FFN conv_1 / conv_2 */
     const float *rel_k, *rel_v;                     /* emb_rel_k / emb_rel_v [2*window+1][H/heads] */

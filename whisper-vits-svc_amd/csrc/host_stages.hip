@@ -120,6 +120,7 @@ struct CV {
     const void* x16 = nullptr;      // the same rows as `x` as a 16-bit tensor (same ldx / x_bs in elements), written by the producer: a
                                     // launch that goes to the bf16 / f16 kernel then takes the _A16 instantiation (no in-register rounding)
     void* y16 = nullptr;            // 16-bit copy of the output for the NEXT launch (written only in the bf16 / f16 modes)
+    int y16_fmt = -1;               // format of that copy: -1 = the launch's own mode, else SVCMI_PREC_BF16 / _F16 whatever the GEMM runs in
 };
 
 // Per-layer mixed precision (SVCMI_PREC_MIXED): every section of the synthesizer sets c.prec to its class's mode before it launches.
@@ -175,9 +176,10 @@ int conv_desc(const Ctx& c, const CV& v, svcmi_conv_desc& d, double& flops, doub
     } else {
         d.split_k = 1;
     }
-    if (v.y16 && act16(c.prec) && !partials && d.split_k == 1) {
-        d.y16 = v.y16; d.y16_bstride = w16(c.prec, 1) * d.y_bstride; d.ldy16 = w16(c.prec, d.ldy); d.y16_format = c.prec;
-        bytes += 2.0 * v.B * t_out * w16(c.prec, N);
+    const int yfmt = v.y16_fmt >= 0 ? v.y16_fmt : c.prec;
+    if (v.y16 && act16(yfmt) && !partials && d.split_k == 1) {
+        d.y16 = v.y16; d.y16_bstride = w16(yfmt, 1) * d.y_bstride; d.ldy16 = w16(yfmt, d.ldy); d.y16_format = yfmt;
+        bytes += 2.0 * v.B * t_out * w16(yfmt, N);
     }
     if (!lp) return SVCMI_PREC_F32;
     d.w = static_cast<const float*>(v.w->w16);
@@ -281,11 +283,12 @@ void attention(Ctx& c, const float* qkv, float* o, int B, int T, int heads, int 
 
 // band-free attention on the 16-bit matrix cores from the QKV projection's 16-bit output copy (bf16 / f16 modes)
 void attention16(Ctx& c, const void* qkv16, float* o, void* o16, int B, int T, int heads, int C, float scale, const int32_t* lengths,
-                 const float* rel_k = nullptr, const float* rel_v = nullptr, int window = 0) {
+                 const float* rel_k = nullptr, const float* rel_v = nullptr, int window = 0, int fmt = -1) {
     const unsigned short* q = static_cast<const unsigned short*>(qkv16);
+    const int f = fmt >= 0 ? fmt : c.prec;
     run(c, OP_ATTENTION16, 4.0 * B * T * (double)T * C, 10.0 * B * T * C, [&] {
         return svcmi_attention16(q, q + C, q + 2 * C, 3 * C, (int64_t)T * 3 * C, o, C, (int64_t)T * C, o16, C, (int64_t)T * C, B, T, heads, C / heads, scale,
-                                 rel_k, rel_v, window, lengths, c.prec, c.stream);
+                                 rel_k, rel_v, window, lengths, f, c.stream);
     });
 }
 
@@ -441,7 +444,10 @@ void prior_fwd(Ctx& c, const svcmi_synth_model& m, const svcmi_synth_io& io, flo
     // the 16-bit matrix cores from the QKV projection's 16-bit output copy (head widths the kernel has: 32 and 96)
     const int hd = H / m.n_heads;
     const bool a16 = mode16(c.prec) && H % 8 == 0 && F % 8 == 0;
-    const bool att16 = a16 && (hd == 96 || hd == 32) && m.enc_window <= 4;
+    // the attention kernel's own mode: the encoder's in a single-mode model; under SVCMI_PREC_MIXED its own class, so that a split-bf16
+    // encoder (fp32-class GEMMs) can still run QK^T / PV on the 16-bit matrix cores from a 16-bit copy of the QKV output
+    const int att_prec = m.precision == SVCMI_PREC_MIXED ? class_prec(m, SVCMI_CLASS_ENC_ATTN) : c.prec;
+    const bool att16 = mode16(att_prec) && H % 8 == 0 && (hd == 96 || hd == 32) && m.enc_window <= 4;
     void* x16 = a16 ? c.ar.take((int64_t)B * T * H * 2) : nullptr;
     void* at16 = a16 ? c.ar.take((int64_t)B * T * H * 2) : nullptr;
     void* hf16 = a16 ? c.ar.take((int64_t)B * T * F * 2) : nullptr;
@@ -452,12 +458,12 @@ void prior_fwd(Ctx& c, const svcmi_synth_model& m, const svcmi_synth_io& io, flo
         CV v; v.B = B; v.t_in = T; v.c_in = v.ldx = H; v.x_bs = (int64_t)T * H;
         {
             CV q = v; q.x = x; q.x16 = i > 0 ? x16 : nullptr; q.w = &L.qkv; q.y = qkv; q.y_bs = (int64_t)T * 3 * H; q.ldy = 3 * H;
-            if (att16) { q.y16 = qkv16; q.split_k = 1; }
+            if (att16) { q.y16 = qkv16; q.y16_fmt = att_prec; q.split_k = 1; }
             conv(c, q);
         }
-        if (att16) attention16(c, qkv16, att, at16, B, T, m.n_heads, H, scale, io.lengths, L.rel_k, L.rel_v, m.enc_window);
+        if (att16) attention16(c, qkv16, att, att_prec == c.prec ? at16 : nullptr, B, T, m.n_heads, H, scale, io.lengths, L.rel_k, L.rel_v, m.enc_window, att_prec);
         else attention(c, qkv, att, B, T, m.n_heads, H, scale, L.rel_k, L.rel_v, m.enc_window, io.lengths, at16);
-        { CV o = v; o.x = att; o.x16 = at16; o.w = &L.o; o.y = yo; o.y_bs = (int64_t)T * H; o.ldy = H; conv(c, o); }
+        { CV o = v; o.x = att; o.x16 = (att16 && att_prec != c.prec) ? nullptr : at16; o.w = &L.o; o.y = yo; o.y_bs = (int64_t)T * H; o.ldy = H; conv(c, o); }
         layernorm(c, x, yo, L.g1, L.b1, x2, B, T, H, H, H, H, 0, x16);
         {
             CV f = v; f.x = x2; f.x16 = x16; f.w = &L.f1; f.ksize = kf; f.pad = pl; f.act = SVCMI_ACT_RELU; f.lengths = io.lengths; f.mask_in = f.mask_out = true;
