@@ -38,11 +38,14 @@ typedef float svcmi_f32x4 __attribute__((vector_size(16)));
 typedef float svcmi_f32x2 __attribute__((vector_size(8)));
 static inline svcmi_f32x2 svcmi_fma2(svcmi_f32x2 a, svcmi_f32x2 b, svcmi_f32x2 c) { return svcmi_f32x2{fmaf(a[0], b[0], c[0]), fmaf(a[1], b[1], c[1])}; }
 static inline svcmi_f32x2 svcmi_splat2(float v) { return svcmi_f32x2{v, v}; }
+static inline svcmi_f32x2 svcmi_splat_lo(svcmi_f32x2 p) { return svcmi_f32x2{p[0], p[0]}; }
+static inline svcmi_f32x2 svcmi_splat_hi(svcmi_f32x2 p) { return svcmi_f32x2{p[1], p[1]}; }
 static inline float svcmi_sgpr_const(float v) { return v; }
 static inline float svcmi_exp2(float x) { return exp2f(x); }
 static inline svcmi_f32x4 svcmi_load_uniform4(const float* p) { svcmi_f32x4 v; memcpy(&v, p, 16); return v; }
 static inline float svcmi_load_uniform1(const float* p) { return *p; }
 static inline const float* svcmi_opaque_uniform(const float* p) { return p; }
+static inline float svcmi_load_saddr(const float* base, unsigned byte_off) { return *(const float*)((const char*)base + byte_off); }
 
 typedef void* hipStream_t;
 

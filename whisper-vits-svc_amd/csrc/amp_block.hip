@@ -71,9 +71,9 @@ __device__ __forceinline__ void snake_phase(const float* A, float* S, const floa
             const float a = expf(alpha_log[ch]);
             const float inv_b = 1.0f / (expf(beta_log[ch]) + 1e-9f);
             const float* xc = At + ch;
-            float xw[RT + 10];
+            SnakeWindow<RT + 10> xw;
 #pragma unroll
-            for (int i = 0; i < RT + 10; ++i) xw[i] = xc[clampi(t0 - 5 + i, 0, n - 1) * LS];
+            for (int i = 0; i < RT + 10; ++i) xw.set(i, xc[clampi(t0 - 5 + i, 0, n - 1) * LS]);
             snake_run<RT>(xw, f, a, inv_b, xc, LS, n, t0, out);
 #pragma unroll
             for (int r = 0; r < RT; ++r) {

@@ -59,9 +59,9 @@ __device__ __forceinline__ void snake_tile(float* S, const float* xb, const floa
                 const float a = expf(p.alpha_log[ch]);
                 const float inv_b = 1.0f / (expf(p.beta_log[ch]) + 1e-9f);
                 const float* xc = xb + ch;
-                float xw[RT + 10];
+                SnakeWindow<RT + 10> xw;
 #pragma unroll
-                for (int i = 0; i < RT + 10; ++i) xw[i] = xc[(long long)clampi(t0 - 5 + i, 0, n - 1) * ld];
+                for (int i = 0; i < RT + 10; ++i) xw.set(i, xc[(long long)clampi(t0 - 5 + i, 0, n - 1) * ld]);
                 snake_run<RT>(xw, f, a, inv_b, xc, ld, n, t0, out);
 #pragma unroll
                 for (int r = 0; r < RT; ++r) {
@@ -108,9 +108,9 @@ __device__ __forceinline__ void snake_tile_u(float* smem, const float* xb, const
             const float a = expf(alpha_log[ch]);
             const float inv_b = 1.0f / (expf(beta_log[ch]) + 1e-9f);
             const float* xc = xb + ch;
-            float xw[RT + 5];
+            SnakeWindow<RT + 5> xw;
 #pragma unroll
-            for (int i = 0; i < RT + 5; ++i) xw[i] = xc[(long long)clampi(tq0 - 5 + i, 0, n - 1) * ld];
+            for (int i = 0; i < RT + 5; ++i) xw.set(i, xc[(long long)clampi(tq0 - 5 + i, 0, n - 1) * ld]);
             snake_pairs<RT>(xw, f, a, inv_b, xc, ld, n, tq0, s2);
         }
 #pragma unroll
@@ -460,7 +460,9 @@ static void launch_amp_group(const AmpGroupArgs& g, int count, int batch, int le
         }
     }
     if constexpr (TT == 2) {
-        if (g_amp_u > 0 && c == 20) {
+        // 20 channels: the U variant's 52 KB of LDS per block cost more occupancy than its saved instructions buy for ONE clip (89.9 vs
+        // 87.7 us), but from ~4 clips per launch on it wins (B = 4: 294.6 vs 335.9 us at d = 1, 287.9 vs 300.3 at d = 5: profiles/r04f_*)
+        if ((g_amp_u > 0 || (g_amp_u == 0 && (long long)batch * len >= 500000)) && c == 20) {
             constexpr int TB = AmpTile<20, 2, 2, 3>::TB;
             SVCMI_LAUNCH((snake_conv_group_u_kernel<20, 20, 2, 2>), dim3((unsigned)((len + TB - 1) / TB), (unsigned)batch, (unsigned)count),
                          dim3(TPB), 0, stream, g);

@@ -46,9 +46,19 @@ __global__ __launch_bounds__(TPB) void snake_alias_kernel(SnakeArgs p) {
 #pragma unroll
     for (int k = 0; k < 12; ++k) f[k] = filt[k];
     // x window with replicate padding (resample.py:25-27): xw[i] = x[clamp(t0 - 5 + i)]
-    float xw[RT + 10];
+    SnakeWindow<RT + 10> xw;
+    if (t0 >= 5 && t0 + RT + 4 < n) {
+        // interior run (all but the first and last of a sequence): no clamps, and one 32-bit offset per lane from the wave-uniform batch
+        // base, advanced by ld per row -- the general form costs a clamp + a 64-bit multiply-add + a 64-bit add per load (ISA: 90 of the
+        // ~520 vector instructions of a work item were address arithmetic)
+        const float* xu = svcmi_opaque_uniform(p.x[gi] + (long long)b * n * ld);
+        const unsigned o = 4u * (unsigned)((t0 - 5) * ld + ch), step = 4u * (unsigned)ld;       // BYTE offsets < 2^32: tensors are < 2^29 bytes
 #pragma unroll
-    for (int i = 0; i < RT + 10; ++i) xw[i] = xc[(long long)clampi(t0 - 5 + i, 0, n - 1) * ld];
+        for (int i = 0; i < RT + 10; ++i) xw.set(i, svcmi_load_saddr(xu, o + (unsigned)i * step));
+    } else {
+#pragma unroll
+        for (int i = 0; i < RT + 10; ++i) xw.set(i, xc[(long long)clampi(t0 - 5 + i, 0, n - 1) * ld]);
+    }
     float out[RT];
     snake_run<RT>(xw, f, a, inv_b, xc, ld, n, t0, out);
 #pragma unroll

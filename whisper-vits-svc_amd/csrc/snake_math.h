@@ -118,6 +118,23 @@ __device__ __forceinline__ void snake_fn2_all(const svcmi_f32x2 (&y)[N], float a
     }
 }
 
+// The x window of a work item as ALIGNED register pairs: element i lives in half (i & 1) of pair (i >> 1).  The up-sampler multiplies a
+// tap pair (f[2j], f[2j+1]) by the same x value in both halves; with the value in a half of an aligned pair the broadcast is an
+// operand-select modifier of v_pk_fma_f32 (op_sel), with the value in a lone register the compiler spends a v_mov per tap to build the
+// pair (ISA of round 3: 5 of the ~29 VALU instructions per up-sampled pair).
+template <int N>
+struct SnakeWindow {
+    svcmi_f32x2 p[(N + 1) / 2];
+    __device__ __forceinline__ void set(int i, float v) { p[i >> 1][i & 1] = v; }
+    __device__ __forceinline__ svcmi_f32x2 splat(int i) const { return (i & 1) ? svcmi_splat_hi(p[i >> 1]) : svcmi_splat_lo(p[i >> 1]); }
+};
+// taps of the 2x up-sampler with its gain folded in: (2 f[2j], 2 f[2j+1]).  Scaling by two commutes with every rounding of the fma
+// chain (no overflow / underflow at audio scale), so sum_j (2 f) x == 2 * sum_j f x bit for bit -- one packed multiply less per pair.
+__device__ __forceinline__ void snake_up_taps(const float (&f)[12], svcmi_f32x2 (&g2)[6]) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) g2[j] = svcmi_f32x2{2.f * f[2 * j], 2.f * f[2 * j + 1]};
+}
+
 // s_up[u] for one up-sampled index 0 <= u < 2n straight from global memory; only the runs that touch a sequence end evaluate
 // it (once each), for the replicate padding of the low-pass input (filter.py:86-95).
 __device__ __forceinline__ float snake_s_at(const float* xc, int ld, int n, int u, const float* f, float a, float inv_b) {
@@ -132,20 +149,21 @@ __device__ __forceinline__ float snake_s_at(const float* xc, int ld, int n, int 
 // up-sampler, resample.py:25-27); f = the 12 filter taps; xc / ld address the channel's column for the two end-of-sequence
 // values.  Outputs for t outside [0, n) are meaningless (callers mask them).
 template <int RT>
-__device__ __forceinline__ void snake_run(const float (&xw)[RT + 10], const float (&f)[12], float a, float inv_b,
+__device__ __forceinline__ void snake_run(const SnakeWindow<RT + 10>& xw, const float (&f)[12], float a, float inv_b,
                                           const float* xc, int ld, int n, int t0, float (&out)[RT]) {
     const SnakeConsts k = snake_consts();
-    svcmi_f32x2 f2[6];
+    svcmi_f32x2 f2[6], g2[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) f2[j] = svcmi_f32x2{f[2 * j], f[2 * j + 1]};
+    snake_up_taps(f, g2);
     // s2[m] = (s_up[2*t0 - 5 + 2m], s_up[2*t0 - 5 + 2m + 1]): polyphase up-sampler + SnakeBeta, each value computed once
     svcmi_f32x2 s2[RT + 5], y2[RT + 5];
 #pragma unroll
     for (int m = 0; m < RT + 5; ++m) {
         svcmi_f32x2 y = svcmi_splat2(0.f);          // (odd phase: even taps, even phase: odd taps)
 #pragma unroll
-        for (int j = 0; j < 6; ++j) y = svcmi_fma2(f2[j], svcmi_splat2(xw[5 - j + m]), y);
-        y2[m] = y * svcmi_splat2(k.two);
+        for (int j = 0; j < 6; ++j) y = svcmi_fma2(g2[j], xw.splat(5 - j + m), y);
+        y2[m] = y;
     }
     snake_fn2_all<RT + 5>(y2, a, inv_b, k, s2);
     const int u0 = 2 * t0 - 5;
@@ -175,19 +193,18 @@ __device__ __forceinline__ void snake_run(const float (&xw)[RT + 10], const floa
 //   snake_pairs:  s2[mm] = (s_up[2*tq0 - 5 + 2mm], s_up[2*tq0 - 5 + 2mm + 1]), mm < NP, from xw[i] = x[clamp(tq0 - 5 + i, 0, n-1)], i < NP + 5
 //   snake_fir:    out[r] = sum_i f2[i] . P[r + i], r < NR, from NR + 5 consecutive pairs P
 template <int NP>
-__device__ __forceinline__ void snake_pairs(const float (&xw)[NP + 5], const float (&f)[12], float a, float inv_b, const float* xc, int ld,
+__device__ __forceinline__ void snake_pairs(const SnakeWindow<NP + 5>& xw, const float (&f)[12], float a, float inv_b, const float* xc, int ld,
                                             int n, int tq0, svcmi_f32x2 (&s2)[NP]) {
     const SnakeConsts k = snake_consts();
-    svcmi_f32x2 f2[6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) f2[j] = svcmi_f32x2{f[2 * j], f[2 * j + 1]};
+    svcmi_f32x2 g2[6];
+    snake_up_taps(f, g2);
     svcmi_f32x2 y2[NP];
 #pragma unroll
     for (int m = 0; m < NP; ++m) {
         svcmi_f32x2 y = svcmi_splat2(0.f);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) y = svcmi_fma2(f2[j], svcmi_splat2(xw[5 - j + m]), y);
-        y2[m] = y * svcmi_splat2(k.two);
+        for (int j = 0; j < 6; ++j) y = svcmi_fma2(g2[j], xw.splat(5 - j + m), y);
+        y2[m] = y;
     }
     snake_fn2_all<NP>(y2, a, inv_b, k, s2);
     const int u0 = 2 * tq0 - 5;

@@ -20,6 +20,9 @@ typedef float svcmi_f32x4 __attribute__((ext_vector_type(4)));
 typedef float svcmi_f32x2 __attribute__((ext_vector_type(2)));      // packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32)
 __device__ __forceinline__ svcmi_f32x2 svcmi_fma2(svcmi_f32x2 a, svcmi_f32x2 b, svcmi_f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ svcmi_f32x2 svcmi_splat2(float v) { return svcmi_f32x2{v, v}; }
+// (lo, lo) / (hi, hi) of a register pair: folds into the op_sel modifiers of the packed instruction that consumes it
+__device__ __forceinline__ svcmi_f32x2 svcmi_splat_lo(svcmi_f32x2 p) { return __builtin_shufflevector(p, p, 0, 0); }
+__device__ __forceinline__ svcmi_f32x2 svcmi_splat_hi(svcmi_f32x2 p) { return __builtin_shufflevector(p, p, 1, 1); }
 // A constant the compiler must keep in a scalar register: packed instructions cannot encode literals, and given a literal the
 // instruction selector prefers two scalar v_fmaak_f32 over one v_pk_fma_f32 -- an SGPR operand keeps the polynomial packed.
 __device__ __forceinline__ float svcmi_sgpr_const(float v) {
@@ -40,6 +43,12 @@ __device__ __forceinline__ svcmi_f32x4 svcmi_load_uniform4(const float* p) {
 __device__ __forceinline__ const float* svcmi_opaque_uniform(const float* p) {
     asm volatile("" : "+s"(p));
     return p;
+}
+// One float at (wave-uniform base) + (per-lane 32-bit BYTE offset): `global_load_dword v, v_off, s[base]`.  The generic form spends a
+// 64-bit multiply-add and a 64-bit add per load on address arithmetic; here it is one v_add_u32 per further row.  `base` must come
+// from svcmi_opaque_uniform (an SGPR pair the optimiser cannot fold lane terms into); byte offsets < 2^32.
+__device__ __forceinline__ float svcmi_load_saddr(const float* base, unsigned byte_off) {
+    return *(const __attribute__((address_space(1))) float*)((const __attribute__((address_space(1))) char*)base + byte_off);
 }
 __device__ __forceinline__ float svcmi_load_uniform1(const float* p) { return *(const __attribute__((address_space(4))) float*)(p); }
 
