@@ -108,8 +108,29 @@ def ampblock(ops, c, ld, L, B):
 
 
 def main():
+    global timeit
     what = sys.argv[1:] or ["gemm", "snake", "dec", "attn"]
     ops = Ops()
+    if "attnrel" in what:     # relative-position attention of the prior encoder (2 heads x 96): register-fed kernel vs the LDS-staged one
+        H, D, W = 2, 96, 4
+        for (B, T) in ((1, 1000), (4, 1000), (16, 1000), (1, 2510)):
+            g = torch.Generator().manual_seed(B * T)
+            qkv = torch.randn(B, T, 3 * H * D, generator=g).cuda()
+            rk = (torch.randn(2 * W + 1, D, generator=g) * D ** -0.5).cuda()
+            rv = (torch.randn(2 * W + 1, D, generator=g) * D ** -0.5).cuda()
+            out = torch.empty(B, T, H * D, device="cuda")
+            fl = 4.0 * B * T * T * H * D
+            base = None
+            for code in (-1, 0, 41, 42, 81, 82):
+                ops.lib.svcmi_tune_set(b"attn_lds", code)
+                try:
+                    o = ops.attention(qkv, H, D ** -0.5, rel_k=rk, rel_v=rv, window=W, out=out).clone()
+                    us = timeit(lambda: ops.attention(qkv, H, D ** -0.5, rel_k=rk, rel_v=rv, window=W, out=out))
+                    if base is None:
+                        base = o
+                    print(f"attnrel B={B} T={T} attn_lds={code:3d}: {us:8.1f} us  {fl / us / 1e6:6.1f} TF/s  max diff to the register-fed kernel {float((o - base).abs().max()):.1e}", flush=True)
+                finally:
+                    ops.lib.svcmi_tune_set(b"attn_lds", 0)
     if "ampblock" in what:
         for B in ((1, 16) if "quick" in what else (1, 4, 16)):
             ampblock(ops, 10, 12, 320000, B)
@@ -168,7 +189,6 @@ def main():
             gemm(ops, "stage1_C80_B16", 20000, 80, 80, k=7, dil=3, res=True, tiles=(0,), splits=(1,), B=16, prec="bf16", a16=a16)
             gemm(ops, "stage0_C160_B16", 5000, 160, 160, k=7, dil=3, res=True, tiles=(0,), splits=(1,), B=16, prec="bf16", a16=a16)
     if "gemmpmc" in what:     # few launches, for counter collection
-        global timeit
         _t = timeit
         timeit = lambda fn, iters=3, warm=1: _t(fn, iters, warm)
         gemm(ops, "whisper_mlp1", 500, 1280, 5120, tiles=(1, 2, 3), splits=(1,))

@@ -414,6 +414,11 @@ ATTN_CASES_LDS = [
     dict(id="lds44_d64_T300", B=1, T=300, H=1, D=64, lds=44),
     dict(id="lds81_d64_T150", B=1, T=150, H=2, D=64, lds=81),
     dict(id="lds82_d64_ragged_T260", B=2, T=260, H=1, D=64, lengths=[200, 260], lds=82),
+    # relative-position band through the LDS-staged kernel (round 4; head widths 32 / 96)
+    dict(id="lds41_rel_d32_T70", B=1, T=70, H=2, D=32, rel=True, W=4, lds=41),
+    dict(id="lds42_rel_d32_ragged_T150", B=2, T=150, H=2, D=32, rel=True, W=4, lengths=[150, 61], lds=42),
+    dict(id="lds81_rel_d32_T200_w2", B=1, T=200, H=1, D=32, rel=True, W=2, lds=81),
+    dict(id="lds82_rel_d96_T140", B=1, T=140, H=2, D=96, rel=True, W=4, lds=82),
     # the key-split kernel forced (no LDS staging) at every split of the head width Whisper uses
     dict(id="ks_d64_T130_ns1", B=1, T=130, H=2, D=64, lds=-1, ns=1),
     dict(id="ks_d64_ragged_T257_ns2", B=2, T=257, H=2, D=64, lengths=[257, 140], lds=-1, ns=2),
@@ -427,6 +432,9 @@ ATTN_CASES_LDS_LARGE = [
     dict(id="lds81_whisper_T500_B4", B=4, T=500, H=20, D=64, lds=81),
     dict(id="lds24_whisper_T500", B=1, T=500, H=20, D=64, lds=24),
     dict(id="lds82_T1500", B=1, T=1500, H=4, D=64, lds=82),
+    dict(id="lds81_rel_encp_T1000_B4", B=4, T=1000, H=2, D=96, rel=True, W=4, lds=81),
+    dict(id="lds82_rel_encp_ragged_B3", B=3, T=301, H=2, D=96, rel=True, W=4, lengths=[301, 250, 7], lds=82),
+    dict(id="auto_rel_encp_T1000_B16", B=16, T=1000, H=2, D=96, rel=True, W=4),          # the heuristic picks the LDS-staged kernel (256 blocks)
 ]
 
 ATTN_CASES_LARGE = [

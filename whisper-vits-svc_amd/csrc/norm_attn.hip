@@ -734,14 +734,20 @@ __global__ __launch_bounds__(64 * NS) void attention_q32_kernel(AttnArgs p) {
 // the fetched tiles go to the other LDS buffer and ONE block-wide barrier closes the step.  L2 -> CU traffic per launch drops by QT (32
 // FLOP per fetched byte at QT = 4 instead of 8); the KS partial states of a query tile merge through LDS as in attention_kernel.  Opt-in
 // ("attn_lds" tuning knob) until it has been measured on hardware: with QT = 4 a T = 500 x 20-head launch is only 160 blocks.
-template <int D, int QT, int KS>
+// REL (round 4): the relative-position band of the prior encoder (vits/attentions.py:225-347) in the same decomposition, as attention_kernel
+// and attention16_kernel carry it: R[e] = q . E_k[e] per query, added to the in-band scores of diagonal steps; Pb[e] collects the in-band
+// probabilities so that sum_e Pb[e] E_v[e] is added in the merge.
+template <int D, int QT, int KS, bool REL = false>
 __global__ __launch_bounds__(64 * QT * KS) void attention_lds_kernel(AttnArgs p) {
     constexpr int DS = D / 16, OLD = D + 4, NW = QT * KS, NT = 64 * NW, QB = 16 * QT;
     constexpr int TLD = D + 4;                          // row stride of a staged tile: float4-aligned, rows 4 banks apart
     constexpr int TILE = 32 * TLD;                      // one 32-key tile (K or V)
     constexpr int STAGE = KS * 2 * 2 * TILE;            // [ks][buffer][K | V]
-    constexpr int MERGE = NW * 16 * OLD + 2 * NW * 16;  // partial O / max / sum of every wave (aliases the tiles after the last step)
-    __shared__ __attribute__((aligned(16))) float smem[STAGE > MERGE ? STAGE : MERGE];
+    constexpr int MERGE = NW * 16 * OLD + 2 * NW * 16 + (REL ? NW * 16 * BST : 0);  // partial O / max / sum (/ band sums) of every wave (aliases the tiles after the last step)
+    constexpr int MAIN = STAGE > MERGE ? STAGE : MERGE;
+    __shared__ __attribute__((aligned(16))) float smem[MAIN + (REL ? 2 * NREL * D : 0)];
+    float* const Ek = smem + MAIN;                      // [NREL][D]  (REL only; never aliased by the tiles / the merge state)
+    float* const Ev = Ek + NREL * D;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = SVCMI_UNIFORM((int)(tid >> 6));
@@ -759,6 +765,8 @@ __global__ __launch_bounds__(64 * QT * KS) void attention_lds_kernel(AttnArgs p)
     const int len = p.lengths ? p.lengths[b] : T;
     const float scale2 = p.scale * LOG2E;
     const int q0 = qg * QB + 16 * qt_l, qi = q0 + lq;
+    const int W = REL ? p.window : 0;
+    const int nrel = REL ? 2 * W + 1 : 0;
 
     float qf[DS][4];
     {
@@ -767,6 +775,23 @@ __global__ __launch_bounds__(64 * QT * KS) void attention_lds_kernel(AttnArgs p)
         for (int s = 0; s < DS; ++s) {
             const float4 t4 = *reinterpret_cast<const float4*>(qp + 16 * s);
             qf[s][0] = t4.x; qf[s][1] = t4.y; qf[s][2] = t4.z; qf[s][3] = t4.w;
+        }
+    }
+    float R[REL ? NREL : 1], Pb[REL ? NREL : 1];
+    if constexpr (REL) {
+        for (int i = tid; i < nrel * D; i += NT) { Ek[i] = p.rel_k[i]; Ev[i] = p.rel_v[i]; }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < NREL; ++e) {
+            R[e] = 0.f; Pb[e] = 0.f;
+            if (e < nrel) {           // wave-uniform
+                float a = 0.f;
+#pragma unroll
+                for (int s = 0; s < DS; ++s)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a = fmaf(qf[s][j], Ek[e * D + 16 * s + 4 * g4 + j], a);
+                R[e] = quarter_sum(a);
+            }
         }
     }
     svcmi_f32x4 oacc[DS];
@@ -837,6 +862,7 @@ __global__ __launch_bounds__(64 * QT * KS) void attention_lds_kernel(AttnArgs p)
             sacc[1] = svcmi_mfma_16x16x4(a1.w, qf[s][3], sacc[1]);
         }
         const bool clean = kt + 32 <= (len < T ? len : T) && q0 + 16 <= len;     // wave-uniform
+        const bool diag = REL && (kt + 31 >= q0 - W) && (kt <= q0 + 15 + W);       // wave-uniform: this step touches the band
         float sv[2][4];
         float mt = NEG_BIG;
 #pragma unroll
@@ -844,7 +870,17 @@ __global__ __launch_bounds__(64 * QT * KS) void attention_lds_kernel(AttnArgs p)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = kt + 16 * u + 4 * g4 + r;
-                float a = sacc[u][r] * scale2;
+                float a = sacc[u][r];
+                if constexpr (REL) {
+                    if (diag) {
+                        const int rel = key - qi + W;
+                        float add = 0.f;
+#pragma unroll
+                        for (int e = 0; e < NREL; ++e) add = (rel == e && e < nrel) ? R[e] : add;
+                        a += add;
+                    }
+                }
+                a *= scale2;
                 if (!clean) {
                     if (qi >= len || key >= len) a = MASKED2;       // masked_fill(mask == 0, -1e4)
                     if (key >= T) a = NEG_BIG;                      // beyond the sequence: weight 0
@@ -871,6 +907,20 @@ __global__ __launch_bounds__(64 * QT * KS) void attention_lds_kernel(AttnArgs p)
                 pv[u][r] = mnew > -1.0e38f ? svcmi_exp2(sv[u][r] - mnew) : 0.f;
                 lrun += pv[u][r];
             }
+        if constexpr (REL) {
+#pragma unroll
+            for (int e = 0; e < NREL; ++e) Pb[e] *= corr;
+            if (diag) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int rel = kt + 16 * u + 4 * g4 + r - qi + W;
+#pragma unroll
+                        for (int e = 0; e < NREL; ++e) Pb[e] += (rel == e && e < nrel) ? pv[u][r] : 0.f;
+                    }
+            }
+        }
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -887,7 +937,12 @@ __global__ __launch_bounds__(64 * QT * KS) void attention_lds_kernel(AttnArgs p)
     float* const Opart = smem;                              // [NW][16][OLD]
     float* const Mpart = Opart + NW * 16 * OLD;             // [NW][16]
     float* const Lpart = Mpart + NW * 16;                   // [NW][16]
+    float* const Bpart = Lpart + NW * 16;                   // [NW][16][BST]  (REL)
     lrun = quarter_sum(lrun);
+    if constexpr (REL) {
+#pragma unroll
+        for (int e = 0; e < NREL; ++e) Pb[e] = quarter_sum(Pb[e]);
+    }
     {
         float* orow = Opart + (w * 16 + lq) * OLD + 4 * g4;
 #pragma unroll
@@ -896,6 +951,10 @@ __global__ __launch_bounds__(64 * QT * KS) void attention_lds_kernel(AttnArgs p)
         if (g4 == 0) {
             Mpart[w * 16 + lq] = mrun;
             Lpart[w * 16 + lq] = lrun;
+            if constexpr (REL) {
+#pragma unroll
+                for (int e = 0; e < NREL; ++e) Bpart[(w * 16 + lq) * BST + e] = Pb[e];
+            }
         }
     }
     __syncthreads();
@@ -908,6 +967,9 @@ __global__ __launch_bounds__(64 * QT * KS) void attention_lds_kernel(AttnArgs p)
         for (int k2 = 0; k2 < KS; ++k2) mall = fmaxf(mall, Mpart[(k2 * QT + qtl) * 16 + ql]);
         float den = 0.f;
         float4 num = make_float4(0.f, 0.f, 0.f, 0.f);
+        float bs[REL ? NREL : 1];
+#pragma unroll
+        for (int e = 0; e < (REL ? NREL : 1); ++e) bs[e] = 0.f;
 #pragma unroll
         for (int k2 = 0; k2 < KS; ++k2) {
             const int ww = k2 * QT + qtl;
@@ -917,6 +979,20 @@ __global__ __launch_bounds__(64 * QT * KS) void attention_lds_kernel(AttnArgs p)
             const float4 ov = *reinterpret_cast<const float4*>(Opart + (ww * 16 + ql) * OLD + c4);
             num.x = fmaf(cw, ov.x, num.x); num.y = fmaf(cw, ov.y, num.y);
             num.z = fmaf(cw, ov.z, num.z); num.w = fmaf(cw, ov.w, num.w);
+            if constexpr (REL) {
+#pragma unroll
+                for (int e = 0; e < NREL; ++e) bs[e] = fmaf(cw, Bpart[(ww * 16 + ql) * BST + e], bs[e]);
+            }
+        }
+        if constexpr (REL) {
+#pragma unroll
+            for (int e = 0; e < NREL; ++e) {
+                if (e < nrel) {
+                    const float4 ev = *reinterpret_cast<const float4*>(Ev + e * D + c4);
+                    num.x = fmaf(bs[e], ev.x, num.x); num.y = fmaf(bs[e], ev.y, num.y);
+                    num.z = fmaf(bs[e], ev.z, num.z); num.w = fmaf(bs[e], ev.w, num.w);
+                }
+            }
         }
         const int qrow = qg * QB + qr;
         if (qrow < T) {
@@ -1337,6 +1413,26 @@ int launch_attn(const AttnArgs& a_in, int batch, void* stream) {
                 default: return SVCMI_EINVAL;
             }
             return SVCMI_LAST_ERROR();
+        }
+    }
+    if constexpr (D == 96 || D == 32) {
+        // relative-position band through the LDS-staged kernel (round 4): the prior encoder has 2 heads, so only batched launches fill the
+        // chip with 8-query-tile blocks (B = 16 x T = 1000: 256 blocks); one clip (16 blocks) keeps the register-fed kernel below
+        if (a.rel_k && a.window <= MAXW && g_attn_lds >= 0 && g_attn_ns == 0) {
+            const long long blocks8 = (long long)((a.t + 127) / 128) * a.heads * batch;
+            int code = g_attn_lds > 1 ? g_attn_lds : (g_attn_lds == 1 ? 82 : (blocks8 >= 128 ? (blocks8 >= 512 ? 81 : 82) : 0));
+            if (code == 81 || code == 82 || code == 41 || code == 42) {
+                const int qt = code / 10;
+                a.nq = (a.t + 16 * qt - 1) / (16 * qt);
+                dim3 g((unsigned)((long long)a.nq * a.heads * batch));
+                switch (code) {
+                    case 41: SVCMI_LAUNCH((attention_lds_kernel<D, 4, 1, true>), g, dim3(64 * 4), 0, stream, a); break;
+                    case 42: SVCMI_LAUNCH((attention_lds_kernel<D, 4, 2, true>), g, dim3(64 * 8), 0, stream, a); break;
+                    case 81: SVCMI_LAUNCH((attention_lds_kernel<D, 8, 1, true>), g, dim3(64 * 8), 0, stream, a); break;
+                    default: SVCMI_LAUNCH((attention_lds_kernel<D, 8, 2, true>), g, dim3(64 * 16), 0, stream, a); break;
+                }
+                return SVCMI_LAST_ERROR();
+            }
         }
     }
     if (q32) a.nq = (a.t + 31) / 32;
