@@ -212,6 +212,8 @@ static inline svcmi_f32x4 svcmi_mfma16_16x16x32(svcmi_u32x4 a, svcmi_u32x4 b, sv
     return c;
 }
 
+static inline unsigned svcmi_pack_lo16(unsigned a, unsigned b) { return (a & 0xffffu) | (b << 16); }
+static inline unsigned svcmi_pack_hi16(unsigned a, unsigned b) { return (a >> 16) | (b & 0xffff0000u); }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 

@@ -1110,23 +1110,48 @@ __global__ __launch_bounds__(64 * QT * KS) void attention16_kernel(Attn16Args p)
     const int per = ((T + KS - 1) / KS + 31) / 32 * 32;
     const int steps = per / 32;
     const int jbeg = ks * per;
-    // staging role inside the key range: QT * 64 threads move 32 rows x D/8 16-byte chunks of K and of V per step
-    constexpr int C8 = D / 8, CH = 32 * C8, PER_T = (2 * CH + 64 * QT - 1) / (64 * QT);
+    // staging role inside the key range: QT * 64 threads move 32 rows x D/8 16-byte chunks of K per step, and the V tile as TASKS of
+    // (key group of 4 rows, chunk of UD d-values): a task loads its 4 rows' chunk, transposes 4 x UD 16-bit values in registers (one
+    // v_perm_b32 per output dword) and writes UD units [d][4 keys] as UD / 2 ds_write_b128 -- the round-3 form wrote every 16-bit value
+    // with its own ds_write_b16 (32 per chunk; PMC: LDS bank-conflict share 0.44-0.65 of the kernel's LDS cycles)
+    constexpr int NTS = 64 * QT;                         // staging threads of a key range
+    constexpr int C8 = D / 8, CH = 32 * C8, PER_K = (CH + NTS - 1) / NTS;
+    constexpr int VSPLIT = QT >= 4 ? 2 : 1;              // QT >= 4: half chunks (8-byte loads), so that 8 * C8 * 2 tasks spread over more threads
+    constexpr int UD = 8 / VSPLIT, VW = UD / 2;          // d-values / dwords per row of a task
+    constexpr int NV = 8 * C8 * VSPLIT, PER_V = (NV + NTS - 1) / NTS;
     const int st = qt_l * 64 + lane;
     const unsigned short* kg_ = p.k + (long long)b * p.bs16 + h * D;
     const unsigned short* vg_ = p.v + (long long)b * p.bs16 + h * D;
     float* const Kt = smem + ks * 2 * (KT + VT);            // [buffer][K | V] of this key range
-    svcmi_u32x4 sreg[PER_T];
+    svcmi_u32x4 kreg[PER_K];
+    unsigned vreg[PER_V][4][VW];
     auto fetch = [&](int kt) {
 #pragma unroll
-        for (int j = 0; j < PER_T; ++j) {
-            const int idx = st + j * 64 * QT;
-            if (idx < 2 * CH) {
-                const int c = idx < CH ? idx : idx - CH;
-                const int row = c / C8, c8 = c - row * C8;
+        for (int j = 0; j < PER_K; ++j) {
+            const int idx = st + j * NTS;
+            if (idx < CH) {
+                const int row = idx / C8, c8 = idx - row * C8;
                 const int key = kt + row;
-                const long long off = (long long)(key < T ? key : T - 1) * p.ld16 + 8 * c8;
-                sreg[j] = *reinterpret_cast<const svcmi_u32x4*>((idx < CH ? kg_ : vg_) + off);
+                kreg[j] = *reinterpret_cast<const svcmi_u32x4*>(kg_ + (long long)(key < T ? key : T - 1) * p.ld16 + 8 * c8);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PER_V; ++j) {
+            const int idx = st + j * NTS;
+            if (idx < NV) {
+                const int kq = idx / (C8 * VSPLIT), cu = idx - kq * (C8 * VSPLIT);      // key group (4 rows), chunk of UD d-values
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int key = kt + 4 * kq + i;
+                    const unsigned short* src = vg_ + (long long)(key < T ? key : T - 1) * p.ld16 + UD * cu;
+                    if constexpr (VSPLIT == 1) {
+                        const svcmi_u32x4 t4 = *reinterpret_cast<const svcmi_u32x4*>(src);
+                        vreg[j][i][0] = t4[0]; vreg[j][i][1] = t4[1]; vreg[j][i][2] = t4[2]; vreg[j][i][3] = t4[3];
+                    } else {
+                        const svcmi_u32x2 t2 = *reinterpret_cast<const svcmi_u32x2*>(src);
+                        vreg[j][i][0] = t2[0]; vreg[j][i][1] = t2[1];
+                    }
+                }
             }
         }
     };
@@ -1134,20 +1159,27 @@ __global__ __launch_bounds__(64 * QT * KS) void attention16_kernel(Attn16Args p)
         float* const Kc = Kt + buf * (KT + VT);
         unsigned short* const Vc = reinterpret_cast<unsigned short*>(Kc + KT);
 #pragma unroll
-        for (int j = 0; j < PER_T; ++j) {
-            const int idx = st + j * 64 * QT;
-            if (idx < 2 * CH) {
-                const int c = idx < CH ? idx : idx - CH;
-                const int row = c / C8, c8 = c - row * C8;
-                if (idx < CH) {
-                    *reinterpret_cast<svcmi_u32x4*>(Kc + row * KLD + 4 * c8) = sreg[j];
-                } else {                                   // transposed: element (key group row >> 2, d, key row & 3)
-                    unsigned short* dst = Vc + ((row >> 2) * (D + 16) + 8 * c8) * 4 + (row & 3);
+        for (int j = 0; j < PER_K; ++j) {
+            const int idx = st + j * NTS;
+            if (idx < CH) {
+                const int row = idx / C8, c8 = idx - row * C8;
+                *reinterpret_cast<svcmi_u32x4*>(Kc + row * KLD + 4 * c8) = kreg[j];
+            }
+        }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        dst[(2 * e) * 4] = (unsigned short)(sreg[j][e] & 0xffffu);
-                        dst[(2 * e + 1) * 4] = (unsigned short)(sreg[j][e] >> 16);
-                    }
+        for (int j = 0; j < PER_V; ++j) {
+            const int idx = st + j * NTS;
+            if (idx < NV) {
+                const int kq = idx / (C8 * VSPLIT), cu = idx - kq * (C8 * VSPLIT);
+                unsigned short* dst = Vc + (kq * (D + 16) + UD * cu) * 4;      // unit (key group kq, d = UD * cu): 4 keys x 2 bytes, units of consecutive d adjacent
+#pragma unroll
+                for (int wd = 0; wd < VW; ++wd) {          // dword wd of the rows holds d = 2 wd (low half) and 2 wd + 1 (high half): two units = 16 bytes
+                    svcmi_u32x4 o;
+                    o[0] = svcmi_pack_lo16(vreg[j][0][wd], vreg[j][1][wd]);
+                    o[1] = svcmi_pack_lo16(vreg[j][2][wd], vreg[j][3][wd]);
+                    o[2] = svcmi_pack_hi16(vreg[j][0][wd], vreg[j][1][wd]);
+                    o[3] = svcmi_pack_hi16(vreg[j][2][wd], vreg[j][3][wd]);
+                    *reinterpret_cast<svcmi_u32x4*>(dst + 8 * wd) = o;
                 }
             }
         }

@@ -100,6 +100,10 @@ __device__ __forceinline__ svcmi_f32x4 svcmi_mfma16_16x16x32(svcmi_u32x4 a, svcm
     else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(svcmi_bf16x8, a), __builtin_bit_cast(svcmi_bf16x8, b), c, 0, 0, 0);
 }
 
+// (lo16(a) | lo16(b) << 16) and (hi16(a) | hi16(b) << 16) as ONE v_perm_b32 each: the 16-bit transposes of the attention16 V staging
+__device__ __forceinline__ unsigned svcmi_pack_lo16(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }
+__device__ __forceinline__ unsigned svcmi_pack_hi16(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+
 // Asynchronous global -> LDS copy (LDS-DMA) through a buffer descriptor: `buffer_load_dword[x4] voff, rsrc, 0 offen lds`.
 // Lane l fetches 16 (4) bytes at rsrc.base + voff[l]; they land at lds_wave_base + 16*l (4*l) bytes, where
 // `lds_wave_base` is wave-uniform (it travels in M0).  The hardware range-checks voff against rsrc.num_records
