@@ -557,11 +557,12 @@ extern "C" int svcmi_conv_tune_set(const char* name, int32_t value);      // con
 extern "C" int svcmi_attn_tune_set(const char* name, int32_t value);      // norm_attn.hip: "attn_ns"
 extern "C" int svcmi_host_tune_set(const char* name, int32_t value);      // host_stages.hip: "amp_grouped", "amp_block"
 extern "C" int svcmi_amp_block_tune_set(const char* name, int32_t value); // amp_block.hip: "amp_block_variant"
+extern "C" int svcmi_snake_tune_set(const char* name, int32_t value);     // generator.hip: "snake_rt"
 
 extern "C" int svcmi_tune_set(const char* name, int32_t value) {
     if (!name) return SVCMI_EINVAL;
     if (svcmi_conv_tune_set(name, value) == 0 || svcmi_attn_tune_set(name, value) == 0 || svcmi_host_tune_set(name, value) == 0 ||
-        svcmi_amp_block_tune_set(name, value) == 0) return 0;
+        svcmi_amp_block_tune_set(name, value) == 0 || svcmi_snake_tune_set(name, value) == 0) return 0;
     const char* k = "amp_tt";
     int i = 0;
     while (k[i] && name[i] == k[i]) ++i;

@@ -10,7 +10,8 @@
 namespace {
 
 constexpr int TPB = 256;
-constexpr int RT = 8;   // outputs per thread along time
+constexpr int SNAKE_RT_BIG = 8;   // run length of the SnakeAlias stream kernel for arithmetic-bound (batched) launches: measured choice, see svcmi_snake_alias_group_f32
+int g_snake_rt = 0;
 
 #include "snake_math.h"
 
@@ -25,7 +26,11 @@ struct SnakeArgs {
     int f16;                               // 0 bf16, 1 f16, 2 split bf16 rows [hi: ld | lo: ld] (svcmi_store4_16's codes)
 };
 
+// RTK = outputs per thread along time: a run of RTK outputs evaluates RTK + 5 up-sampled pairs (13 per 8 = 1.63x, 17 per 12 = 1.42x, 21 per
+// 16 = 1.31x) at the price of registers; same operation sequence per value, so every run length gives the same bits.
+template <int RTK>
 __global__ __launch_bounds__(TPB) void snake_alias_kernel(SnakeArgs p) {
+    constexpr int RT = RTK;
     const int b = blockIdx.y, gi = blockIdx.z;
     const int n = p.n, c = p.c, ld = p.ld;
     const float* filt = p.filt;
@@ -195,10 +200,25 @@ extern "C" int svcmi_snake_alias_group_f32(const float* const* x, float* const* 
         a.x[i] = x[j]; a.y[i] = yj; a.y16[i] = hj; a.alpha_log[i] = alpha_log[j]; a.beta_log[i] = beta_log[j];
     }
     a.filt = filt; a.n = len; a.c = c; a.ld = ld; a.f16 = y16 ? svcmi_fmt16(y16_format) : 0;
-    const long long runs = ((long long)len + RT - 1) / RT;
+    // run length per thread: 8 for one clip (more, smaller work items: the launch is latency-bound), longer runs once the launch is
+    // arithmetic-bound (tuning knob "snake_rt": 0 = this rule, 8 | 12 | 16 forced)
+    const long long elems = (long long)batch * len * c * count;
+    const int rt = g_snake_rt ? g_snake_rt : (elems >= (1LL << 25) ? SNAKE_RT_BIG : 8);
+    const long long runs = ((long long)len + rt - 1) / rt;
     const long long threads = runs * c;
-    SVCMI_LAUNCH(snake_alias_kernel, dim3((unsigned)((threads + TPB - 1) / TPB), batch, count), dim3(TPB), 0, stream, a);
+    const dim3 grid((unsigned)((threads + TPB - 1) / TPB), batch, count);
+    if (rt == 16) SVCMI_LAUNCH(snake_alias_kernel<16>, grid, dim3(TPB), 0, stream, a);
+    else if (rt == 12) SVCMI_LAUNCH(snake_alias_kernel<12>, grid, dim3(TPB), 0, stream, a);
+    else SVCMI_LAUNCH(snake_alias_kernel<8>, grid, dim3(TPB), 0, stream, a);
     return SVCMI_LAST_ERROR();
+}
+
+extern "C" int svcmi_snake_tune_set(const char* name, int32_t value) {
+    const char* k = "snake_rt";
+    int i = 0;
+    while (k[i] && name[i] == k[i]) ++i;
+    if (k[i] == 0 && name[i] == 0 && (value == 0 || value == 8 || value == 12 || value == 16)) { g_snake_rt = value; return 0; }
+    return SVCMI_EINVAL;
 }
 
 extern "C" int svcmi_snake_alias_f32(const float* x, float* y, const float* alpha_log, const float* beta_log,
