@@ -144,7 +144,14 @@ enum svcmi_precision { SVCMI_PREC_F32 = 0, SVCMI_PREC_BF16X3 = 1, SVCMI_PREC_BF1
                        SVCMI_PREC_BF16_A16 = 4, SVCMI_PREC_F16_A16 = 5, SVCMI_PREC_BF16X3_A16 = 6,
                        /* model-level only (svcmi_synth_model.precision): every layer CLASS of the synthesizer runs in its own mode,
                         * svcmi_synth_model.class_prec[] -- the per-layer mixed policy that keeps the 16-bit waveform error inside the parity bar */
-                       SVCMI_PREC_MIXED = 7 };
+                       SVCMI_PREC_MIXED = 7,
+                       /* fp16 activations x SPLIT fp16 weights (round 4): a mode of a model / layer class that behaves like SVCMI_PREC_F16 (fp16 activation
+                        * rows from the producers, fp16 attention) except that a convolution reading 16-bit activations runs as SVCMI_PREC_F16W2_A16: the
+                        * static weight w = hi + lo with hi = fp16(w), lo = fp16(w - hi) (exact to 2^-22; the matrix cores honour the subnormal lo values:
+                        * scripts/probes/mfma_f16_subnormal.hip), acc += a*hi + a*lo -- two MFMAs per fragment pair, the error of the product is the
+                        * ACTIVATION rounding alone (0.6-0.7x of plain fp16, scripts/precision_sensitivity.py --operands a).  Weight image of the _A16 code:
+                        * rows [hi: ldw16 | lo: ldw16] in natural k order; the non-_A16 launches of such a layer use the plain SVCMI_PREC_F16 image. */
+                       SVCMI_PREC_F16W2 = 8, SVCMI_PREC_F16W2_A16 = 9 };
 int svcmi_pack_weights_lp(const float* w, int32_t n, int32_t ldw, int32_t precision, void* out, int32_t ldw16, void* stream);
 int svcmi_conv_gemm_lp(const svcmi_conv_desc* d, int32_t precision, void* stream);
 int svcmi_conv_gemm_group_lp(const svcmi_conv_desc* descs, int32_t count, int32_t precision, void* stream);

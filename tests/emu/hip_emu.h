@@ -170,6 +170,7 @@ static inline float emu_f16_f32(unsigned h) {
     if (e == 0) return (sign ? -1.f : 1.f) * ldexpf((float)m, -24);
     return svcmi_bits_f32(sign | ((e + 112) << 23) | (m << 13));
 }
+static inline float svcmi_f16_bits_f32(unsigned h) { return emu_f16_f32(h & 0xffffu); }
 static inline unsigned svcmi_cvt_pk_bf16(float a, float b) { return emu_bf16_rne(a) | (emu_bf16_rne(b) << 16); }
 static inline unsigned svcmi_cvt_pk_f16(float a, float b) { return emu_f16_rne(a) | (emu_f16_rne(b) << 16); }
 template <bool F16>

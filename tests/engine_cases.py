@@ -90,7 +90,10 @@ def check_generator_widths_against_oracle(ops, device, T=5, B=2, tol=TIGHT, prec
         assert trace.get("svcmi_conv_gemm_lp", {}).get("launches", 0) >= 20 and trace.get("svcmi_conv_gemm_group_lp", {}).get("launches", 0) >= 6, \
             f"reduced-precision kernels did not run: { {k: v['launches'] for k, v in trace.items()} }"
         assert errs["wave"] > 0.0
-        if precision in ("f16", "bf16"):      # the wide stages' grouped GEMMs read SnakeAlias's 16-bit rows
+        if precision in ("f16", "bf16", "f16w2"):      # the wide stages' grouped GEMMs read SnakeAlias's 16-bit rows
+            if precision == "f16w2":           # ... and take the split-weight kernel there
+                from svcmi import _lib
+                assert _lib.PREC_F16W2_A16 in trace["svcmi_conv_gemm_group_lp"]["precisions"], trace["svcmi_conv_gemm_group_lp"]
             assert trace["svcmi_conv_gemm_group_lp"]["a16_launches"] >= 6, trace["svcmi_conv_gemm_group_lp"]
     assert errs["source"] <= 5e-5 and errs["wave"] <= min(tol * 5, WAVE_TOL), errs
     return errs

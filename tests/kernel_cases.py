@@ -86,6 +86,12 @@ CONV_CASES_LP_SMALL = [
     dict(id="a16_x3_vec_c24_masks_ktail", B=2, T=37, cin=24, n=20, k=5, pad=2, lengths=[37, 20], mask_in=True, mask_out=True, prec="bf16x3", a16=True),
     dict(id="a16_x3_128x128_k1", B=1, T=150, cin=256, n=140, k=1, prec="bf16x3", a16=True, tile=3),
     dict(id="a16_x3_stride2_k3_splitk", B=1, T=81, cin=96, n=40, k=3, stride=2, pad=1, prec="bf16x3", a16=True, split_k=3),
+    # fp16 activations x split fp16 weights (SVCMI_PREC_F16W2_A16: rows [hi | lo], two MFMAs; lo is mostly subnormal fp16)
+    dict(id="a16_w2_64x64_chunk_k3", B=1, T=90, cin=64, n=70, k=3, pad=1, prec="f16w2", a16=True, res=True),
+    dict(id="a16_w2_p16_c40_k11_d5_out16", B=1, T=300, cin=40, n=40, k=11, dil=5, pad=25, res=True, prec="f16w2", a16=True, tile=4, out16=True),
+    dict(id="a16_w2_p16_c80_k7_d3", B=2, T=130, cin=80, n=80, k=7, dil=3, pad=9, prec="f16w2", a16=True, tile=6),
+    dict(id="a16_w2_vec_c24_masks_ktail", B=2, T=37, cin=24, n=20, k=5, pad=2, lengths=[37, 20], mask_in=True, mask_out=True, prec="f16w2", a16=True),
+    dict(id="w2_without_x16_is_plain_f16", B=1, T=70, cin=32, n=40, k=3, pad=1, prec="f16w2"),
     # split_k = 0 (library heuristic) on long-K, few-tile shapes WITH the 16-bit output copy: the copy only comes out of the non-split
     # epilogue, so the launchers must not split (y16 was left uninitialised)
     dict(id="lp_f16_splitk_auto_out16", B=1, T=33, cin=16, n=8, k=63, pad=31, split_k=0, prec="f16", out16=True),
@@ -136,13 +142,15 @@ def check_conv(ops, c, device):
     if prec is None:
         ref = exact
     else:       # the same rounding the kernel applies to both operands, products and sums in fp32
-        rnd = (lambda t: t.half().float()) if prec == "f16" else (lambda t: t.bfloat16().float())
+        rnd = (lambda t: t.half().float()) if prec in ("f16", "f16w2") else (lambda t: t.bfloat16().float())
         xh, wh = rnd(xin), rnd(w)
         ref = conv(xh, wh, bias)
         if prec == "bf16x3":
             ref = ref + conv(rnd(xin - xh), wh) + conv(xh, rnd(w - wh))
+        if prec == "f16w2" and c.get("a16"):          # a * hi + a * lo: the weight exact to 2^-22, the activation rounded (without x16: plain fp16)
+            ref = ref + conv(xh, rnd(w - wh))
         # and the mode's own error against the fp32 result stays in its class
-        bound = {"bf16x3": 2e-5, "f16": 2e-3, "bf16": 1.5e-2}[prec]
+        bound = {"bf16x3": 2e-5, "f16": 2e-3, "bf16": 1.5e-2, "f16w2": 2e-3}[prec]
         err = (ref - exact).abs().max().item() / max(1.0, exact.abs().max().item())
         assert err <= bound, f"{c['id']}: {prec} rounding error {err:.2e} > {bound:.0e}"
     t_out = ref.shape[1]
@@ -164,7 +172,7 @@ def check_conv(ops, c, device):
         xd = xd.reshape(B, t_phys)      # a plain signal, ldx = 1
     launches, saved_min = ops.launches, ops.lp_min_flops
     ops.lp_min_flops = 0.0
-    dt16 = {"f16": torch.float16, "bf16": torch.bfloat16}.get(prec)
+    dt16 = {"f16": torch.float16, "bf16": torch.bfloat16, "f16w2": torch.float16}.get(prec)
     x16 = xd.to(dt16) if c.get("a16") and dt16 else None          # what a producing kernel's 16-bit output holds: the same values, rounded
     if c.get("a16") and prec == "bf16x3":                # ... or split into (hi, lo) bf16 planes: rows [hi: Cp | lo: Cp]
         x16 = _split16(xd)
@@ -179,7 +187,7 @@ def check_conv(ops, c, device):
     if prec is not None:
         assert getattr(wp, "_svcmi_lp", None), f"{c['id']}: the reduced-precision kernel did not run"
         if c.get("a16"):
-            a16_code = 6 if prec == "bf16x3" else PRECISIONS[prec] + 2
+            a16_code = {"bf16x3": 6, "f16w2": 9}.get(prec, PRECISIONS[prec] + 2)
             assert wp._svcmi_lp.get(a16_code) is not None, f"{c['id']}: the 16-bit-activation kernel did not run"
     if c.get("out16"):
         y, y16 = y

@@ -62,6 +62,12 @@ def test_mixed_precision_policy_switches_modes_per_layer_class(ops):
     print(E.check_mixed_precision_policy(ops, "cpu"))
 
 
+def test_generator_base_widths_f16_activations_split_f16_weights(ops):
+    """SVCMI_PREC_F16W2: fp16 activation rows, (hi, lo) fp16 weight pairs in the launches that read them -- closer to fp32 than plain fp16."""
+    e_w2 = E.check_generator_widths_against_oracle(ops, "cpu", T=3, B=1, tol=4e-3, precision="f16w2")
+    print(e_w2)
+
+
 def test_whisper_tiny_f16_operands(ops):
     """fp16 operands (what the reference's `.half()` accelerator path uses, whisper/inference.py:22-23) on the tiny encoder:
     error in the fp16 class, far from fp32's 1e-6 but bounded."""

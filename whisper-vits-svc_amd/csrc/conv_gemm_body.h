@@ -62,7 +62,9 @@ namespace {
 constexpr int BK = 32;
 enum { MODE_CHUNK = 0, MODE_VEC = 1, MODE_SCALAR = 2, MODE_CHUNK_RS = 3 };   // _RS: CHUNK with x_row_shift != 0
 
-enum { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_BF16 = 2, PREC_F16 = 3, PREC_BF16_A16 = 4, PREC_F16_A16 = 5, PREC_BF16X3_A16 = 6 };   // == enum svcmi_precision
+enum { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_BF16 = 2, PREC_F16 = 3, PREC_BF16_A16 = 4, PREC_F16_A16 = 5, PREC_BF16X3_A16 = 6, PREC_F16W2_A16 = 9 };   // == enum svcmi_precision
+// F16W2_A16 (round 4): fp16 activation rows as F16_A16, but the weight image holds (hi, lo) fp16 pairs -- rows [hi | lo] -- and a fragment pair
+// costs two MFMAs (a*hi + a*lo): the weight is exact to 2^-22, only the activation rounding is left in the product.
 // _A16: the ACTIVATIONS arrive as a 16-bit tensor too (written by the producing kernel's epilogue) and the weight image is in natural
 // k order (svcmi_pack_weights_lp with an _A16 precision).  Both tiles then use the fp32 kernel's data movement unchanged -- rows of 128
 // bytes, eight 16-byte chunks XOR-swizzled by swz(row), 8 rows per 1-KiB DMA piece -- on 16-bit data: a K-step covers 64 k instead of
@@ -166,9 +168,10 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
     constexpr bool LP = PREC != PREC_F32 && !A16;     // 16-bit weight image(s) in 64-byte rows, fp32 activations rounded in registers
     constexpr int KS = A16 ? 2 * BK : BK;             // k per K-step
     constexpr unsigned ESZ = A16 ? 2u : 4u;           // bytes per activation element
-    constexpr bool F16OP = PREC == PREC_F16 || PREC == PREC_F16_A16;
+    constexpr bool F16OP = PREC == PREC_F16 || PREC == PREC_F16_A16 || PREC == PREC_F16W2_A16;
     constexpr bool X3A = PREC == PREC_BF16X3_A16;     // ... both as (hi, lo) bf16 pairs
-    constexpr int NB = (PREC == PREC_BF16X3 || X3A) ? 2 : 1;   // B images per stage (hi, lo)
+    constexpr bool W2A = PREC == PREC_F16W2_A16;      // ... fp16 activations x (hi, lo) fp16 weights
+    constexpr int NB = (PREC == PREC_BF16X3 || X3A || W2A) ? 2 : 1;   // B images per stage (hi, lo)
     constexpr int NA = X3A ? 2 : 1;                   // A images per stage
     constexpr int BM = 64 * WM, BN = P16 ? 16 * WN : 64 * WN;
     constexpr int BROW = LP ? BK / 2 : BK;            // floats per B row in LDS (LP: 32 x 2 bytes)
@@ -179,7 +182,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
     // LDS ring of NST operand tiles (48 / 72 / 64 KiB per block): tile it+NST-1 is in flight while tile
     // `it` is consumed, so a K-step never waits a full HBM/L2 round trip -- what short K ranges (split-K slices,
     // the k=1 projections of the prior encoder / flow, k=3 convolutions) would otherwise pay on every step.
-    constexpr int NST = NSTO ? NSTO : X3A ? 2 : (LP ? 3 : (P16 ? ((BM + BNL) > 192 ? 2 : 3) : ((WM * WN == 1) ? 3 : (WM * WN == 2 ? 3 : 2))));
+    constexpr int NST = NSTO ? NSTO : (X3A || (W2A && P16)) ? 2 : (LP ? 3 : (P16 ? ((BM + BNL) > 192 ? 2 : 3) : ((WM * WN == 1) ? 3 : (WM * WN == 2 ? 3 : 2))));
     constexpr int RING = NST * (NA * BM * BK + NB * BTILE);
     static_assert(LP || A16 || BM * CLD <= RING, "C tile must fit in the operand buffers");
     __shared__ __attribute__((aligned(16))) float smem[(RING > BM * CLD ? RING : BM * CLD) + 4];   // + the split-K ticket word
@@ -318,7 +321,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
     const int frow = lane & (FR - 1), fhi = P16 ? (lane >> 4) : (lane >> 5);
     const int a_off = (wm * FR * WM + frow) * BK, b_off = (wn * FR * WN + frow) * BROW;
     // Fragment reads of sub-step s into (a4, b4).  `tie` is a register the MFMAs issued next consume.
-    constexpr int FA = NA * WM, FB = (X3A ? 2 : 1) * WN;      // fragments per sub-step (X3A: hi images first, then lo)
+    constexpr int FA = NA * WM, FB = ((X3A || W2A) ? 2 : 1) * WN;      // fragments per sub-step (X3A / W2A: hi images first, then lo)
     auto load_frags = [&](const float* Ab, const float* Bb, int s, svcmi_f32x4 (&a4)[FA], svcmi_f32x4 (&b4)[FB], svcmi_f32x4& tie) {
         const int pos = ((((P16 ? 4 : 2) * s + fhi) ^ swz(frow)) << 2);
 #pragma unroll
@@ -480,6 +483,15 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
                     for (int j = 0; j < WN; ++j) mma16(acc[i][j], svcmi_as_u32x4(af[WM + i]), svcmi_as_u32x4(bf[j]));
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) mma16(acc[i][j], svcmi_as_u32x4(af[i]), svcmi_as_u32x4(bf[WN + j]));
+            } else if constexpr (W2A) {         // a*hi + a*lo
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) mma16(acc[i][j], svcmi_as_u32x4(af[i]), svcmi_as_u32x4(bf[j]));
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -754,7 +766,7 @@ int prepare(const svcmi_conv_desc* d, ConvArgs& a, int& mode, int prec = PREC_F3
                    ((uintptr_t)d->y16 & 7) || (d->flags & SVCMI_CONV_PARTIALS) || d->split_k > 1))
         return SVCMI_EINVAL;
     /* 32-bit buffer offsets with a 2^30 out-of-range sentinel: each operand buffer stays below 2^29 bytes */
-    if ((long long)d->t_in * d->ldx >= (1LL << 27) || (long long)d->n_out * d->ldw * ((prec == PREC_BF16X3 || x3a) ? 2 : 1) >= (1LL << (lp ? 28 : 27))) return SVCMI_EUNSUPPORTED;
+    if ((long long)d->t_in * d->ldx >= (1LL << 27) || (long long)d->n_out * d->ldw * ((prec == PREC_BF16X3 || x3a || prec == PREC_F16W2_A16) ? 2 : 1) >= (1LL << (lp ? 28 : 27))) return SVCMI_EUNSUPPORTED;
     if (((long long)d->ksize * d->dilation + d->pad) * d->ldx >= (1LL << 27)) return SVCMI_EUNSUPPORTED;
     if (d->batch <= 0 || d->t_in <= 0 || d->t_out <= 0 || d->c_in <= 0 || d->n_out <= 0 || d->ksize <= 0) return SVCMI_EINVAL;
     if (d->stride <= 0 || d->dilation <= 0 || d->x_row_shift < 0 || d->x_row_shift > 1) return SVCMI_EINVAL;

@@ -11,7 +11,7 @@ namespace {
 // k = 32*blk + (e < 4 ? 4q + e : 16 + 4q + e - 4)  (chunk q pairs with the fp32 A chunks q and q + 4, conv_gemm_body.h).
 __global__ __launch_bounds__(256) void pack_lp_kernel(const float* w, int n, int ldw, unsigned short* out, int ldw16, int prec) {
     const long long total = (long long)n * ldw16;
-    const int nb = (prec == PREC_BF16X3 || prec == PREC_BF16X3_A16) ? 2 : 1;
+    const int nb = (prec == PREC_BF16X3 || prec == PREC_BF16X3_A16 || prec == PREC_F16W2_A16) ? 2 : 1;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         const int row = (int)(idx / ldw16), pos = (int)(idx - (long long)row * ldw16);
         const int blk = pos >> 5, q = (pos >> 3) & 3, e = pos & 7;
@@ -20,6 +20,10 @@ __global__ __launch_bounds__(256) void pack_lp_kernel(const float* w, int n, int
         unsigned short* dst = out + (long long)row * nb * ldw16 + pos;
         if (prec == PREC_F16 || prec == PREC_F16_A16) {
             dst[0] = (unsigned short)(svcmi_cvt_pk_f16(v, 0.f) & 0xffffu);
+        } else if (prec == PREC_F16W2_A16) {        // hi = fp16(w), lo = fp16(w - hi): lo is mostly SUBNORMAL fp16, which the matrix cores honour
+            const unsigned h = svcmi_cvt_pk_f16(v, 0.f) & 0xffffu;
+            dst[0] = (unsigned short)h;
+            dst[ldw16] = (unsigned short)(svcmi_cvt_pk_f16(v - svcmi_f16_bits_f32(h), 0.f) & 0xffffu);
         } else {
             const unsigned h = svcmi_cvt_pk_bf16(v, 0.f) & 0xffffu;
             dst[0] = (unsigned short)h;
@@ -78,7 +82,7 @@ int dispatch_group(GroupArgs& g, const TileChoice& t, int count, int batch, int 
 
 extern "C" int svcmi_pack_weights_lp(const float* w, int32_t n, int32_t ldw, int32_t precision, void* out, int32_t ldw16, void* stream) {
     if (!w || !out || n <= 0 || ldw <= 0) return SVCMI_EINVAL;
-    if (precision < SVCMI_PREC_BF16X3 || precision > SVCMI_PREC_BF16X3_A16) return SVCMI_EINVAL;
+    if ((precision < SVCMI_PREC_BF16X3 || precision > SVCMI_PREC_BF16X3_A16) && precision != SVCMI_PREC_F16W2_A16) return SVCMI_EINVAL;
     if (ldw16 % 32 != 0 || ldw16 < ldw) return SVCMI_EINVAL;
     if (((uintptr_t)out & 15) != 0) return SVCMI_EALIGN;
     const long long total = (long long)n * ldw16;
@@ -89,7 +93,7 @@ extern "C" int svcmi_pack_weights_lp(const float* w, int32_t n, int32_t ldw, int
 }
 
 extern "C" int svcmi_conv_gemm_lp(const svcmi_conv_desc* d, int32_t precision, void* stream) {
-    if (precision < SVCMI_PREC_BF16X3 || precision > SVCMI_PREC_BF16X3_A16) return SVCMI_EINVAL;
+    if ((precision < SVCMI_PREC_BF16X3 || precision > SVCMI_PREC_BF16X3_A16) && precision != SVCMI_PREC_F16W2_A16) return SVCMI_EINVAL;
     ConvArgs a;
     int mode;
     if (int rc = prepare(d, a, mode, precision)) return rc;
@@ -123,12 +127,13 @@ extern "C" int svcmi_conv_gemm_lp(const svcmi_conv_desc* d, int32_t precision, v
         case SVCMI_PREC_BF16_A16: return dispatch<PREC_BF16_A16>(a, t, d->batch, mode, stream);
         case SVCMI_PREC_F16_A16: return dispatch<PREC_F16_A16>(a, t, d->batch, mode, stream);
         case SVCMI_PREC_BF16X3_A16: return dispatch<PREC_BF16X3_A16>(a, t, d->batch, mode, stream);
+        case SVCMI_PREC_F16W2_A16: return dispatch<PREC_F16W2_A16>(a, t, d->batch, mode, stream);
         default: return dispatch<PREC_F16>(a, t, d->batch, mode, stream);
     }
 }
 
 extern "C" int svcmi_conv_gemm_group_lp(const svcmi_conv_desc* descs, int32_t count, int32_t precision, void* stream) {
-    if (precision < SVCMI_PREC_BF16X3 || precision > SVCMI_PREC_BF16X3_A16) return SVCMI_EINVAL;
+    if ((precision < SVCMI_PREC_BF16X3 || precision > SVCMI_PREC_BF16X3_A16) && precision != SVCMI_PREC_F16W2_A16) return SVCMI_EINVAL;
     if (!descs || count < 1 || count > GROUP_MAX) return SVCMI_EINVAL;
     GroupArgs g;
     int order[GROUP_MAX] = {0, 1, 2};
@@ -162,6 +167,7 @@ extern "C" int svcmi_conv_gemm_group_lp(const svcmi_conv_desc* descs, int32_t co
         case SVCMI_PREC_BF16_A16: return dispatch_group<PREC_BF16_A16>(g, t, count, d0.batch, mode, stream);
         case SVCMI_PREC_F16_A16: return dispatch_group<PREC_F16_A16>(g, t, count, d0.batch, mode, stream);
         case SVCMI_PREC_BF16X3_A16: return dispatch_group<PREC_BF16X3_A16>(g, t, count, d0.batch, mode, stream);
+        case SVCMI_PREC_F16W2_A16: return dispatch_group<PREC_F16W2_A16>(g, t, count, d0.batch, mode, stream);
         default: return dispatch_group<PREC_F16>(g, t, count, d0.batch, mode, stream);
     }
 }

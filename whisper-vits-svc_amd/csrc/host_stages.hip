@@ -127,14 +127,17 @@ struct CV {
 int class_prec(const svcmi_synth_model& m, int cls) {
     if (m.precision != SVCMI_PREC_MIXED) return m.precision;
     const int p = cls >= 0 && cls < SVCMI_PREC_CLASSES ? m.class_prec[cls] : SVCMI_PREC_F32;
-    return p >= SVCMI_PREC_F32 && p <= SVCMI_PREC_F16 ? p : SVCMI_PREC_F32;
+    return (p >= SVCMI_PREC_F32 && p <= SVCMI_PREC_F16) || p == SVCMI_PREC_F16W2 ? p : SVCMI_PREC_F32;
 }
 
-bool mode16(int prec) { return prec == SVCMI_PREC_BF16 || prec == SVCMI_PREC_F16; }
+// SVCMI_PREC_F16W2 is a MODE (fp16 activation rows like SVCMI_PREC_F16; split fp16 weights in the launches that read them): everything
+// that names a 16-bit FORMAT (a producer's y16_format, the attention kernels, the plain 16-bit weight image) sees fmt16_of() = F16.
+int fmt16_of(int prec) { return prec == SVCMI_PREC_F16W2 ? SVCMI_PREC_F16 : prec; }
+bool mode16(int prec) { return prec == SVCMI_PREC_BF16 || prec == SVCMI_PREC_F16 || prec == SVCMI_PREC_F16W2; }
 // Modes whose GEMM chains hand 16-bit activations from producer to consumer: bf16 / f16 rows, or (bf16x3) split rows [hi: C | lo: C].
 bool act16(int prec) { return mode16(prec) || prec == SVCMI_PREC_BF16X3; }
 int w16(int prec, int C) { return prec == SVCMI_PREC_BF16X3 ? 2 * C : C; }             // 16-bit values per row of C channels
-int a16_code(int prec) { return prec == SVCMI_PREC_BF16X3 ? SVCMI_PREC_BF16X3_A16 : prec + 2; }
+int a16_code(int prec) { return prec == SVCMI_PREC_BF16X3 ? SVCMI_PREC_BF16X3_A16 : (prec == SVCMI_PREC_F16W2 ? SVCMI_PREC_F16W2_A16 : prec + 2); }
 
 int conv_t_out(const CV& v) { return v.t_out >= 0 ? v.t_out : (v.t_in + 2 * v.pad - v.dil * (v.ksize - 1) - 1) / v.stride + 1; }
 
@@ -176,7 +179,7 @@ int conv_desc(const Ctx& c, const CV& v, svcmi_conv_desc& d, double& flops, doub
     } else {
         d.split_k = 1;
     }
-    const int yfmt = v.y16_fmt >= 0 ? v.y16_fmt : c.prec;
+    const int yfmt = fmt16_of(v.y16_fmt >= 0 ? v.y16_fmt : c.prec);
     if (v.y16 && act16(yfmt) && !partials && d.split_k == 1) {
         d.y16 = v.y16; d.y16_bstride = w16(yfmt, 1) * d.y_bstride; d.ldy16 = w16(yfmt, d.ldy); d.y16_format = yfmt;
         bytes += 2.0 * v.B * t_out * w16(yfmt, N);
@@ -190,9 +193,10 @@ int conv_desc(const Ctx& c, const CV& v, svcmi_conv_desc& d, double& flops, doub
         d.w = static_cast<const float*>(v.w->w16a);
         d.ldx = w16(c.prec, v.ldx); d.x_bstride = w16(c.prec, 1) * v.x_bs;
         bytes -= (4.0 - 2.0 * w16(c.prec, 1)) * v.B * (double)v.t_in * v.c_in;
-        return a16_code(c.prec);    // SVCMI_PREC_BF16_A16 / _F16_A16 / _BF16X3_A16
+        if (c.prec == SVCMI_PREC_F16W2) bytes += 2.0 * (double)N * v.ksize * v.c_in;      // the lo image
+        return a16_code(c.prec);    // SVCMI_PREC_BF16_A16 / _F16_A16 / _BF16X3_A16 / _F16W2_A16
     }
-    return c.prec;
+    return fmt16_of(c.prec);        // (F16W2 without 16-bit activations: the plain fp16 kernel on the fp16 image)
 }
 
 void conv(Ctx& c, const CV& v) {
@@ -237,7 +241,7 @@ int conv_group(Ctx& c, const CV* vs, int count, bool dry = false) {
                 v.x16 = nullptr;
                 conv_desc(c, v, d[i], flops[i], bytes[i], total);
             }
-        if (lp) prec = a16 ? a16_code(c.prec) : c.prec;
+        if (lp) prec = a16 ? a16_code(c.prec) : fmt16_of(c.prec);
         if (!lp)
             for (int i = 0; i < count; ++i) {      // back to fp32 descriptors: a group runs on ONE kernel
                 CV v = vs[i];
@@ -259,7 +263,7 @@ void layernorm(Ctx& c, const float* x, const float* res, const float* g, const f
                int ldy, int gb_bs, void* y16 = nullptr) {
     if (!act16(c.prec)) y16 = nullptr;
     run(c, OP_LAYERNORM, 0.0, 4.0 * B * T * C * (2 + (res != nullptr)), [&] {
-        return svcmi_layernorm_f32(x, res, g, b, y, B, T, C, ldx, ldr, ldy, gb_bs, 1e-5f, y16, w16(c.prec, C), c.prec, c.stream);
+        return svcmi_layernorm_f32(x, res, g, b, y, B, T, C, ldx, ldr, ldy, gb_bs, 1e-5f, y16, w16(c.prec, C), fmt16_of(c.prec), c.stream);
     });
 }
 
@@ -267,7 +271,7 @@ void splitk_layernorm(Ctx& c, const float* part, int split, const float* bias, f
                       int T, int C, void* y16 = nullptr) {
     if (!act16(c.prec)) y16 = nullptr;
     run(c, OP_SPLITK_LN, 0.0, 4.0 * B * T * C * (3 + split), [&] {
-        return svcmi_splitk_layernorm_f32(part, split, bias, x, g, b, y, B, T, C, C, C, 1e-5f, y16, w16(c.prec, C), c.prec, c.stream);
+        return svcmi_splitk_layernorm_f32(part, split, bias, x, g, b, y, B, T, C, C, C, 1e-5f, y16, w16(c.prec, C), fmt16_of(c.prec), c.stream);
     });
 }
 
@@ -277,7 +281,7 @@ void attention(Ctx& c, const float* qkv, float* o, int B, int T, int heads, int 
     if (!act16(c.prec)) o16 = nullptr;
     run(c, OP_ATTENTION, 4.0 * B * T * (double)T * C, 16.0 * B * T * C, [&] {
         return svcmi_attention_f32(qkv, qkv + C, qkv + 2 * C, o, 3 * C, 3 * C, 3 * C, C, bs, bs, bs, (int64_t)T * C, B, T, heads, C / heads,
-                                   scale, rel_k, rel_v, window, lengths, o16, w16(c.prec, C), (int64_t)T * w16(c.prec, C), c.prec, c.stream);
+                                   scale, rel_k, rel_v, window, lengths, o16, w16(c.prec, C), (int64_t)T * w16(c.prec, C), fmt16_of(c.prec), c.stream);
     });
 }
 
@@ -285,7 +289,7 @@ void attention(Ctx& c, const float* qkv, float* o, int B, int T, int heads, int 
 void attention16(Ctx& c, const void* qkv16, float* o, void* o16, int B, int T, int heads, int C, float scale, const int32_t* lengths,
                  const float* rel_k = nullptr, const float* rel_v = nullptr, int window = 0, int fmt = -1) {
     const unsigned short* q = static_cast<const unsigned short*>(qkv16);
-    const int f = fmt >= 0 ? fmt : c.prec;
+    const int f = fmt16_of(fmt >= 0 ? fmt : c.prec);
     run(c, OP_ATTENTION16, 4.0 * B * T * (double)T * C, 10.0 * B * T * C, [&] {
         return svcmi_attention16(q, q + C, q + 2 * C, 3 * C, (int64_t)T * 3 * C, o, C, (int64_t)T * C, o16, C, (int64_t)T * C, B, T, heads, C / heads, scale,
                                  rel_k, rel_v, window, lengths, f, c.stream);
@@ -461,9 +465,9 @@ void prior_fwd(Ctx& c, const svcmi_synth_model& m, const svcmi_synth_io& io, flo
             if (att16) { q.y16 = qkv16; q.y16_fmt = att_prec; q.split_k = 1; }
             conv(c, q);
         }
-        if (att16) attention16(c, qkv16, att, att_prec == c.prec ? at16 : nullptr, B, T, m.n_heads, H, scale, io.lengths, L.rel_k, L.rel_v, m.enc_window, att_prec);
+        if (att16) attention16(c, qkv16, att, fmt16_of(att_prec) == fmt16_of(c.prec) ? at16 : nullptr, B, T, m.n_heads, H, scale, io.lengths, L.rel_k, L.rel_v, m.enc_window, att_prec);
         else attention(c, qkv, att, B, T, m.n_heads, H, scale, L.rel_k, L.rel_v, m.enc_window, io.lengths, at16);
-        { CV o = v; o.x = att; o.x16 = (att16 && att_prec != c.prec) ? nullptr : at16; o.w = &L.o; o.y = yo; o.y_bs = (int64_t)T * H; o.ldy = H; conv(c, o); }
+        { CV o = v; o.x = att; o.x16 = (att16 && fmt16_of(att_prec) != fmt16_of(c.prec)) ? nullptr : at16; o.w = &L.o; o.y = yo; o.y_bs = (int64_t)T * H; o.ldy = H; conv(c, o); }
         layernorm(c, x, yo, L.g1, L.b1, x2, B, T, H, H, H, H, 0, x16);
         {
             CV f = v; f.x = x2; f.x16 = x16; f.w = &L.f1; f.ksize = kf; f.pad = pl; f.act = SVCMI_ACT_RELU; f.lengths = io.lengths; f.mask_in = f.mask_out = true;
@@ -692,7 +696,7 @@ bool amp_stage_grouped(Ctx& c, const svcmi_synth_model& m, const svcmi_gen_stage
                     if (!h16) vs[j].x16 = nullptr;
                 }
                 run(c, OP_SNAKE_ALIAS_GROUP, 0.0, (h16 ? 4.0 + 2.0 * w16(c.prec, 1) : 8.0) * nb * B * L * cp, [&] {
-                    return svcmi_snake_alias_group_f32(px, h16 ? nullptr : py, pa, pb, m.filt, nb, B, (int32_t)L, cp, cp, h16 ? t1h : nullptr, c.prec,
+                    return svcmi_snake_alias_group_f32(px, h16 ? nullptr : py, pa, pb, m.filt, nb, B, (int32_t)L, cp, cp, h16 ? t1h : nullptr, fmt16_of(c.prec),
                                                        c.stream);
                 });
             };
@@ -828,10 +832,10 @@ void generator_fwd(Ctx& c, const svcmi_synth_model& m, const svcmi_synth_io& io,
 }
 
 bool synth_shapes_ok(const svcmi_synth_model& m, const svcmi_synth_io& io) {
-    if (m.precision < SVCMI_PREC_F32 || (m.precision > SVCMI_PREC_F16 && m.precision != SVCMI_PREC_MIXED)) return false;
+    if (m.precision < SVCMI_PREC_F32 || (m.precision > SVCMI_PREC_F16 && m.precision != SVCMI_PREC_MIXED && m.precision != SVCMI_PREC_F16W2)) return false;
     if (m.precision == SVCMI_PREC_MIXED)
         for (int i = 0; i < SVCMI_PREC_CLASSES; ++i)
-            if (m.class_prec[i] < SVCMI_PREC_F32 || m.class_prec[i] > SVCMI_PREC_F16) return false;
+            if ((m.class_prec[i] < SVCMI_PREC_F32 || m.class_prec[i] > SVCMI_PREC_F16) && m.class_prec[i] != SVCMI_PREC_F16W2) return false;
     return io.batch > 0 && io.t > 0 && m.n_enc >= 1 && m.n_enc <= SVCMI_MAX_ENC_LAYERS && m.n_flow >= 0 && m.n_flow <= SVCMI_MAX_FLOWS &&
            m.n_stages >= 1 && m.n_stages <= SVCMI_MAX_STAGES && m.hidden % 4 == 0 && m.inter % 8 == 0 && 2 * m.inter <= 3 * m.hidden &&
            m.upsample_input % 4 == 0 && (io.ppg_row_shift == 0 || io.ppg_row_shift == 1) && io.ppg_bstride % 4 == 0;

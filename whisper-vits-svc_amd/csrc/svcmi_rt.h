@@ -82,6 +82,7 @@ typedef _Float16 svcmi_f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 svcmi_f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ svcmi_u32x4 svcmi_as_u32x4(svcmi_f32x4 v) { return __builtin_bit_cast(svcmi_u32x4, v); }
 __device__ __forceinline__ float svcmi_bits_f32(unsigned u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ float svcmi_f16_bits_f32(unsigned h) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(h & 0xffffu)); }   // the fp16 value in the low 16 bits
 // (lo, hi) halves = round-to-nearest-even of (a, b): v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32
 __device__ __forceinline__ unsigned svcmi_cvt_pk_bf16(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(svcmi_f32x2{a, b}, svcmi_bf16x2));

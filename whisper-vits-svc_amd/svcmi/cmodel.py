@@ -20,11 +20,13 @@ def _weight(cw, ops, w, bias, prec, keep, a16=False):
     cw.n, cw.ldw = int(w.shape[0]), int(w.shape[1])
     cw.w16, cw.w16a, cw.ldw16, cw.prec16 = 0, 0, 0, 0
     if prec != PREC_F32 and w.dim() == 2 and w.is_contiguous():
-        img = ops.lp_weight(w, prec)
+        base = PREC_F16 if prec == _lib.PREC_F16W2 else prec               # f16w2: the launches without 16-bit activations are plain fp16
+        img = ops.lp_weight(w, base)
         cw.w16, cw.ldw16, cw.prec16 = img.data_ptr(), img.shape[1] // (2 if prec == PREC_BF16X3 else 1), prec
         keep.append(img)
         if a16:
-            img_a = ops.lp_weight(w, _lib.PREC_BF16X3_A16 if prec == PREC_BF16X3 else prec + 2)          # PREC_BF16_A16 / PREC_F16_A16 / PREC_BF16X3_A16
+            a16_code = {PREC_BF16X3: _lib.PREC_BF16X3_A16, _lib.PREC_F16W2: _lib.PREC_F16W2_A16}.get(prec, prec + 2)
+            img_a = ops.lp_weight(w, a16_code)          # PREC_BF16_A16 / PREC_F16_A16 / PREC_BF16X3_A16 / PREC_F16W2_A16 ([hi | lo] rows)
             cw.w16a = img_a.data_ptr()
             keep.append(img_a)
     keep.append(w)

@@ -143,7 +143,7 @@ class Ops:
                 if img is None:
                     n, ldw = w.shape
                     ldw16 = (ldw + 31) // 32 * 32
-                    img = torch.empty(n, (2 if prec in (PREC_BF16X3, _lib.PREC_BF16X3_A16) else 1) * ldw16, dtype=torch.int16, device=w.device)
+                    img = torch.empty(n, (2 if prec in (PREC_BF16X3, _lib.PREC_BF16X3_A16, _lib.PREC_F16W2_A16) else 1) * ldw16, dtype=torch.int16, device=w.device)
                     self._call("svcmi_pack_weights_lp", _ptr(w), n, ldw, prec, _ptr(img), ldw16, self._stream())
                     if self.on_gpu:            # packed on THIS thread's stream; other streams may read it right away
                         torch.cuda.current_stream().synchronize()
@@ -157,7 +157,7 @@ class Ops:
                 and (not d.x_row_shift or d.c_in % 32 == 0) and (d.flags >> 8) in (0, 1, 3, 4, 6, 9))
 
     def _to_lp(self, d, w, work):
-        prec = self.precision
+        prec = PREC_F16 if self.precision == _lib.PREC_F16W2 else self.precision        # f16w2 without 16-bit activations = plain fp16
         img = self.lp_weight(w, prec)
         d.w, d.ldw = img.data_ptr(), img.shape[1] // (2 if prec == PREC_BF16X3 else 1)
         work["bytes"] += d.n_out * d.ksize * d.c_in * (4.0 if prec == PREC_BF16X3 else 2.0) - 4.0 * d.n_out * d.ksize * d.c_in
@@ -380,6 +380,8 @@ class Ops:
                                     or (prec != PREC_BF16X3 and prec == _fmt16(x16.dtype))):
                 self._chk(x16)
                 prec = {PREC_BF16: _lib.PREC_BF16_A16, PREC_F16: _lib.PREC_F16_A16, PREC_BF16X3: _lib.PREC_BF16X3_A16}[prec]   # natural-order weight image
+                if self.precision == _lib.PREC_F16W2:
+                    prec = _lib.PREC_F16W2_A16                                     # ... of (hi, lo) fp16 pairs
                 img = self.lp_weight(w, prec)
                 d.x, d.w, d.ldx, d.x_bstride = x16.data_ptr(), img.data_ptr(), x16.stride(1), x16.stride(0)
             self._call("svcmi_conv_gemm_lp", ctypes.byref(d), prec, self._stream(), work=work)
