@@ -10,4 +10,4 @@ from .svc_inference import DummyRetrieval, IRetrieval, chunk_schedule, load_svc_
 from .vits.models import SynthesizerInfer  # noqa: F401
 from .whisper.inference import load_model as load_whisper_model  # noqa: F401
 
-__version__ = "0.1.0"
+__version__ = "0.4.0"
