@@ -587,7 +587,7 @@ def main():
             from svcmi import _lib
             code, cls = _lib.parse_precision(p)
             names = {v: k for k, v in _lib.PRECISIONS.items() if k in ("f32", "bf16x3", "bf16", "f16", "f16w2")}
-            return "mixed per-layer policy (" + ", ".join(f"{k}={names[cls[i]]}" for k, i in sorted(_lib.CLASS_NAMES.items(), key=lambda kv: kv[1]) if i < 6 or k == "encattn") + ")"
+            return "mixed per-layer policy (" + ", ".join(f"{k}={names[cls[i]]}" for k, i in sorted(_lib.CLASS_NAMES.items(), key=lambda kv: kv[1])) + ")"
         return p
     prec_txt = ", ".join(f"{n} {'fp32' if norm(p) is None else spell(p) + ' GEMM operands / fp32 accumulate'}"
                          for n, p in (("Whisper", wprec), ("synthesizer", sprec)) if not (n == "Whisper" and not need_whisper))

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SVCMI_ABI_VERSION 19
+#define SVCMI_ABI_VERSION 20
 
 enum svcmi_status { SVCMI_OK = 0, SVCMI_EINVAL = -1, SVCMI_EUNSUPPORTED = -2, SVCMI_EALIGN = -3 };
 
@@ -262,6 +262,15 @@ typedef struct svcmi_snake_conv_desc {
 } svcmi_snake_conv_desc;
 int svcmi_snake_conv_group_f32(const svcmi_snake_conv_desc* descs, int32_t count, const float* filt, int32_t batch,
                                int32_t len, int32_t c, int32_t ld, void* stream);
+
+/* The grouped half-step with its convolution on the fp16 matrix cores -- the narrow stages' member of the per-layer mixed-precision
+ * policy (classes amp3 / amp4).  `precision`: SVCMI_PREC_F16 (weights rounded to fp16, one MFMA per tile) or SVCMI_PREC_F16W2 (weights as
+ * hi + lo fp16, two MFMAs: only the activated input is rounded).  x / res / y / bias / weights are the SAME fp32 tensors the _f32 entry
+ * takes (the block converts its problem's weights to MFMA fragment order in LDS); accumulation, epilogue and SnakeAlias are fp32.
+ * 10 and 20 channels; y, res and bias 16-byte aligned. */
+int svcmi_snake_conv_lp_supported(int32_t c, int32_t ld, int32_t ksize, int32_t dilation, int32_t precision);
+int svcmi_snake_conv_group_lp(const svcmi_snake_conv_desc* descs, int32_t count, const float* filt, int32_t batch,
+                              int32_t len, int32_t c, int32_t ld, int32_t precision, void* stream);
 
 /* A WHOLE AMP block (vits_decoder/bigv.py:22-58, AMPBlock.forward :50-58) of a narrow stage as one launch, for up to 3 blocks of a stage
  * (3 / 7 / 11 taps; blockIdx.z) that share the stage input x:

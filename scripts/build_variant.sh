@@ -6,7 +6,9 @@ NAME=$1; shift
 cd "$(dirname "$0")/../whisper-vits-svc_amd"
 mkdir -p _obj/$NAME svcmi/exp
 for f in csrc/*.hip; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c $f -o _obj/$NAME/$(basename $f).o &
+  EXTRA=""
+  [ "$(basename $f)" = amp_fused.hip ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form=1"      # (build.py FILE_FLAGS)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $EXTRA "$@" -c $f -o _obj/$NAME/$(basename $f).o &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o svcmi/exp/libsvcmi_$NAME.so _obj/$NAME/*.o

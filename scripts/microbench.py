@@ -268,6 +268,30 @@ def main():
                         print(f"ampgroup C={C} n={n} d={d} B={B} amp_u={u}: {us:8.1f} us  {B * fl / us / 1e6:6.1f} TF/s", flush=True)
                 ops.lib.svcmi_tune_set(b"amp_u", 0)
         ops.lib.svcmi_tune_set(b"amp_tt", 0)
+    if "amplp" in what:       # the grouped half-step: fp32 vector kernel vs the fp16 matrix-core variants, both activation-phase forms
+        filt = torch.tensor([0.00202896, 0.00938947, -0.02554346, -0.05765738, 0.12857258, 0.44320980, 0.44320980,
+                             0.12857258, -0.05765738, -0.02554346, 0.00938947, 0.00202896], device="cuda")
+        for (C, n) in ((20, 160000), (10, 320000)):
+            ld = (C + 3) // 4 * 4
+            fl = sum(2.0 * n * C * C * k for k in (3, 7, 11))
+            for B in (1, 4):
+                probs = [dict(x=torch.randn(B, n, ld, device="cuda"), alpha_log=torch.randn(ld, device="cuda") * 0.3,
+                              beta_log=torch.randn(ld, device="cuda") * 0.3, w=PW.pack_conv(torch.randn(C, C, k) / math.sqrt(C * k), ld, ld).cuda(),
+                              bias=torch.randn(ld, device="cuda"), ksize=k, dilation=1, res=torch.randn(B, n, ld, device="cuda"),
+                              out=torch.empty(B, n, ld, device="cuda")) for k in (3, 7, 11)]
+                for d in (1, 5):
+                    for pr in probs:
+                        pr["dilation"] = d
+                    for u in (-1, 1):
+                        ops.lib.svcmi_tune_set(b"amp_u", u)
+                        ref = None
+                        for prec in (None, "f16", "f16w2"):
+                            us = timeit(lambda: ops.snake_conv_group(probs, filt, c=C, precision=prec))
+                            out = probs[2]["out"][..., :C].clone()
+                            ref = out if ref is None else ref
+                            print(f"amplp C={C} n={n} B={B} d={d} amp_u={u:2d} {str(prec):6s}: {us:8.1f} us  {B * fl / us / 1e6:6.1f} TF/s  "
+                                  f"max diff to fp32 {float((out - ref).abs().max()):.1e}", flush=True)
+                ops.lib.svcmi_tune_set(b"amp_u", 0)
     if "small" in what:       # the short-K / few-tile GEMMs of the prior encoder, flow and widest decoder stage
         sp = (1, 0, 2, 3, 4)
         for k, d in ((3, 1), (7, 3), (11, 5)):

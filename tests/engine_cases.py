@@ -114,7 +114,7 @@ def check_mixed_precision_policy(ops, device, T=3, B=1):
     outs, traces = {}, {}
     try:
         for pol in (None, "f16", "mixed:" + ",".join(f"{k}=f16" for k in _lib.CLASS_NAMES), "bf16x3",
-                    "mixed:" + ",".join(f"{k}=bf16x3" for k in _lib.CLASS_NAMES), "mixed", "mixed:enc=f32,flow=f32,ups=f32,amp0=f32,amp1=f32,amp2=f32"):
+                    "mixed:" + ",".join(f"{k}=bf16x3" for k in _lib.CLASS_NAMES), "mixed", "mixed:" + ",".join(f"{k}=f32" for k in _lib.CLASS_NAMES)):
             m.precision = pol
             ops.trace_begin()
             outs[pol] = m.inference(d["ppg"], d["vec"], d["pit"], d["spk"], d["lengths"], src, noise=d["enc_noise"]).clone()
@@ -133,6 +133,9 @@ def check_mixed_precision_policy(ops, device, T=3, B=1):
     assert not torch.equal(outs["mixed"], outs["f16"]) and not torch.equal(outs["mixed"], outs["bf16x3"])
     ran = precs(traces["mixed"])
     assert _lib.PREC_BF16X3 in ran and (_lib.PREC_F16 in ran or _lib.PREC_F16_A16 in ran), ran      # both families in ONE pass
+    # the narrow stages (classes amp3 / amp4 = f16w2 by default): their half-steps ran on the fp16 matrix cores, and only there
+    assert traces["mixed"].get("svcmi_snake_conv_group_lp", {}).get("launches", 0) >= 12, {k: v["launches"] for k, v in traces["mixed"].items()}
+    assert "svcmi_snake_conv_group_lp" not in traces[None] and "svcmi_snake_conv_group_lp" not in traces["bf16x3"]
     for bad in ("mixed:decoder=f16", "mixed:enc=int8", "fp8"):
         with pytest.raises(_lib.SvcmiError):
             _lib.parse_precision(bad)

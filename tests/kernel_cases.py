@@ -671,6 +671,63 @@ def check_snake_conv_group(ops, device, c=20, ld=20, B=2, n=300):
             ops.lib.svcmi_tune_set(b"amp_u", 0)
 
 
+def check_snake_conv_group_lp(ops, device, c=20, ld=20, B=2, n=300, precision="f16"):
+    """The grouped half-step with its convolution on the fp16 matrix cores (svcmi_snake_conv_group_lp) against the SAME arithmetic in
+    torch: S = SnakeAlias(x) rounded to fp16, weights rounded to fp16 ("f16") or kept as hi + lo fp16 ("f16w2"), products accumulated
+    wide -- what is left is the fp32 accumulation order (1e-5) -- and, loosely, against the fp32 kernel (the error class of the mode).
+    3 / 7 / 11 taps x dilations 1 / 5 / 3, residual, alpha, accumulate, sequence ends inside a tile, both activation-phase variants."""
+    g = _g(900 + c + n)
+    filt_c = W.kaiser_sinc_filter().view(-1)
+    filt = filt_c.to(device)
+    probs, want, want32 = [], [], []
+    for i, (k, d) in enumerate(((3, 1), (11, 5), (7, 3))):
+        x = torch.zeros(B, n, ld)
+        x[..., :c] = torch.randn(B, n, c, generator=g) * 1.5
+        res = torch.zeros(B, n, ld)
+        res[..., :c] = torch.randn(B, n, c, generator=g)
+        y0 = torch.zeros(B, n, ld)
+        y0[..., :c] = torch.randn(B, n, c, generator=g)
+        al, be = torch.zeros(ld), torch.zeros(ld)
+        al[:c], be[:c] = torch.randn(c, generator=g) * 0.3, torch.randn(c, generator=g) * 0.3
+        w = torch.randn(c, c, k, generator=g) / math.sqrt(c * k)
+        bias = torch.randn(c, generator=g)
+        acc = i == 1
+        s = O.snake_alias(x[..., :c].transpose(1, 2), al[:c], be[:c], filt_c)
+        # the rounded operand from the library's own SnakeAlias (the fused tile runs the same operation sequence, csrc/snake_math.h): an
+        # activation that differs from the oracle's in the last fp32 bit can land on the other side of an fp16 rounding boundary, and one
+        # such flip is 2^-11 |s| |w| ~ 2e-4 -- the oracle's S (checked against the library's to 1e-5 by check_snake) only feeds the loose bound
+        s_lib = ops.snake_alias(x.to(device), al.to(device), be.to(device), filt).cpu()[..., :c].transpose(1, 2)
+        s16 = s_lib.half().double()
+        w_hi = w.half()
+        wq = w_hi.double() + ((w - w_hi.float()).half().double() if precision == "f16w2" else 0.0)
+        ref = F.conv1d(s16, wq, bias.double(), dilation=d, padding=(k - 1) * d // 2).transpose(1, 2)
+        ref = (ref + res[..., :c].double()) * 0.5 + (y0[..., :c].double() if acc else 0.0)
+        want.append(ref.float())
+        ref32 = F.conv1d(s, w, bias, dilation=d, padding=(k - 1) * d // 2).transpose(1, 2)
+        want32.append((ref32 + res[..., :c]) * 0.5 + (y0[..., :c] if acc else 0.0))
+        probs.append(dict(x=x.to(device), alpha_log=al.to(device), beta_log=be.to(device), w=PW.pack_conv(w, ld, ld).to(device),
+                          bias=PW.pad_vec(bias, ld).to(device), ksize=k, dilation=d, res=res.to(device), alpha=0.5, accumulate=acc, y0=y0))
+    code = PRECISIONS[precision]
+    for k, d in ((3, 1), (7, 3), (11, 5)):
+        assert ops.lib.svcmi_snake_conv_lp_supported(c, ld, k, d, code)
+    assert not ops.lib.svcmi_snake_conv_lp_supported(40, 40, 3, 1, code) and not ops.lib.svcmi_snake_conv_lp_supported(c, ld, 3, 1, 2)
+    for amp_u in (-1, 1):
+        assert ops.lib.svcmi_tune_set(b"amp_u", amp_u) == 0
+        try:
+            for n_prob in (1, 3):
+                for pr in probs:
+                    pr["out"] = pr["y0"].clone().to(device) if pr["accumulate"] else torch.full((B, n, ld), 7.0).to(device)
+                got = ops.snake_conv_group(probs[:n_prob], filt, c=c, precision=precision)
+                for j in range(n_prob):
+                    _close(got[j][..., :c], want[j], 2e-5, f"snake_conv_group_lp {precision} c={c} amp_u={amp_u} problem {j}")
+                    err = float((got[j][..., :c].cpu() - want32[j]).abs().max())
+                    assert 0 < err < (2e-3 if precision == "f16w2" else 4e-3) * max(1.0, float(want32[j].abs().max())), (precision, j, err)
+                    if ld > c:
+                        assert float(got[j][..., c:].abs().max()) == 0.0
+        finally:
+            ops.lib.svcmi_tune_set(b"amp_u", 0)
+
+
 def check_amp_block_group(ops, device, c=10, ld=12, B=2, n=700, variants=(0,), nblocks=3):
     """A whole AMP block per launch (svcmi_amp_block_group_f32: the tile stays in LDS over the six half-steps, halos recomputed) equals
     the chain of half-step launches (svcmi_snake_conv_f32) bit for bit -- every tile geometry of the kernel, sequence ends inside the

@@ -104,6 +104,12 @@ def test_snake_conv_group(ops, c, ld, n):
     K.check_snake_conv_group(ops, "cuda", c=c, ld=ld, B=1 if n > 1000 else 2, n=n)
 
 
+@pytest.mark.parametrize("precision", ["f16", "f16w2"])
+@pytest.mark.parametrize("c,ld,n", [(10, 12, 300), (20, 20, 300), (20, 20, 1), (10, 12, 257), (20, 20, 160000), (10, 12, 320000)])
+def test_snake_conv_group_on_the_fp16_matrix_cores(ops, c, ld, n, precision):
+    K.check_snake_conv_group_lp(ops, "cuda", c=c, ld=ld, B=1 if n > 1000 else 2, n=n, precision=precision)
+
+
 @pytest.mark.parametrize("c,ld,n,B", [(10, 12, 700, 2), (10, 12, 33, 2), (10, 12, 320000, 1), (20, 20, 600, 2), (20, 20, 1, 1), (20, 20, 160000, 1),
                                       (10, 12, 40000, 4), (20, 20, 20000, 4)])
 def test_amp_block_group_equals_the_half_step_chain(ops, c, ld, n, B):

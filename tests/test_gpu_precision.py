@@ -157,7 +157,7 @@ def test_configs2_batch16_flow_decoder(ops, clip10, mode):
 # fp16 waveform error for 2 % of the FLOPs, the prior encoder a quarter (and all of it on outlier weights), the AMP convolutions and
 # the flow -- 90 % of the FLOPs -- the rest in equal small parts.  The sweep below measures candidate policies on configs[2]
 # (error of item 0 against the fp32 ORACLE, all 16 items against the fp32 engine, time per step) and on the outlier-stress weights.
-MIXED_POLICIES = ["mixed", "mixed:amp0=f16w2", "mixed:amp0=f16w2,amp1=f16w2,amp2=f16w2", "mixed:amp1=f16w2,amp2=f16w2", "mixed:encattn=f16", "mixed:amp0=f16", "mixed:amp1=bf16x3", "mixed:amp1=bf16x3,amp2=bf16x3", "mixed:flow=bf16x3",
+MIXED_POLICIES = ["mixed", "mixed:amp3=f16,amp4=f16", "mixed:amp3=f32,amp4=f32", "mixed:amp0=f16w2", "mixed:amp0=f16w2,amp1=f16w2,amp2=f16w2", "mixed:amp1=f16w2,amp2=f16w2", "mixed:encattn=f16", "mixed:amp0=f16", "mixed:amp1=bf16x3", "mixed:amp1=bf16x3,amp2=bf16x3", "mixed:flow=bf16x3",
                   "mixed:flow=bf16x3,amp1=bf16x3", "mixed:enc=f16,ups=f16,amp0=f16"]
 MIXED_BOUND = 5e-4          # waveform max-abs of the DEFAULT policy vs the fp32 oracle on configs[2] (north_star bar: 1e-3)
 

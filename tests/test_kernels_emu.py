@@ -94,6 +94,11 @@ def test_snake_conv_group(ops, c, ld):
     K.check_snake_conv_group(ops, "cpu", c=c, ld=ld, B=2, n=150)
 
 
+@pytest.mark.parametrize("c,ld,n,precision", [(10, 12, 150, "f16"), (20, 20, 300, "f16w2"), (20, 20, 40, "f16"), (10, 12, 290, "f16w2")])
+def test_snake_conv_group_on_the_fp16_matrix_cores(ops, c, ld, n, precision):
+    K.check_snake_conv_group_lp(ops, "cpu", c=c, ld=ld, B=2 if n < 200 else 1, n=n, precision=precision)
+
+
 @pytest.mark.parametrize("c,ld,n,variants,nblocks", [(10, 12, 700, (1, 3), 3), (10, 12, 40, (1,), 2), (20, 20, 600, (1, 4), 3), (20, 20, 1, (1,), 1)])
 def test_amp_block_group_equals_the_half_step_chain(ops, c, ld, n, variants, nblocks):
     K.check_amp_block_group(ops, "cpu", c=c, ld=ld, B=2 if n < 100 else 1, n=n, variants=variants, nblocks=nblocks)

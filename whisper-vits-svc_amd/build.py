@@ -13,6 +13,12 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "svcmi", "libsvcmi.so")
 
 
+# Per-file compiler flags.  amp_fused.hip: MFMA accumulators in ARCHITECTURAL registers -- in snake_conv16_group_kernel they are dead
+# during the activation phase that sets the kernel's VGPR count, while accumulation registers come ON TOP of it in the unified file
+# (117 + 32 -> occupancy 3 instead of 4).  The file holds no other matrix-core kernel.
+FILE_FLAGS = {"amp_fused.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+
+
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
@@ -41,7 +47,7 @@ def build_hip(force=False, verbose=False):
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
-        cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+        cmd = [hipcc] + flags + FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

@@ -37,9 +37,16 @@ struct AmpArgs {
     float alpha;
 };
 
+// One value of the activated tile: fp32 (row stride LS floats) or, for the 16-bit matrix-core variant below, fp16 (row stride LS halves)
+template <bool H16, int LS>
+__device__ __forceinline__ void tile_store(float* S, int row, int ch, float v) {
+    if constexpr (H16) reinterpret_cast<unsigned short*>(S)[row * LS + ch] = (unsigned short)svcmi_cvt_pk_f16(v, 0.f);
+    else S[row * LS + ch] = v;
+}
+
 // S = SnakeAlias(x) for the rows [t_blk - halo, t_blk - halo + rows) of one batch item: zero outside [0, n) (the
 // convolution's zero padding) and in the pad channels.  Shared by the AMP half-step and the output layer.
-template <int CP, int CR, int LS>
+template <int CP, int CR, int LS, bool H16 = false>
 __device__ __forceinline__ void snake_tile(float* S, const float* xb, const float* alpha_log, const float* beta_log,
                                            const float* filt, int n, int ld, int t_blk, int halo, int rows, int tid) {
     struct { const float* alpha_log; const float* beta_log; const float* filt; } p = {alpha_log, beta_log, filt};
@@ -71,7 +78,7 @@ __device__ __forceinline__ void snake_tile(float* S, const float* xb, const floa
             }
 #pragma unroll
             for (int r = 0; r < RT; ++r)
-                if (r0 + r < rows) S[(r0 + r) * LS + ch] = out[r];
+                if (r0 + r < rows) tile_store<H16, LS>(S, r0 + r, ch, out[r]);
         }
 }
 
@@ -85,7 +92,7 @@ struct UTile {
     static constexpr int LU = 2 * CP + 2;
 };
 
-template <int CP, int CR, int LS, int MAXI>
+template <int CP, int CR, int LS, int MAXI, bool H16 = false>
 __device__ __forceinline__ void snake_tile_u(float* smem, const float* xb, const float* alpha_log, const float* beta_log,
                                              const float* filt, int n, int ld, int t_blk, int halo, int rows, int tid) {
     constexpr int LU = UTile<CP>::LU;
@@ -153,7 +160,7 @@ __device__ __forceinline__ void snake_tile_u(float* smem, const float* xb, const
             const int ch = item % CP, r0 = (item / CP) * RT;
 #pragma unroll
             for (int r = 0; r < RT; ++r)
-                if (r0 + r < rows) smem[(r0 + r) * LS + ch] = outs[q][r];
+                if (r0 + r < rows) tile_store<H16, LS>(smem, r0 + r, ch, outs[q][r]);
         }
     }
 }
@@ -284,6 +291,157 @@ __global__ __launch_bounds__(TPB) void snake_conv_group_u_kernel(AmpGroupArgs g)
     static_assert(((TL::ROWS + RT - 1) / RT) * CP <= 4 * TPB, "snake_tile_u keeps at most 4 work items per thread in registers");
     __shared__ __attribute__((aligned(16))) float S[NU > NS ? NU : NS];
     snake_conv_body<CP, CR, 0, G, TT, true>(g.p[blockIdx.z], S);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same half-step with the convolution on the 16-bit matrix cores (per-layer mixed precision, classes amp3 / amp4 = f16 | f16w2).
+// The argument at the top of this file is about the fp32 MFMA, which runs at the VALU rate; v_mfma_f32_16x16x32_f16 is 8x that, so
+// here a tile padded from 20 to 32 output channels and from 20 to 24 values per tap still costs a fifth of the VALU convolution
+// (which is half of the fp32 kernel's time: profiles/r04n_amp_phase_timing.log).  Formulation, per block of 256 output rows:
+//   * S = SnakeAlias(x) of the tile goes to LDS as fp16, row stride 48 bytes (16 consecutive rows x 16 bytes cover the 64 banks once);
+//   * the weights of this problem are converted ONCE per block from the fp32 image into MFMA fragment order in LDS: fragment
+//     (k-step, co-tile, term) = 64 lanes x 16 bytes; TERMS = 2 keeps hi = fp16(w) and lo = fp16(w - hi) (weights exact to 2^-22, two
+//     MFMAs per tile: the f16w2 class), TERMS = 1 only hi;
+//   * D = W * S^T: the A operand is a weight fragment (row = output channel), the B operand 8 consecutive input channels of one S row
+//     (col = time), K walks (tap, 8-channel slice) pairs, 4 per instruction -- so a lane ends up with 4 CONSECUTIVE output channels
+//     of one time step and the epilogue (bias, residual, alpha, accumulate) is float4 loads / stores;
+//   * a wave owns 4 time tiles of 16 rows and all output channels: every weight fragment read from LDS feeds 4 MFMAs.
+// fp32 in, fp32 out, fp32 accumulation: only the operands of the products are rounded.
+template <int CP, int CR, int TERMS>
+struct Amp16 {
+    static constexpr int CK = (CR + 7) / 8;                  // 8-channel K slices per tap
+    static constexpr int LSH = 24;                           // S row stride in halves
+    static constexpr int NCT = (CR + 15) / 16;               // output-channel tiles
+    static constexpr int TB = 256;                           // output rows per block (= the fp32 kernels' default tiles)
+    static constexpr int ROWS = TB + 10 * DMAX;
+    static constexpr int MAXSTEPS = (11 * CK + 3) / 4;       // MFMA K-steps at 11 taps
+    static constexpr int S_FLOATS = (ROWS * LSH / 2 + 3) / 4 * 4;
+    static constexpr int U_FLOATS = ((ROWS + 5) * UTile<CP>::LU + 3) / 4 * 4;
+    static constexpr int W_FLOATS = MAXSTEPS * NCT * TERMS * 64 * 4;
+    static_assert(CK * 8 <= LSH && CP <= CK * 8 && CP + 4 >= CK * 8, "pad columns [CP, 8 CK) are one 8-byte store per row");
+};
+
+template <int CP, int CR, int TERMS, bool UT>
+__device__ __forceinline__ void snake_conv16_body(const AmpArgs& p, float* smem, float* wl) {
+    using TL = Amp16<CP, CR, TERMS>;
+    constexpr int CK = TL::CK, LSH = TL::LSH, NCT = TL::NCT, TB = TL::TB;
+    const int KS = p.ks;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = SVCMI_UNIFORM((int)(tid >> 6));
+    const int b = blockIdx.y;
+    const int n = p.n, ld = p.ld, d = p.dil;
+    const int halo = (KS - 1) * d / 2;
+    const int t_blk = blockIdx.x * TB;
+    const int rows = TB + 2 * halo;
+    const float* xb = p.x + (long long)b * n * ld;
+    const int nsteps = (KS * CK + 3) / 4;
+
+    // ---- weights -> fp16 fragments in LDS (slices past the last tap and channels past CR are zero).  With the up-sampled tile (UT) the
+    // fragments live in the part of the U region that S does not cover, so they are written AFTER the activation phase has consumed U
+    svcmi_u32x4* wf = reinterpret_cast<svcmi_u32x4*>(wl);
+    auto pack_weights = [&] {
+    for (int u = tid; u < nsteps * NCT * 64; u += TPB) {
+        const int l = u & 63, f = u >> 6;
+        const int ct = f % NCT, step = f / NCT;
+        const int co = ct * 16 + (l & 15), s = 4 * step + (l >> 4);
+        const int tap = s / CK, cb = s - tap * CK;
+        float v[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ci0 = cb * 8 + 4 * h;
+            float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (co < CR && tap < KS && ci0 < CR) q = *reinterpret_cast<const float4*>(p.w + (long long)co * p.ldw + tap * CP + ci0);
+            v[4 * h] = q.x;
+            v[4 * h + 1] = ci0 + 1 < CR ? q.y : 0.f;
+            v[4 * h + 2] = ci0 + 2 < CR ? q.z : 0.f;
+            v[4 * h + 3] = ci0 + 3 < CR ? q.w : 0.f;
+        }
+        svcmi_u32x4 hi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hi[e] = svcmi_cvt_pk_f16(v[2 * e], v[2 * e + 1]);
+        wf[(f * TERMS) * 64 + l] = hi;
+        if constexpr (TERMS == 2) {
+            svcmi_u32x4 lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                lo[e] = svcmi_cvt_pk_f16(v[2 * e] - svcmi_f16_bits_f32(hi[e]), v[2 * e + 1] - svcmi_f16_bits_f32(hi[e] >> 16));
+            wf[(f * TERMS + 1) * 64 + l] = lo;
+        }
+    }
+    };
+    if constexpr (!UT) pack_weights();
+
+    // ---- S = SnakeAlias(x) as fp16 rows; the pad columns [CP, 8 CK) meet zero weights but must not hold NaN patterns
+    if constexpr (UT) snake_tile_u<CP, CR, LSH, (((TL::ROWS + RT - 1) / RT) * CP + TPB - 1) / TPB, true>(smem, xb, p.alpha_log, p.beta_log, p.filt, n, ld, t_blk, halo, rows, tid);
+    else snake_tile<CP, CR, LSH, true>(smem, xb, p.alpha_log, p.beta_log, p.filt, n, ld, t_blk, halo, rows, tid);
+    if constexpr (UT) pack_weights();
+    unsigned short* S16 = reinterpret_cast<unsigned short*>(smem);
+    if constexpr (CP < CK * 8)
+        for (int r = tid; r < rows; r += TPB) *reinterpret_cast<svcmi_u32x2*>(S16 + r * LSH + CP) = svcmi_u32x2{0u, 0u};
+    __syncthreads();
+
+    // ---- D[co][t] += W[co][(tap, ci)] * S[t + tap * d][ci] on v_mfma_f32_16x16x32_f16
+    constexpr int NT = 4;                                   // time tiles per wave
+    const int tq = lane & 15, kq = lane >> 4;
+    svcmi_f32x4 acc[NT][NCT];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc[tt][ct] = svcmi_f32x4{0.f, 0.f, 0.f, 0.f};
+    const int row0 = wave * (16 * NT) + tq;                 // S row of this lane's time step in tile 0 at tap 0
+    for (int step = 0; step < nsteps; ++step) {
+        const int s = 4 * step + kq;
+        int tap = s / CK;
+        const int cb = s - tap * CK;
+        tap = tap < KS ? tap : KS - 1;                      // (a slice past the last tap: any finite row, its weights are zero)
+        const unsigned short* sp = S16 + (row0 + tap * d) * LSH + cb * 8;
+        svcmi_u32x4 bf[NT], af[NCT][TERMS];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int tm = 0; tm < TERMS; ++tm) af[ct][tm] = wf[((step * NCT + ct) * TERMS + tm) * 64 + lane];
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) bf[tt] = *reinterpret_cast<const svcmi_u32x4*>(sp + tt * 16 * LSH);
+#pragma unroll
+        for (int tm = 0; tm < TERMS; ++tm)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) acc[tt][ct] = svcmi_mfma16_16x16x32<true>(af[ct][tm], bf[tt], acc[tt][ct]);
+    }
+
+    // ---- epilogue: lane = (time tq of the tile, output channels ct * 16 + 4 kq .. + 3)
+    float* yb = p.y + (long long)b * n * ld;
+    const float* rb = p.res ? p.res + (long long)b * n * ld : nullptr;
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+        const int t = t_blk + wave * (16 * NT) + tt * 16 + tq;
+        asm volatile("" ::: "memory");      // one time tile's residual / old-output loads in flight at a time (all of them hoisted: 190 VGPRs)
+        if (t >= n) continue;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const int co4 = ct * 16 + 4 * kq;
+            if (co4 >= CP) continue;
+            float v[4] = {acc[tt][ct][0], acc[tt][ct][1], acc[tt][ct][2], acc[tt][ct][3]};
+            float* yr = yb + (long long)t * ld + co4;
+            float4 bq = make_float4(0.f, 0.f, 0.f, 0.f), rq = bq, oq = bq;
+            if (p.bias) bq = *reinterpret_cast<const float4*>(p.bias + co4);
+            if (rb) rq = *reinterpret_cast<const float4*>(rb + (long long)t * ld + co4);
+            if (p.accumulate) oq = *reinterpret_cast<const float4*>(yr);
+            const float bv[4] = {bq.x, bq.y, bq.z, bq.w}, rv[4] = {rq.x, rq.y, rq.z, rq.w}, ov[4] = {oq.x, oq.y, oq.z, oq.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = co4 + e < CR ? (v[e] + bv[e] + rv[e]) * p.alpha + ov[e] : 0.f;
+            *reinterpret_cast<float4*>(yr) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+template <int CP, int CR, int TERMS, bool UT>
+__global__ __launch_bounds__(TPB) void snake_conv16_group_kernel(AmpGroupArgs g) {
+    using TL = Amp16<CP, CR, TERMS>;
+    constexpr int NSW = TL::S_FLOATS + TL::W_FLOATS;        // S rows, then the weight fragments; the U tile (if any) lies over both
+    __shared__ __attribute__((aligned(16))) float smem[UT && TL::U_FLOATS > NSW ? TL::U_FLOATS : NSW];
+    snake_conv16_body<CP, CR, TERMS, UT>(g.p[blockIdx.z], smem, smem + TL::S_FLOATS);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -509,6 +667,50 @@ extern "C" int svcmi_snake_conv_group_f32(const svcmi_snake_conv_desc* descs, in
     if (tt == 4) launch_amp_group<4>(g, count, batch, len, c, stream);
     else if (tt == 1) launch_amp_group<1>(g, count, batch, len, c, stream);
     else launch_amp_group<2>(g, count, batch, len, c, stream);
+    return SVCMI_LAST_ERROR();
+}
+
+// The grouped half-step with the convolution on the fp16 matrix cores (snake_conv16_group_kernel): `precision` = SVCMI_PREC_F16 (weights
+// rounded to fp16) or SVCMI_PREC_F16W2 (weights as hi + lo fp16, two MFMAs per tile); activations fp16, accumulation / epilogue / I/O fp32.
+extern "C" int svcmi_snake_conv_lp_supported(int32_t c, int32_t ld, int32_t ksize, int32_t dilation, int32_t precision) {
+    return svcmi_snake_conv_supported(c, ld, ksize, dilation) && c <= 20 && (precision == SVCMI_PREC_F16 || precision == SVCMI_PREC_F16W2);
+}
+
+template <int CP, int CR, int TERMS>
+static void launch_amp16_group(const AmpGroupArgs& g, int count, int batch, int len, bool ut, void* stream) {
+    constexpr int TB = Amp16<CP, CR, TERMS>::TB;
+    const dim3 grid((unsigned)((len + TB - 1) / TB), (unsigned)batch, (unsigned)count);
+    if (ut) SVCMI_LAUNCH((snake_conv16_group_kernel<CP, CR, TERMS, true>), grid, dim3(TPB), 0, stream, g);
+    else SVCMI_LAUNCH((snake_conv16_group_kernel<CP, CR, TERMS, false>), grid, dim3(TPB), 0, stream, g);
+}
+
+extern "C" int svcmi_snake_conv_group_lp(const svcmi_snake_conv_desc* descs, int32_t count, const float* filt, int32_t batch,
+                                         int32_t len, int32_t c, int32_t ld, int32_t precision, void* stream) {
+    if (!descs || !filt || count < 1 || count > AMP_GROUP || batch <= 0 || len <= 0) return SVCMI_EINVAL;
+    if (batch > 65535) return SVCMI_EUNSUPPORTED;
+    int order[AMP_GROUP] = {0, 1, 2};
+    for (int i = 0; i < count; ++i)           // most taps first (blockIdx.z = 0 is dispatched first)
+        for (int j = i + 1; j < count; ++j)
+            if (descs[order[j]].ksize > descs[order[i]].ksize) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
+    AmpGroupArgs g;
+    for (int i = 0; i < count; ++i) {
+        const svcmi_snake_conv_desc& d = descs[order[i]];
+        if (!d.x || !d.w || !d.y || !d.alpha_log || !d.beta_log || d.x == d.y) return SVCMI_EINVAL;
+        if (!svcmi_snake_conv_lp_supported(c, ld, d.ksize, d.dilation, precision)) return SVCMI_EUNSUPPORTED;
+        if (d.ldw < d.ksize * ld || d.ldw % 4 != 0) return SVCMI_EINVAL;
+        if (((uintptr_t)d.w & 15) || ((uintptr_t)d.x & 7) || ((uintptr_t)d.y & 15) || ((uintptr_t)d.res & 15) || ((uintptr_t)d.bias & 15)) return SVCMI_EALIGN;
+        AmpArgs& a = g.p[i];
+        a.x = d.x; a.w = d.w; a.bias = d.bias; a.res = d.res; a.y = d.y; a.alpha_log = d.alpha_log; a.beta_log = d.beta_log;
+        a.filt = filt; a.n = len; a.ld = ld; a.ldw = d.ldw; a.dil = d.dilation; a.accumulate = d.accumulate; a.alpha = d.alpha;
+        a.ks = d.ksize;
+    }
+    for (int i = count; i < AMP_GROUP; ++i) g.p[i] = g.p[0];
+    // the up-sampled-tile variant of the activation phase (knob "amp_u" as for the fp32 kernels): here it wins at both widths and every
+    // batch size, because the weight fragments share the U tile's LDS (profiles/r04p_amplp.log: 50 vs 55 us at 20 channels, 49 vs 59 at 10)
+    const bool ut = g_amp_u >= 0;
+    const bool w2 = precision == SVCMI_PREC_F16W2;
+    if (c == 10) { if (w2) launch_amp16_group<12, 10, 2>(g, count, batch, len, ut, stream); else launch_amp16_group<12, 10, 1>(g, count, batch, len, ut, stream); }
+    else { if (w2) launch_amp16_group<20, 20, 2>(g, count, batch, len, ut, stream); else launch_amp16_group<20, 20, 1>(g, count, batch, len, ut, stream); }
     return SVCMI_LAST_ERROR();
 }
 

@@ -23,19 +23,22 @@ int g_amp_grouped = 1;     // tuning / test knob ("amp_grouped", 0 | 1): 0 force
 // the half-step chain in every tile geometry (10 channels: 445 vs 411 us at B = 1, 5.96 vs 5.13 ms at B = 16; 20 channels: 659 vs 552 us,
 // 9.3 vs 6.2 ms) -- bit-identical, kept as a tested alternative
 int g_amp_block = 0;
+// tuning knob ("amp_lp", 0 | 1): 1 = in the f16 / f16w2 precision classes the narrow stages' half-steps run their convolution on the
+// fp16 matrix cores (svcmi_snake_conv_group_lp); 0 = they stay on the fp32 vector kernels whatever the class says
+int g_amp_lp = 1;
 
 enum Op {
     OP_CONV_F32, OP_CONV_LP, OP_CONV_GROUP_F32, OP_CONV_GROUP_LP, OP_LAYERNORM, OP_SPLITK_LN, OP_ATTENTION, OP_SNAKE_ALIAS,
     OP_SNAKE_ALIAS_GROUP, OP_BLOCK_MEAN, OP_SNAKE_CONV, OP_SNAKE_CONV_GROUP, OP_UPSAMPLE_NOISE, OP_SNAKE_POST, OP_WN_GATE,
     OP_COUPLING_PRE, OP_COUPLING_POST, OP_EMBED_PITCH, OP_SAMPLE_PRIOR, OP_NCL_TO_NLC, OP_COPY2D, OP_PITCH_PREFIX, OP_PITCH_SOURCE,
-    OP_ATTENTION16, OP_AMP_BLOCK_GROUP, OP_COUNT
+    OP_ATTENTION16, OP_AMP_BLOCK_GROUP, OP_SNAKE_CONV_GROUP_LP, OP_COUNT
 };
 const char* const OP_NAMES[OP_COUNT] = {
     "svcmi_conv_gemm_f32", "svcmi_conv_gemm_lp", "svcmi_conv_gemm_group_f32", "svcmi_conv_gemm_group_lp", "svcmi_layernorm_f32",
     "svcmi_splitk_layernorm_f32", "svcmi_attention_f32", "svcmi_snake_alias_f32", "svcmi_snake_alias_group_f32", "svcmi_block_mean_f32",
     "svcmi_snake_conv_f32", "svcmi_snake_conv_group_f32", "svcmi_upsample_noise_f32", "svcmi_snake_post_f32", "svcmi_wn_gate_f32",
     "svcmi_coupling_pre_f32", "svcmi_coupling_post_f32", "svcmi_embed_pitch_f32", "svcmi_sample_prior_f32", "svcmi_ncl_to_nlc_f32",
-    "svcmi_copy2d_f32", "svcmi_pitch_prefix_f64", "svcmi_pitch_source_f32", "svcmi_attention16", "svcmi_amp_block_group_f32"};
+    "svcmi_copy2d_f32", "svcmi_pitch_prefix_f64", "svcmi_pitch_source_f32", "svcmi_attention16", "svcmi_amp_block_group_f32", "svcmi_snake_conv_group_lp"};
 
 // ------------------------------------------------------------------------------------------------ per-launch trace (bench.py)
 struct TraceRec {
@@ -663,6 +666,10 @@ bool amp_stage_grouped(Ctx& c, const svcmi_synth_model& m, const svcmi_gen_stage
     if (!fused && mode16(c.prec) && cp % 8 == 0)
         for (int j = 0; j < nb; ++j) t1h[j] = c.ar.take(n * 2);
     const float* xc[3] = {y, y, y};
+    // f16 / f16w2 classes, narrow stages: the half-step with its convolution on the fp16 matrix cores
+    bool lp = fused && g_amp_lp && (c.prec == SVCMI_PREC_F16 || c.prec == SVCMI_PREC_F16W2);
+    for (int j = 0; lp && j < nb; ++j)
+        for (int q = 0; q < nd; ++q) lp = lp && svcmi_snake_conv_lp_supported(st.c, cp, st.blocks[j].k, st.blocks[j].dil[q], c.prec);
     for (int q = 0; q < nd; ++q) {
         float** outs = q == nd - 1 ? t2 : xj;
         if (fused) {
@@ -674,15 +681,19 @@ bool amp_stage_grouped(Ctx& c, const svcmi_synth_model& m, const svcmi_gen_stage
                                              b.dil[q], 0, 1.0f};
                 fl += 2.0 * B * L * st.c * st.c * b.k;
             }
-            run(c, OP_SNAKE_CONV_GROUP, fl, 8.0 * nb * B * L * st.c,
-                [&] { return svcmi_snake_conv_group_f32(d, nb, m.filt, B, (int32_t)L, st.c, cp, c.stream); });
+            auto half_step = [&] {
+                if (lp) run(c, OP_SNAKE_CONV_GROUP_LP, fl, 8.0 * nb * B * L * st.c,
+                            [&] { return svcmi_snake_conv_group_lp(d, nb, m.filt, B, (int32_t)L, st.c, cp, c.prec, c.stream); });
+                else run(c, OP_SNAKE_CONV_GROUP, fl, 8.0 * nb * B * L * st.c,
+                         [&] { return svcmi_snake_conv_group_f32(d, nb, m.filt, B, (int32_t)L, st.c, cp, c.stream); });
+            };
+            half_step();
             for (int j = 0; j < nb; ++j) {
                 const svcmi_amp_block& b = st.blocks[j];
                 d[j] = svcmi_snake_conv_desc{t1[j], b.c2[q].w, b.c2[q].bias, xc[j], outs[j], b.a2_alpha[q], b.a2_beta[q], b.c2[q].ldw, b.k,
                                              1, 0, 1.0f};
             }
-            run(c, OP_SNAKE_CONV_GROUP, fl, 8.0 * nb * B * L * st.c,
-                [&] { return svcmi_snake_conv_group_f32(d, nb, m.filt, B, (int32_t)L, st.c, cp, c.stream); });
+            half_step();
         } else {
             const float* px[3]; float* py[3]; const float *pa[3], *pb[3];
             CV vs[3];
@@ -997,6 +1008,7 @@ extern "C" int svcmi_struct_sizes(int64_t* out, int32_t cap) {
 extern "C" int svcmi_host_tune_set(const char* name, int32_t value) {
     if (strcmp(name, "amp_grouped") == 0 && (value == 0 || value == 1)) { g_amp_grouped = value; return 0; }
     if (strcmp(name, "amp_block") == 0 && (value == 0 || value == 1)) { g_amp_block = value; return 0; }
+    if (strcmp(name, "amp_lp") == 0 && (value == 0 || value == 1)) { g_amp_lp = value; return 0; }
     return SVCMI_EINVAL;
 }
 

@@ -8,7 +8,7 @@ DEFAULT_LIB = os.path.join(HERE, "libsvcmi.so")
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_MISH, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4, 5
 CONV_ACCUMULATE, CONV_MASK_IN, CONV_MASK_OUT, CONV_PARTIALS = 1, 2, 4, 8
-ABI_VERSION = 19
+ABI_VERSION = 20
 PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16, PREC_BF16_A16, PREC_F16_A16, PREC_BF16X3_A16 = 0, 1, 2, 3, 4, 5, 6
 PRECISIONS = {None: 0, "f32": 0, "fp32": 0, "bf16x3": 1, "bf16": 2, "f16": 3, "fp16": 3, "f16w2": 8}
 PREC_F16W2, PREC_F16W2_A16 = 8, 9          # fp16 activations x split fp16 weights: a mode like f16 whose 16-bit-activation launches take two MFMAs on (hi, lo) weight images
@@ -25,7 +25,11 @@ CLASS_NAMES = {"enc": 0, "flow": 1, "ups": 2, "amp0": 3, "amp1": 4, "amp2": 5, "
 # encoder's attention stays on the fp32 matrix cores: with "encattn": "f16" (svcmi_attention16) the step is 4 % faster and as
 # accurate on ordinary weights (3.2e-4), but on the outlier-stress weights (LayerNorm gains up to 30: logits of hundreds) the fp16
 # q / k rounding costs 1.7e-2 against 1.9e-3.
-MIXED_DEFAULT = {"enc": "bf16x3", "encattn": "f32", "ups": "bf16x3", "flow": "f16", "amp0": "bf16x3", "amp1": "f16", "amp2": "f16", "amp3": "f16", "amp4": "f16"}
+# The two narrow stages (amp3 / amp4: 20 and 10 channels, fused SnakeAlias + convolution kernels) run their convolution on the fp16
+# matrix cores with split weights (f16w2: only the activated input is rounded; svcmi_snake_conv_group_lp): 50 instead of 93 us per
+# grouped half-step at 20 channels, 49 instead of 65 at 10 (profiles/r04p_amplp.log) for 3.9e-4 -> 4.3e-4 on configs[2]
+# (plain "f16" there: 1.5 % faster, 4.7e-4).
+MIXED_DEFAULT = {"enc": "bf16x3", "encattn": "f32", "ups": "bf16x3", "flow": "f16", "amp0": "bf16x3", "amp1": "f16", "amp2": "f16", "amp3": "f16w2", "amp4": "f16w2"}
 
 
 def parse_precision(p):
@@ -205,6 +209,8 @@ SIGNATURES = {
     "svcmi_snake_post_f32": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "svcmi_conv_gemm_group_f32": (c_int, [_P, _I, _P]),
     "svcmi_snake_conv_group_f32": (c_int, [_P, _I, _P, _I, _I, _I, _I, _P]),
+    "svcmi_snake_conv_lp_supported": (c_int, [_I, _I, _I, _I, _I]),
+    "svcmi_snake_conv_group_lp": (c_int, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "svcmi_amp_block_group_supported": (c_int, [_I, _I]),
     "svcmi_amp_block_group_f32": (c_int, [_P, _I, _P, _I, _I, _I, _I, _P]),
     "svcmi_snake_alias_group_f32": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P]),

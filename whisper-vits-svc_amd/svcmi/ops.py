@@ -571,9 +571,10 @@ class Ops:
                    ksize, self._stream(), work={"flops": 2.0 * B * L * c * ksize, "bytes": 4.0 * B * L * (c + 1)})
         return out
 
-    def snake_conv_group(self, problems, filt, *, c):
+    def snake_conv_group(self, problems, filt, *, c, precision=None):
         """The fused half-step for up to 3 AMP blocks in one launch.  ``problems``: dicts with x, alpha_log, beta_log, w, bias,
-        ksize, dilation (1), res (None), alpha (1.0), accumulate (False), out."""
+        ksize, dilation (1), res (None), alpha (1.0), accumulate (False), out.  ``precision`` "f16" / "f16w2": the convolution on the
+        fp16 matrix cores (svcmi_snake_conv_group_lp; same fp32 tensors in and out)."""
         descs = (SnakeConvDesc * len(problems))()
         B, L, ld = problems[0]["x"].shape
         flops = 0.0
@@ -585,8 +586,12 @@ class Ops:
             d.ldw, d.ksize, d.dilation = pr["w"].shape[1], pr["ksize"], pr.get("dilation", 1)
             d.accumulate, d.alpha = int(pr.get("accumulate", False)), float(pr.get("alpha", 1.0))
             flops += 2.0 * B * L * c * c * pr["ksize"]
-        self._call("svcmi_snake_conv_group_f32", descs, len(problems), _ptr(filt), B, L, c, ld, self._stream(),
-                   work={"flops": flops, "bytes": 8.0 * len(problems) * B * L * c})
+        if precision is not None:
+            self._call("svcmi_snake_conv_group_lp", descs, len(problems), _ptr(filt), B, L, c, ld, PRECISIONS[precision], self._stream(),
+                       work={"flops": flops, "bytes": 8.0 * len(problems) * B * L * c})
+        else:
+            self._call("svcmi_snake_conv_group_f32", descs, len(problems), _ptr(filt), B, L, c, ld, self._stream(),
+                       work={"flops": flops, "bytes": 8.0 * len(problems) * B * L * c})
         return [pr["out"] for pr in problems]
 
     def amp_block_group(self, x, blocks, filt, *, c):
