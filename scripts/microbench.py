@@ -285,12 +285,14 @@ def main():
                     for u in (-1, 1):
                         ops.lib.svcmi_tune_set(b"amp_u", u)
                         ref = None
-                        for prec in (None, "f16", "f16w2"):
+                        for name, prec, mfma in (("fp32 VALU", None, 0), ("fp32 MFMA", None, 2 if u > 0 else 3), ("f16", "f16", 0), ("f16w2", "f16w2", 0)):
+                            ops.lib.svcmi_tune_set(b"amp_mfma", mfma)
                             us = timeit(lambda: ops.snake_conv_group(probs, filt, c=C, precision=prec))
                             out = probs[2]["out"][..., :C].clone()
                             ref = out if ref is None else ref
-                            print(f"amplp C={C} n={n} B={B} d={d} amp_u={u:2d} {str(prec):6s}: {us:8.1f} us  {B * fl / us / 1e6:6.1f} TF/s  "
-                                  f"max diff to fp32 {float((out - ref).abs().max()):.1e}", flush=True)
+                            print(f"amplp C={C} n={n} B={B} d={d} amp_u={u:2d} {name:9s}: {us:8.1f} us  {B * fl / us / 1e6:6.1f} TF/s  "
+                                  f"max diff to fp32 VALU {float((out - ref).abs().max()):.1e}", flush=True)
+                        ops.lib.svcmi_tune_set(b"amp_mfma", 1)
                 ops.lib.svcmi_tune_set(b"amp_u", 0)
     if "small" in what:       # the short-K / few-tile GEMMs of the prior encoder, flow and widest decoder stage
         sp = (1, 0, 2, 3, 4)

@@ -658,17 +658,44 @@ def check_snake_conv_group(ops, device, c=20, ld=20, B=2, n=300):
                   res=res.to(device), alpha=0.5)
         want.append(ops.snake_conv(pr["x"], pr["alpha_log"], pr["beta_log"], filt, w, bias, c=c, ksize=k, dilation=d, res=pr["res"], alpha=0.5))
         probs.append(dict(pr, out=torch.full((B, n, ld), 7.0).to(device)))
-    for amp_u in ((-1, 1) if c <= 20 else (0,)):     # 1: the variant that keeps the up-sampled activation tile in LDS (snake_tile_u), -1: never; same bits
-        assert ops.lib.svcmi_tune_set(b"amp_u", amp_u) == 0
+    assert ops.lib.svcmi_tune_set(b"amp_mfma", 0) == 0       # the vector-ALU kernels: the single launches' arithmetic, bit for bit
+    try:
+        for amp_u in ((-1, 1) if c <= 20 else (0,)):     # 1: the variant that keeps the up-sampled activation tile in LDS (snake_tile_u), -1: never; same bits
+            assert ops.lib.svcmi_tune_set(b"amp_u", amp_u) == 0
+            try:
+                for n_prob in (1, 2, 3):
+                    for pr in probs:
+                        pr["out"].fill_(7.0)
+                    got = ops.snake_conv_group(probs[:n_prob], filt, c=c)
+                    for j in range(n_prob):
+                        assert torch.equal(got[j], want[j]), (amp_u, n_prob, j, float((got[j] - want[j]).abs().max()))
+            finally:
+                ops.lib.svcmi_tune_set(b"amp_u", 0)
+    finally:
+        ops.lib.svcmi_tune_set(b"amp_mfma", 1)
+    if c > 20:
+        return
+    # the product default: the same half-step with its convolution on the fp32 matrix cores (snake_convm_group_kernel) -- fp32 products
+    # and sums in another order; both activation-phase forms give the same bits
+    outs = {}
+    for form in (2, 3):
+        assert ops.lib.svcmi_tune_set(b"amp_mfma", form) == 0
         try:
-            for n_prob in (1, 2, 3):
+            for n_prob in (1, 3):
                 for pr in probs:
                     pr["out"].fill_(7.0)
                 got = ops.snake_conv_group(probs[:n_prob], filt, c=c)
                 for j in range(n_prob):
-                    assert torch.equal(got[j], want[j]), (amp_u, n_prob, j, float((got[j] - want[j]).abs().max()))
+                    _close(got[j], want[j].cpu(), 1e-5, f"snake_conv_group on the fp32 matrix cores c={c} form={form} problem {j}")
+                    assert not torch.equal(got[j], want[j])          # (it really is the other kernel)
+                    if ld > c:
+                        assert float(got[j][..., c:].abs().max()) == 0.0
+                outs[(form, n_prob)] = [g_.clone() for g_ in got[:n_prob]]
         finally:
-            ops.lib.svcmi_tune_set(b"amp_u", 0)
+            ops.lib.svcmi_tune_set(b"amp_mfma", 1)
+    for n_prob in (1, 3):
+        for a, b in zip(outs[(2, n_prob)], outs[(3, n_prob)]):
+            assert torch.equal(a, b)
 
 
 def check_snake_conv_group_lp(ops, device, c=20, ld=20, B=2, n=300, precision="f16"):

@@ -445,6 +445,124 @@ __global__ __launch_bounds__(TPB) void snake_conv16_group_kernel(AmpGroupArgs g)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The fp32 half-step with its convolution on the fp32 matrix cores (round 4, after the fp16 variant above showed what the VALU
+// convolution costs: 93 -> 50 us at 20 channels with the convolution all but free).  v_mfma_f32_16x16x4_f32 has the VALU's peak rate,
+// so the padded tile (20 -> 32 / 10 -> 16 output channels) does more arithmetic than the direct form -- but it does it on the MATRIX
+// pipe, which runs beside the other waves' SnakeAlias phases on the vector pipe, where the direct convolution (at ~35 % of the VALU
+// peak: dependent FMA chains, LDS operand reads) queues behind them.  Same structure as snake_conv16_body: S (fp32 rows, stride CP
+// floats = 4 * odd: conflict-free ds_read_b128) and the weight fragments in LDS, D = W * S^T, a lane ends with 4 consecutive output
+// channels of one time step.  K walks (tap, 4-channel slice) pairs: in a group of 4 MFMAs lane group g = lane >> 4 owns slice 4 q + g
+// and MFMA s consumes component s of its float4 -- the matrix K index is (g <-> slice, s <-> component) for both operands, so ONE
+// 16-byte LDS read per operand feeds four instructions.  Products and sums are fp32 (the instruction the GEMM family runs on).
+template <int CP, int CR>
+struct AmpM {
+    static constexpr int NC4 = CP / 4;                       // 4-channel K slices per tap (pad channels of S and of the weights are zero)
+    static constexpr int NCT = (CR + 15) / 16;
+    static constexpr int TB = 256;
+    static constexpr int ROWS = TB + 10 * DMAX;
+    static constexpr int MAXQ = (11 * NC4 + 3) / 4;          // groups of 4 MFMAs at 11 taps
+    static constexpr int S_FLOATS = ROWS * CP;
+    static constexpr int U_FLOATS = ((ROWS + 5) * UTile<CP>::LU + 3) / 4 * 4;
+    static constexpr int W_FLOATS = MAXQ * NCT * 64 * 4;
+    static_assert(CP % 4 == 0 && (CP / 4) % 2 == 1, "S row stride = 4 * odd floats");
+};
+
+template <int CP, int CR, bool UT>
+__device__ __forceinline__ void snake_convm_body(const AmpArgs& p, float* smem, float* wl) {
+    using TL = AmpM<CP, CR>;
+    constexpr int NC4 = TL::NC4, NCT = TL::NCT, TB = TL::TB;
+    const int KS = p.ks;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = SVCMI_UNIFORM((int)(tid >> 6));
+    const int b = blockIdx.y;
+    const int n = p.n, ld = p.ld, d = p.dil;
+    const int halo = (KS - 1) * d / 2;
+    const int t_blk = blockIdx.x * TB;
+    const int rows = TB + 2 * halo;
+    const float* xb = p.x + (long long)b * n * ld;
+    const int nq = (KS * NC4 + 3) / 4;
+
+    // ---- weights -> fragment order in LDS (with the U tile: into the part of its region that S does not cover, after the activation phase)
+    svcmi_f32x4* wf = reinterpret_cast<svcmi_f32x4*>(wl);
+    auto pack_weights = [&] {
+        for (int u = tid; u < nq * NCT * 64; u += TPB) {
+            const int l = u & 63, f = u >> 6;
+            const int ct = f % NCT, q = f / NCT;
+            const int co = ct * 16 + (l & 15), sl = 4 * q + (l >> 4);
+            const int tap = sl / NC4, c4 = sl - tap * NC4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (co < CR && tap < KS) v = *reinterpret_cast<const float4*>(p.w + (long long)co * p.ldw + tap * CP + 4 * c4);
+            wf[f * 64 + l] = svcmi_f32x4{v.x, 4 * c4 + 1 < CR ? v.y : 0.f, 4 * c4 + 2 < CR ? v.z : 0.f, 4 * c4 + 3 < CR ? v.w : 0.f};
+        }
+    };
+    if constexpr (!UT) pack_weights();
+    if constexpr (UT) snake_tile_u<CP, CR, CP, (((TL::ROWS + RT - 1) / RT) * CP + TPB - 1) / TPB>(smem, xb, p.alpha_log, p.beta_log, p.filt, n, ld, t_blk, halo, rows, tid);
+    else snake_tile<CP, CR, CP>(smem, xb, p.alpha_log, p.beta_log, p.filt, n, ld, t_blk, halo, rows, tid);
+    if constexpr (UT) pack_weights();
+    __syncthreads();
+
+    constexpr int NT = 4;                                   // time tiles of 16 rows per wave
+    const int tq = lane & 15, kq = lane >> 4;
+    svcmi_f32x4 acc[NT][NCT];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc[tt][ct] = svcmi_f32x4{0.f, 0.f, 0.f, 0.f};
+    const int row0 = wave * (16 * NT) + tq;
+    for (int q = 0; q < nq; ++q) {
+        const int sl = 4 * q + kq;
+        int tap = sl / NC4;
+        const int c4 = sl - tap * NC4;
+        tap = tap < KS ? tap : KS - 1;                      // (a slice past the last tap: any finite row, its weights are zero)
+        const float* sp = smem + (row0 + tap * d) * CP + 4 * c4;
+        svcmi_f32x4 bf[NT], af[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) af[ct] = wf[(q * NCT + ct) * 64 + lane];
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) bf[tt] = *reinterpret_cast<const svcmi_f32x4*>(sp + tt * 16 * CP);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) acc[tt][ct] = svcmi_mfma_16x16x4(af[ct][e], bf[tt][e], acc[tt][ct]);
+    }
+
+    // ---- epilogue: lane = (time tq of the tile, output channels ct * 16 + 4 kq .. + 3); the arithmetic of snake_conv_body per value
+    float* yb = p.y + (long long)b * n * ld;
+    const float* rb = p.res ? p.res + (long long)b * n * ld : nullptr;
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+        const int t = t_blk + wave * (16 * NT) + tt * 16 + tq;
+        asm volatile("" ::: "memory");
+        if (t >= n) continue;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const int co4 = ct * 16 + 4 * kq;
+            if (co4 >= CP) continue;
+            float v[4] = {acc[tt][ct][0], acc[tt][ct][1], acc[tt][ct][2], acc[tt][ct][3]};
+            float* yr = yb + (long long)t * ld + co4;
+            float4 bq = make_float4(0.f, 0.f, 0.f, 0.f), rq = bq, oq = bq;
+            if (p.bias) bq = *reinterpret_cast<const float4*>(p.bias + co4);
+            if (rb) rq = *reinterpret_cast<const float4*>(rb + (long long)t * ld + co4);
+            if (p.accumulate) oq = *reinterpret_cast<const float4*>(yr);
+            const float bv[4] = {bq.x, bq.y, bq.z, bq.w}, rv[4] = {rq.x, rq.y, rq.z, rq.w}, ov[4] = {oq.x, oq.y, oq.z, oq.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = co4 + e < CR ? (v[e] + bv[e] + rv[e]) * p.alpha + ov[e] : 0.f;
+            *reinterpret_cast<float4*>(yr) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+template <int CP, int CR, bool UT>
+__global__ __launch_bounds__(TPB) void snake_convm_group_kernel(AmpGroupArgs g) {
+    using TL = AmpM<CP, CR>;
+    constexpr int NSW = TL::S_FLOATS + TL::W_FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[UT && TL::U_FLOATS > NSW ? TL::U_FLOATS : NSW];
+    snake_convm_body<CP, CR, UT>(g.p[blockIdx.z], smem, smem + TL::S_FLOATS);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Stage entry of the two narrowest generator stages in one launch: polyphase transposed convolution of x plus the strided
 // "noise" convolution of the harmonic source (vits_decoder/generator.py:183-186: `x = ups[i](x); x = x + noise_convs[i](src)`).
 // As two padded implicit-GEMM launches these cost 84 + 105 us (10 channels) and 41 + 63 us (20 channels) for < 0.2 GFLOP:
@@ -606,6 +724,10 @@ extern "C" int svcmi_snake_conv_f32(const float* x, const float* w, const float*
 // choice (profiles/r03i_ampgroup_u.log, MI355X): at 10 channels it wins (65.2 -> 62.6 us per grouped launch, B = 4: 250 -> 234 us), at
 // 20 channels the 52 KB of LDS per block cost more occupancy than the saved instructions buy (84 -> 92.5 us); -1 = never, 1 = wherever it exists
 int g_amp_u = 0;
+// tuning knob ("amp_mfma", 0..3): the grouped fp32 half-step at 10 / 20 channels with its convolution on the fp32 matrix cores
+// (snake_convm_group_kernel).  0 = always the vector-ALU kernels, 1 = measured choice (svcmi_snake_conv_group_f32), 2 / 3 = always the
+// matrix cores, with / without the up-sampled activation tile
+int g_amp_mfma = 1;
 
 template <int TT>
 static void launch_amp_group(const AmpGroupArgs& g, int count, int batch, int len, int c, void* stream) {
@@ -663,6 +785,22 @@ extern "C" int svcmi_snake_conv_group_f32(const svcmi_snake_conv_desc* descs, in
         a.ks = d.ksize;
     }
     for (int i = count; i < AMP_GROUP; ++i) g.p[i] = g.p[0];
+    // measured choice (profiles/r04r_amplp.log): the matrix-core form wins where ONE clip's launch has the chip to itself and the vector
+    // pipe is the bottleneck -- 20 channels, B = 1: 92.7 -> 75.7 us; from B = 4 on (284 vs 280 us) and at 10 channels (67 vs 64) the padded
+    // tile's extra arithmetic costs what the freed vector issue slots buy
+    // (decided by the batch size alone: a time tile of the streaming decoder must take the same kernel as the whole chunk, bit for bit)
+    const bool mfma_auto = g_amp_mfma == 1 && c == 20 && batch <= 2;
+    if ((mfma_auto || g_amp_mfma >= 2) && c <= 20 && !g_amp_tt) {
+        bool al = true;                                   // float4 epilogue: 16-byte aligned rows
+        for (int i = 0; i < count; ++i) al = al && !(((uintptr_t)g.p[i].y | (uintptr_t)g.p[i].res | (uintptr_t)g.p[i].bias) & 15);
+        if (al) {
+            const dim3 grid((unsigned)((len + 255) / 256), (unsigned)batch, (unsigned)count);
+            const bool ut = g_amp_mfma == 3 ? false : g_amp_mfma == 2 ? true : g_amp_u >= 0;
+            if (c == 10) { if (ut) SVCMI_LAUNCH((snake_convm_group_kernel<12, 10, true>), grid, dim3(TPB), 0, stream, g); else SVCMI_LAUNCH((snake_convm_group_kernel<12, 10, false>), grid, dim3(TPB), 0, stream, g); }
+            else { if (ut) SVCMI_LAUNCH((snake_convm_group_kernel<20, 20, true>), grid, dim3(TPB), 0, stream, g); else SVCMI_LAUNCH((snake_convm_group_kernel<20, 20, false>), grid, dim3(TPB), 0, stream, g); }
+            return SVCMI_LAST_ERROR();
+        }
+    }
     const int tt = g_amp_tt ? g_amp_tt : (c == 10 ? 1 : 2);      // measured (scripts/microbench.py ampgroup): 68.5 / 71.3 / 81.1 us at 10 channels, 106 / 89 / 109 at 20
     if (tt == 4) launch_amp_group<4>(g, count, batch, len, c, stream);
     else if (tt == 1) launch_amp_group<1>(g, count, batch, len, c, stream);
@@ -769,6 +907,10 @@ extern "C" int svcmi_tune_set(const char* name, int32_t value) {
     int i = 0;
     while (k[i] && name[i] == k[i]) ++i;
     if (k[i] == 0 && name[i] == 0 && (value == 0 || value == 1 || value == 2 || value == 4)) { g_amp_tt = value; return 0; }
+    const char* km = "amp_mfma";
+    i = 0;
+    while (km[i] && name[i] == km[i]) ++i;
+    if (km[i] == 0 && name[i] == 0 && value >= 0 && value <= 3) { g_amp_mfma = value; return 0; }
     const char* ku = "amp_u";
     i = 0;
     while (ku[i] && name[i] == ku[i]) ++i;
