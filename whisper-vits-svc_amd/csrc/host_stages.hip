@@ -669,7 +669,7 @@ bool amp_stage_grouped(Ctx& c, const svcmi_synth_model& m, const svcmi_gen_stage
     // f16 / f16w2 classes, narrow stages: the half-step with its convolution on the fp16 matrix cores
     bool lp = fused && g_amp_lp && (c.prec == SVCMI_PREC_F16 || c.prec == SVCMI_PREC_F16W2);
     for (int j = 0; lp && j < nb; ++j)
-        for (int q = 0; q < nd; ++q) lp = lp && svcmi_snake_conv_lp_supported(st.c, cp, st.blocks[j].k, st.blocks[j].dil[q], c.prec);
+        for (int q = 0; q < nd; ++q) lp = lp && svcmi_snake_conv_lp_supported(st.c, cp, st.blocks[j].k, st.blocks[j].dil[q], SVCMI_PREC_F16W2);
     for (int q = 0; q < nd; ++q) {
         float** outs = q == nd - 1 ? t2 : xj;
         if (fused) {
@@ -682,8 +682,10 @@ bool amp_stage_grouped(Ctx& c, const svcmi_synth_model& m, const svcmi_gen_stage
                 fl += 2.0 * B * L * st.c * st.c * b.k;
             }
             auto half_step = [&] {
+                // always with split weights (hi + lo fragments, whatever the class: "f16" or "f16w2"): the second MFMA per tile costs 1.5 % of
+                // the launch (the convolution is a tenth of it) and takes a third off the error these stages add (profiles/r04q_*)
                 if (lp) run(c, OP_SNAKE_CONV_GROUP_LP, fl, 8.0 * nb * B * L * st.c,
-                            [&] { return svcmi_snake_conv_group_lp(d, nb, m.filt, B, (int32_t)L, st.c, cp, c.prec, c.stream); });
+                            [&] { return svcmi_snake_conv_group_lp(d, nb, m.filt, B, (int32_t)L, st.c, cp, SVCMI_PREC_F16W2, c.stream); });
                 else run(c, OP_SNAKE_CONV_GROUP, fl, 8.0 * nb * B * L * st.c,
                          [&] { return svcmi_snake_conv_group_f32(d, nb, m.filt, B, (int32_t)L, st.c, cp, c.stream); });
             };
