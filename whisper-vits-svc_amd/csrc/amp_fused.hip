@@ -87,9 +87,14 @@ __device__ __forceinline__ void snake_tile(float* S, const float* xb, const floa
 // outputs); step 2 runs the 12-tap decimating FIR from LDS (13 ds_read_b64 per 8 outputs), keeps its outputs in registers across a
 // barrier and writes S over the SAME memory -- 20 + 9 instead of 42 VALU instructions per output for ~2.2x the LDS footprint of S alone.
 // Bit-identical to snake_tile (same operation sequence per value).  LU = pair-row stride in floats (even; 8 * LU mod 64 spread).
+// (Bank layout, measured and left alone: a wave's float2 access is groups of 2 CP dwords one RUN = 8 pair rows apart, and 8 * LU is a
+// multiple of 16 for every even LU, which stacks the groups 3-4 deep on some banks -- PMC: 0.41-0.44 of the LDS cycles are conflicts.  A
+// per-run skew that makes the groups tile the 64 banks changed no kernel time: profiles/r04t_u_tile_skew_rejected.log.)
 template <int CP>
 struct UTile {
     static constexpr int LU = 2 * CP + 2;
+    __device__ __forceinline__ static int pos(int m) { return m * LU; }                                    // float offset of pair row m
+    static constexpr int floats(int pair_rows) { return (pair_rows + 7) * LU; }      // + 7 rows of slack (see the FIR reads)
 };
 
 template <int CP, int CR, int LS, int MAXI, bool H16 = false>
@@ -122,7 +127,7 @@ __device__ __forceinline__ void snake_tile_u(float* smem, const float* xb, const
         }
 #pragma unroll
         for (int m = 0; m < RT; ++m)
-            if (m0 + m < pairs) *reinterpret_cast<float2*>(smem + (m0 + m) * LU + 2 * ch) = make_float2(s2[m][0], s2[m][1]);
+            if (m0 + m < pairs) *reinterpret_cast<float2*>(smem + UTile<CP>::pos(m0 + m) + 2 * ch) = make_float2(s2[m][0], s2[m][1]);
     }
     __syncthreads();
     const int runs = (rows + RT - 1) / RT;
@@ -137,10 +142,12 @@ __device__ __forceinline__ void snake_tile_u(float* smem, const float* xb, const
                 for (int r = 0; r < RT; ++r) outs[q][r] = 0.f;
             } else {
                 svcmi_f32x2 P[RT + 5];
+                // (pair rows past `pairs` -- the last run of a tile -- feed only outputs past `rows`, which are not stored: the region is
+                // sized for them, UTile::floats, and the offsets stay compile-time constants: r0 is a multiple of RT = 8)
+                const float* ub = smem + UTile<CP>::pos(r0) + 2 * ch;
 #pragma unroll
                 for (int i = 0; i < RT + 5; ++i) {
-                    const int m = r0 + i < pairs ? r0 + i : pairs - 1;
-                    const float2 v = *reinterpret_cast<const float2*>(smem + m * LU + 2 * ch);
+                    const float2 v = *reinterpret_cast<const float2*>(ub + i * LU);
                     P[i] = svcmi_f32x2{v.x, v.y};
                 }
                 snake_fir<RT>(P, f, outs[q]);
@@ -287,7 +294,7 @@ __global__ __launch_bounds__(TPB) void snake_conv_group_kernel(AmpGroupArgs g) {
 template <int CP, int CR, int G, int TT>
 __global__ __launch_bounds__(TPB) void snake_conv_group_u_kernel(AmpGroupArgs g) {
     using TL = AmpTile<CP, G, TT, 11>;
-    constexpr int NU = (TL::ROWS + 5) * UTile<CP>::LU, NS = TL::ROWS * TL::LS;
+    constexpr int NU = UTile<CP>::floats(TL::ROWS + 5), NS = TL::ROWS * TL::LS;
     static_assert(((TL::ROWS + RT - 1) / RT) * CP <= 4 * TPB, "snake_tile_u keeps at most 4 work items per thread in registers");
     __shared__ __attribute__((aligned(16))) float S[NU > NS ? NU : NS];
     snake_conv_body<CP, CR, 0, G, TT, true>(g.p[blockIdx.z], S);
@@ -316,7 +323,7 @@ struct Amp16 {
     static constexpr int ROWS = TB + 10 * DMAX;
     static constexpr int MAXSTEPS = (11 * CK + 3) / 4;       // MFMA K-steps at 11 taps
     static constexpr int S_FLOATS = (ROWS * LSH / 2 + 3) / 4 * 4;
-    static constexpr int U_FLOATS = ((ROWS + 5) * UTile<CP>::LU + 3) / 4 * 4;
+    static constexpr int U_FLOATS = (UTile<CP>::floats(ROWS + 5) + 3) / 4 * 4;
     static constexpr int W_FLOATS = MAXSTEPS * NCT * TERMS * 64 * 4;
     static_assert(CK * 8 <= LSH && CP <= CK * 8 && CP + 4 >= CK * 8, "pad columns [CP, 8 CK) are one 8-byte store per row");
 };
@@ -462,7 +469,7 @@ struct AmpM {
     static constexpr int ROWS = TB + 10 * DMAX;
     static constexpr int MAXQ = (11 * NC4 + 3) / 4;          // groups of 4 MFMAs at 11 taps
     static constexpr int S_FLOATS = ROWS * CP;
-    static constexpr int U_FLOATS = ((ROWS + 5) * UTile<CP>::LU + 3) / 4 * 4;
+    static constexpr int U_FLOATS = (UTile<CP>::floats(ROWS + 5) + 3) / 4 * 4;
     static constexpr int W_FLOATS = MAXQ * NCT * 64 * 4;
     static_assert(CP % 4 == 0 && (CP / 4) % 2 == 1, "S row stride = 4 * odd floats");
 };
