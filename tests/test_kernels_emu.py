@@ -89,12 +89,13 @@ def test_grouped_launches_reduced_precision(ops, n, c, prec):
     K.check_grouped_launches(ops, "cpu", B=2, n=n, c=c, ld=c, prec=prec)
 
 
-@pytest.mark.parametrize("c,ld", [(10, 12), (20, 20)])
-def test_snake_conv_group(ops, c, ld):
-    K.check_snake_conv_group(ops, "cpu", c=c, ld=ld, B=2, n=150)
+@pytest.mark.parametrize("c,ld,n", [(10, 12, 150), (20, 20, 150), (20, 20, 900)])
+def test_snake_conv_group(ops, c, ld, n):
+    K.check_snake_conv_group(ops, "cpu", c=c, ld=ld, B=2 if n < 500 else 1, n=n)
 
 
-@pytest.mark.parametrize("c,ld,n,precision", [(10, 12, 150, "f16"), (20, 20, 300, "f16w2"), (20, 20, 40, "f16"), (10, 12, 290, "f16w2")])
+@pytest.mark.parametrize("c,ld,n,precision", [(10, 12, 150, "f16"), (20, 20, 300, "f16w2"), (20, 20, 40, "f16"), (10, 12, 290, "f16w2"),
+                                              (20, 20, 1100, "f16")])       # (1100 rows: tiles 1 and 2 of 5 take the interior fast path of the U tile)
 def test_snake_conv_group_on_the_fp16_matrix_cores(ops, c, ld, n, precision):
     K.check_snake_conv_group_lp(ops, "cpu", c=c, ld=ld, B=2 if n < 200 else 1, n=n, precision=precision)
 
