@@ -53,6 +53,26 @@ def test_argument_validation_needs_no_gpu(hip_so):
     assert lib.svcmi_conv_gemm_group_f32(descs, 0, None) == -1 and lib.svcmi_conv_gemm_group_f32(descs, 4, None) == -1
     assert lib.svcmi_conv_gemm_group_f32(descs, 2, None) == -1                    # null operands inside the descriptors
     assert lib.svcmi_snake_conv_group_f32((_lib.SnakeConvDesc * 3)(), 0, None, 1, 10, 20, 20, None) == -1
+    # the narrow stages' half-step on the fp16 matrix cores: same descriptors; 10 / 20 channels, fp16 modes only, float4-aligned rows
+    sd = (_lib.SnakeConvDesc * 3)()
+    assert lib.svcmi_snake_conv_group_lp(sd, 0, None, 1, 10, 20, 20, 3, None) == -1 and lib.svcmi_snake_conv_group_lp(sd, 1, None, 1, 10, 20, 20, 3, None) == -1
+    assert lib.svcmi_snake_conv_lp_supported(20, 20, 11, 5, 3) == 1 and lib.svcmi_snake_conv_lp_supported(10, 12, 3, 1, 8) == 1
+    assert lib.svcmi_snake_conv_lp_supported(40, 40, 3, 1, 3) == 0 and lib.svcmi_snake_conv_lp_supported(20, 20, 3, 1, 2) == 0 \
+        and lib.svcmi_snake_conv_lp_supported(20, 20, 5, 1, 3) == 0 and lib.svcmi_snake_conv_lp_supported(20, 20, 3, 6, 3) == 0
+    fb = (ctypes.c_float * 4096)()
+    base = ctypes.addressof(fb) + (-ctypes.addressof(fb)) % 16          # a 16-byte aligned address inside the buffer
+    sd[0].x, sd[0].w, sd[0].y, sd[0].alpha_log, sd[0].beta_log = base, base + 1024, base + 2048, base + 4096, base + 4096
+    sd[0].ldw, sd[0].ksize, sd[0].dilation, sd[0].alpha = 60, 3, 1, 1.0
+    flt = ctypes.c_void_p(base + 8192)
+    assert lib.svcmi_snake_conv_group_lp(sd, 1, flt, 1, 4, 20, 20, 2, None) == -2       # bf16 is not a mode of this kernel: SVCMI_EUNSUPPORTED
+    assert lib.svcmi_snake_conv_group_lp(sd, 1, flt, 1, 4, 40, 40, 3, None) == -2       # 40 channels stay on the GEMM path
+    sd[0].y = base + 2048 + 8
+    assert lib.svcmi_snake_conv_group_lp(sd, 1, flt, 1, 4, 20, 20, 3, None) == -3       # float4 epilogue: SVCMI_EALIGN
+    sd[0].y = base + 2048
+    sd[0].ldw = 58
+    assert lib.svcmi_snake_conv_group_lp(sd, 1, flt, 1, 4, 20, 20, 3, None) == -1       # ldw < ksize * ld / not a multiple of 4
+    sd[0].ldw, sd[0].y = 60, base
+    assert lib.svcmi_snake_conv_group_lp(sd, 1, flt, 1, 4, 20, 20, 3, None) == -1       # x == y: halo reads, not an in-place op
     # reduced-precision entry points: unknown precision / null descriptors / bad image geometry are rejected before any launch
     assert lib.svcmi_conv_gemm_lp(None, 1, None) == -1 and lib.svcmi_conv_gemm_lp(ctypes.byref(d), 0, None) == -1
     assert lib.svcmi_conv_gemm_lp(ctypes.byref(d), 7, None) == -1
