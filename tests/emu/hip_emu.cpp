@@ -3,6 +3,10 @@
 
 #include <ucontext.h>
 
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <random>
 #include <vector>
 
 namespace emu {
@@ -92,6 +96,14 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
     g_blockDim = block;
     g_gridDim = grid;
     g_nthreads = nt;
+    int mode = 0;
+    unsigned seed = 1;
+    if (const char* e = getenv("SVCMI_EMU_ORDER")) {
+        if (strncmp(e, "reverse", 7) == 0) mode = 1;
+        else if (strncmp(e, "shuffle", 7) == 0) { mode = 2; if (e[7] == ':') seed = (unsigned)atoi(e + 8); }
+    }
+    std::mt19937 rng(seed);
+    std::vector<int> order(nt);
     for (unsigned bz = 0; bz < grid.z; ++bz)
         for (unsigned by = 0; by < grid.y; ++by)
             for (unsigned bx = 0; bx < grid.x; ++bx) {
@@ -116,7 +128,13 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
                 int remaining = nt;
                 while (remaining > 0) {
                     unsigned long ev = g_events;
-                    for (int t = 0; t < nt; ++t) {
+                    // SVCMI_EMU_ORDER = reverse | shuffle[:seed]: another order of the fibers inside every scheduling round.  A kernel whose
+                    // result depends on it has a cross-thread hazard inside one barrier interval (a missing __syncthreads): the race check
+                    // of tests/test_kernels_emu.py runs the half-step kernels under all three orders.
+                    for (int t = 0; t < nt; ++t) order[t] = mode == 1 ? nt - 1 - t : t;
+                    if (mode == 2) std::shuffle(order.begin(), order.end(), rng);
+                    for (int tt = 0; tt < nt; ++tt) {
+                        const int t = order[tt];
                         Fiber& f = g_fibers[t];
                         if (f.done) continue;
                         g_cur = &f;

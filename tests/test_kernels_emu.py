@@ -177,3 +177,23 @@ def test_outputs16(ops):
 @pytest.mark.parametrize("case", K.ATTN16_CASES, ids=lambda c: c["id"])
 def test_attention16(ops, case):
     K.check_attention16(ops, case, "cpu")
+
+
+@pytest.mark.parametrize("order", ["reverse", "shuffle:5"])
+def test_kernels_do_not_depend_on_the_thread_order_inside_a_barrier_interval(ops, order, monkeypatch):
+    """The emulator runs the fibers of a block in thread order between barriers; SVCMI_EMU_ORDER makes it run them backwards / shuffled
+    (tests/emu/hip_emu.cpp).  A kernel with a missing __syncthreads (a thread reading LDS another thread writes in the same interval)
+    gives different results then: the LDS-heavy kernels -- the half-step kernels in all forms, the fused AMP block, GEMM, attention,
+    split-K LayerNorm -- are checked against their references under both orders."""
+    monkeypatch.setenv("SVCMI_EMU_ORDER", order)
+    K.check_snake_conv_group_lp(ops, "cpu", c=20, ld=20, B=1, n=300, precision="f16w2")
+    K.check_snake_conv_group_lp(ops, "cpu", c=10, ld=12, B=2, n=150, precision="f16")
+    K.check_snake_conv_group(ops, "cpu", c=20, ld=20, B=1, n=300)
+    K.check_snake_conv_group(ops, "cpu", c=10, ld=12, B=2, n=150)
+    K.check_amp_block_group(ops, "cpu", c=10, ld=12, B=1, n=300, variants=(1,), nblocks=2)
+    K.check_snake_post(ops, "cpu", B=1, n=300)
+    K.check_conv(ops, K.CONV_CASES_SMALL[1], "cpu")
+    K.check_conv(ops, K.CONV_CASES_SMALL[3], "cpu")
+    K.check_attention(ops, K.ATTN_CASES_SMALL[0], "cpu")
+    K.check_attention(ops, K.ATTN_CASES_LDS[0], "cpu")
+    K.check_splitk_layernorm(ops, "cpu", B=1, S=3, T=5, c=1280)
