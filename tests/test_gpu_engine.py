@@ -180,6 +180,18 @@ def test_30s_clip_second_chunk_against_oracle(ops):
     assert err <= E.WAVE_TOL
 
 
+def test_streaming_decoder_tiles_with_the_matrix_core_half_steps(ops):
+    """The time-tiled generator with the narrow stages' matrix-core half-steps in the path.  fp32, B = 1 (the fp32 matrix-core form at 20
+    channels, chosen by the batch size alone): tiles reproduce the untiled generator bit for bit.  Mixed policy (configs[4] as bench.py
+    runs it): the eligibility of a launch for the 16-bit kernels follows its size, so tiles differ from the whole chunk by roundings of
+    the mode -- inside the mode's error class, measured here (round 4: 3.4e-4)."""
+    hp = C.base_hp()
+    print("fp32 B = 1, tiled vs default path:", E.check_streaming_decoder(ops, "cuda", hp, T=700, tiles=(256, 97), B=1))
+    d = E.check_streaming_decoder(ops, "cuda", hp, T=700, tiles=(256, 97), B=1, precision="mixed")
+    print("mixed: largest difference between a tiling and the untiled chunk %.2e" % d)
+    assert d <= 1e-3
+
+
 def test_streaming_decoder_is_bit_identical_and_matches_oracle_on_30s_chunk(ops):
     """configs[4]: the time-tiled ("streaming") generator inside the reference chunks of a 30 s clip.  Tiles of 256 / 500 / 1000
     frames reproduce the untiled generator bit for bit at base.yaml widths (B = 2, T = 1300), and the second chunk of the 30 s

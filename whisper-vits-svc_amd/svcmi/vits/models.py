@@ -41,8 +41,9 @@ class SynthesizerInfer:
         # Streaming decoder (BASELINE.json configs[4]): None = the generator sees a whole synthesis chunk;
         # N = it runs over time tiles of N frames plus a STREAM_HALO-frame halo on each side that is computed and discarded.
         # The generator's exact receptive field is < 31 frames (see STREAM_HALO) and every kernel's arithmetic for an output row is
-        # independent of the row's position in a launch, so the kept samples are BIT-IDENTICAL for every N (split-K is pinned
-        # off in this mode: its slice count would otherwise follow the problem size).  The reference's own chunk seams
+        # independent of the row's position in a launch, so the kept samples are BIT-IDENTICAL for every N in fp32 (split-K is pinned
+        # off in this mode: its slice count would otherwise follow the problem size; in the 16-bit modes a launch's eligibility for the
+        # 16-bit kernels follows its size too, so tilings there agree to the mode's rounding, 3e-4 under "mixed").  The reference's own chunk seams
         # (svc_inference.py:94-131) are untouched: tiling happens inside a chunk.
         self.stream_frames = None
         # svc_infer: synthesis chunks of one clip in flight on this many HIP streams (1 = one after the other, the reference's order);
