@@ -30,6 +30,19 @@ constexpr int DMAX = 5;      // largest dilation (bigv.py dilations 1, 3, 5)
 
 #include "snake_math.h"
 
+// Build experiment for round 5 (scripts/build_variant.sh addr32 -DSVCMI_TILE_ADDR32=1; default 0 = the validated code): the x window of the
+// activation phase indexed as clamp(t) * CP in 32-bit arithmetic (ld == CP for every accepted shape, len * ld < 2^31) instead of a 64-bit
+// multiply-add per load -- the quarter-rate part of the ~170 address instructions per work item.  Its results were right on
+// hardware in the r04u probes (the variant "i0"); not yet timed.
+#ifndef SVCMI_TILE_ADDR32
+#define SVCMI_TILE_ADDR32 0
+#endif
+template <int CP>
+__device__ __forceinline__ float tile_x(const float* xc, int t, int n, int ld) {
+    if constexpr (SVCMI_TILE_ADDR32 != 0) return xc[clampi(t, 0, n - 1) * CP];
+    else return xc[(long long)clampi(t, 0, n - 1) * ld];
+}
+
 struct AmpArgs {
     const float* x; const float* w; const float* bias; const float* res; float* y;
     const float* alpha_log; const float* beta_log; const float* filt;
@@ -68,7 +81,7 @@ __device__ __forceinline__ void snake_tile(float* S, const float* xb, const floa
                 const float* xc = xb + ch;
                 SnakeWindow<RT + 10> xw;
 #pragma unroll
-                for (int i = 0; i < RT + 10; ++i) xw.set(i, xc[(long long)clampi(t0 - 5 + i, 0, n - 1) * ld]);
+                for (int i = 0; i < RT + 10; ++i) xw.set(i, tile_x<CP>(xc, t0 - 5 + i, n, ld));
                 snake_run<RT>(xw, f, a, inv_b, xc, ld, n, t0, out);
 #pragma unroll
                 for (int r = 0; r < RT; ++r) {
@@ -122,7 +135,7 @@ __device__ __forceinline__ void snake_tile_u(float* smem, const float* xb, const
             const float* xc = xb + ch;
             SnakeWindow<RT + 5> xw;
 #pragma unroll
-            for (int i = 0; i < RT + 5; ++i) xw.set(i, xc[(long long)clampi(tq0 - 5 + i, 0, n - 1) * ld]);
+            for (int i = 0; i < RT + 5; ++i) xw.set(i, tile_x<CP>(xc, tq0 - 5 + i, n, ld));
             snake_pairs<RT>(xw, f, a, inv_b, xc, ld, n, tq0, s2);
         }
 #pragma unroll
