@@ -53,8 +53,13 @@ __device__ __forceinline__ const float* tile_column(const float* xc) {
 }
 template <int CP>
 __device__ __forceinline__ float tile_x(const float* xc, int t, int n, int ld) {
+#if SVCMI_TILE_ADDR32 == 2 && !defined(SVCMI_EMU)
+    // (behind the opaque pointer the compiler no longer knows the address space: say "global", or the loads become flat_load)
+    return ((const __attribute__((address_space(1))) float*)xc)[tile_row_offset<CP>(clampi(t, 0, n - 1))];
+#else
     if constexpr (SVCMI_TILE_ADDR32 != 0) return xc[tile_row_offset<CP>(clampi(t, 0, n - 1))];
     else return xc[(long long)clampi(t, 0, n - 1) * ld];
+#endif
 }
 
 struct AmpArgs {
