@@ -135,6 +135,36 @@ __device__ __forceinline__ void snake_up_taps(const float (&f)[12], svcmi_f32x2 
     for (int j = 0; j < 6; ++j) g2[j] = svcmi_f32x2{2.f * f[2 * j], 2.f * f[2 * j + 1]};
 }
 
+// The two 6-tap packed FMA chains of a work item: y2[m] = sum_j g2[j] * x[5 - j + m] (up-sampler) and out[r] = sum_i f2[i] . P[r + i]
+// (decimating low-pass).  Written value by value the compiler emits each chain as six DEPENDENT v_pk_fma_f32 on one accumulator with an
+// s_nop between them (ISA of round 4: 78 s_nop per U-fill work item); SVCMI_SNAKE_INTERLEAVE = 1 (build experiment for round 5, default 0 =
+// the validated instruction stream) walks the taps in the outer loop and the values in the inner one, so consecutive instructions belong to
+// different chains.  Same operations per value in the same order: bit-identical results either way.
+#ifndef SVCMI_SNAKE_INTERLEAVE
+#define SVCMI_SNAKE_INTERLEAVE 0
+#endif
+template <int NP, class Window>
+__device__ __forceinline__ void snake_upsample(const Window& xw, const svcmi_f32x2 (&g2)[6], svcmi_f32x2 (&y2)[NP]) {
+#pragma unroll
+    for (int m = 0; m < NP; ++m) y2[m] = svcmi_splat2(0.f);
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int m = 0; m < NP; ++m) y2[m] = svcmi_fma2(g2[j], xw.splat(5 - j + m), y2[m]);
+}
+template <int NR>
+__device__ __forceinline__ void snake_fir_taps(const svcmi_f32x2 (&P)[NR + 5], const svcmi_f32x2 (&f2)[6], float (&out)[NR]) {
+    svcmi_f32x2 z[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) z[r] = svcmi_splat2(0.f);
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) z[r] = svcmi_fma2(f2[i], P[r + i], z[r]);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) out[r] = z[r][0] + z[r][1];
+}
+
 // s_up[u] for one up-sampled index 0 <= u < 2n straight from global memory; only the runs that touch a sequence end evaluate
 // it (once each), for the replicate padding of the low-pass input (filter.py:86-95).
 __device__ __forceinline__ float snake_s_at(const float* xc, int ld, int n, int u, const float* f, float a, float inv_b) {
@@ -158,6 +188,9 @@ __device__ __forceinline__ void snake_run(const SnakeWindow<RT + 10>& xw, const 
     snake_up_taps(f, g2);
     // s2[m] = (s_up[2*t0 - 5 + 2m], s_up[2*t0 - 5 + 2m + 1]): polyphase up-sampler + SnakeBeta, each value computed once
     svcmi_f32x2 s2[RT + 5], y2[RT + 5];
+#if SVCMI_SNAKE_INTERLEAVE
+    snake_upsample<RT + 5>(xw, g2, y2);
+#else
 #pragma unroll
     for (int m = 0; m < RT + 5; ++m) {
         svcmi_f32x2 y = svcmi_splat2(0.f);          // (odd phase: even taps, even phase: odd taps)
@@ -165,6 +198,7 @@ __device__ __forceinline__ void snake_run(const SnakeWindow<RT + 10>& xw, const 
         for (int j = 0; j < 6; ++j) y = svcmi_fma2(g2[j], xw.splat(5 - j + m), y);
         y2[m] = y;
     }
+#endif
     snake_fn2_all<RT + 5>(y2, a, inv_b, k, s2);
     const int u0 = 2 * t0 - 5;
     if (u0 < 0 || u0 + 2 * RT + 9 > 2 * n - 1) {      // replicate padding of the low-pass input
@@ -178,6 +212,9 @@ __device__ __forceinline__ void snake_run(const SnakeWindow<RT + 10>& xw, const 
                 s2[m][h] = u < 0 ? s_first : (u > 2 * n - 1 ? s_last : s2[m][h]);
             }
     }
+#if SVCMI_SNAKE_INTERLEAVE
+    snake_fir_taps<RT>(s2, f2, out);
+#else
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
         svcmi_f32x2 z = svcmi_splat2(0.f);
@@ -185,6 +222,7 @@ __device__ __forceinline__ void snake_run(const SnakeWindow<RT + 10>& xw, const 
         for (int i = 0; i < 6; ++i) z = svcmi_fma2(f2[i], s2[r + i], z);
         out[r] = z[0] + z[1];
     }
+#endif
 }
 
 // The two halves of snake_run as separate steps, for kernels that keep the up-sampled SnakeBeta values of a whole tile in LDS so that
@@ -199,6 +237,9 @@ __device__ __forceinline__ void snake_pairs(const SnakeWindow<NP + 5>& xw, const
     svcmi_f32x2 g2[6];
     snake_up_taps(f, g2);
     svcmi_f32x2 y2[NP];
+#if SVCMI_SNAKE_INTERLEAVE
+    snake_upsample<NP>(xw, g2, y2);
+#else
 #pragma unroll
     for (int m = 0; m < NP; ++m) {
         svcmi_f32x2 y = svcmi_splat2(0.f);
@@ -206,6 +247,7 @@ __device__ __forceinline__ void snake_pairs(const SnakeWindow<NP + 5>& xw, const
         for (int j = 0; j < 6; ++j) y = svcmi_fma2(g2[j], xw.splat(5 - j + m), y);
         y2[m] = y;
     }
+#endif
     snake_fn2_all<NP>(y2, a, inv_b, k, s2);
     const int u0 = 2 * tq0 - 5;
     if (u0 < 0 || u0 + 2 * NP - 1 > 2 * n - 1) {      // replicate padding of the low-pass input (filter.py:86-95)
@@ -226,6 +268,9 @@ __device__ __forceinline__ void snake_fir(const svcmi_f32x2 (&P)[NR + 5], const 
     svcmi_f32x2 f2[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) f2[j] = svcmi_f32x2{f[2 * j], f[2 * j + 1]};
+#if SVCMI_SNAKE_INTERLEAVE
+    snake_fir_taps<NR>(P, f2, out);
+#else
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         svcmi_f32x2 z = svcmi_splat2(0.f);
@@ -233,4 +278,5 @@ __device__ __forceinline__ void snake_fir(const svcmi_f32x2 (&P)[NR + 5], const 
         for (int i = 0; i < 6; ++i) z = svcmi_fma2(f2[i], P[r + i], z);
         out[r] = z[0] + z[1];
     }
+#endif
 }
