@@ -515,7 +515,8 @@ def main():
     if world > 1:
         vw = D.broadcast_packed(vw, 0, device)
         if need_whisper:
-            ww = D.broadcast_packed(ww, 0, device)
+            # a Whisper that RUNS in fp16 (configs[4]) travels as fp16: 0.96 GB instead of 1.91 GB over xGMI (svcmi.dist.gemm_operands)
+            ww = D.broadcast_packed(ww, 0, device, fp16_filter=D.gemm_operands() if norm(wprec) == "f16" else None)
         torch.cuda.synchronize()
     log(f"[rank {rank}] weights ready in {time.perf_counter() - t0:.1f}s (rank 0: synthetic checkpoint {t_make:.1f}s + fold / pack / upload "
         f"{t1 - t0 - t_make:.1f}s; broadcast {time.perf_counter() - t1:.1f}s)")
@@ -605,6 +606,9 @@ def main():
                    "clips_in_flight": inflight,
                    "world_size": world, "dist_backend": (dist.get_backend() if world > 1 else None),
                    "rccl_ranks_seen": ranks_seen(world, device),
+                   # multi-rank runs of an f16 Whisper ship its GEMM operands as fp16 (every rank, rank 0 included, then holds the
+                   # fp16-rounded weights: the live error's fp32 leg uses them too, i.e. it measures activation rounding only)
+                   "whisper_weights_wire": "f16" if (world > 1 and need_whisper and norm(wprec) == "f16") else "f32",
                    "weights": ("rank 0 packs, one broadcast of the packed arena per model (" + str(dist.get_backend()) + ")") if world > 1 else "packed on this rank",
                    "per_gpu_value": round(value / world, 2), "realtime_factor": round(value / world, 2)},
     }

@@ -219,7 +219,8 @@ int svcmi_attention16(const void* q, const void* k, const void* v, int32_t ld16,
 /* Anti-aliased SnakeBeta (vits_decoder/alias/act.py:124-129): 2x Kaiser-sinc polyphase upsample with
  * replicate padding (resample.py:25-33), x + sin^2(x*e^alpha)/(e^beta + 1e-9) (act.py:79-92), 12-tap
  * low-pass + 2x decimation (filter.py:86-95).  x,y: [batch][len][ld] time-major, c <= ld channels;
- * alpha_log/beta_log: [c]; filt: the 12 taps (filter.py:28-57).  SURVEY.md A.5. */
+ * alpha_log/beta_log: [c]; filt: the 12 taps (filter.py:28-57).  SURVEY.md A.5.  One batch item is addressed with 32-bit byte
+ * offsets: len * ld * 4 >= 2^31 returns SVCMI_EUNSUPPORTED (a 32 kHz x 10-channel tensor of that size is 1.5 hours of audio). */
 int svcmi_snake_alias_f32(const float* x, float* y, const float* alpha_log, const float* beta_log,
                           const float* filt, int32_t batch, int32_t len, int32_t c, int32_t ld, void* stream);
 /* The same activation for up to 3 tensors of one shape in one launch (x[i] -> y[i] with alpha_log[i] / beta_log[i]): the AMP
@@ -522,11 +523,15 @@ int svcmi_whisper_encoder_fwd(const svcmi_whisper_model* m, const float* mel, co
 /* layer classes of the per-layer mixed-precision policy: prior encoder (enc_p: pre / hub / attention + FFN layers / proj, and its attention
  * kernel), flow (pre / in / res_skip / post of every coupling layer), the generator's trunk (conv_pre + every ups[i]), and the AMP-block
  * convolutions of generator stage i (SVCMI_CLASS_AMP0 + i; stages on the fused vector-ALU kernels compute in fp32 whatever this says) */
-enum svcmi_prec_class { SVCMI_CLASS_ENC = 0, SVCMI_CLASS_FLOW = 1, SVCMI_CLASS_UPS = 2, SVCMI_CLASS_AMP0 = 3 /* .. AMP0 + 4 */,
+#define SVCMI_AMP_CLASSES 5                         /* amp0 .. amp4; a generator with a sixth stage (SVCMI_MAX_STAGES) runs it in amp4's mode */
+enum svcmi_prec_class { SVCMI_CLASS_ENC = 0, SVCMI_CLASS_FLOW = 1, SVCMI_CLASS_UPS = 2, SVCMI_CLASS_AMP0 = 3 /* .. AMP0 + SVCMI_AMP_CLASSES - 1 */,
                         /* the prior encoder's ATTENTION kernel: SVCMI_PREC_BF16 / _F16 = both products on the 16-bit matrix cores
                          * (svcmi_attention16, from a 16-bit copy of the QKV projection's output), anything else = the fp32 kernel */
                         SVCMI_CLASS_ENC_ATTN = 8 };
 #define SVCMI_PREC_CLASSES 12
+#ifdef __cplusplus
+static_assert(SVCMI_CLASS_AMP0 + SVCMI_AMP_CLASSES <= SVCMI_CLASS_ENC_ATTN, "AMP classes must not reach the encoder-attention class");
+#endif
 typedef struct svcmi_enc_layer {                    /* attentions.Encoder layer i, vits/attentions.py:36-72 */
     svcmi_weight qkv, o, f1, f2;                    /* conv_q|k|v fused, conv_o, FFN conv_1 / conv_2 */
     const float *rel_k, *rel_v;                     /* emb_rel_k / emb_rel_v [2*window+1][H/heads] */

@@ -2,8 +2,11 @@
 
 ``log_mel_spectrogram`` restates whisper/audio.py:68-100 (torch.stft on the CPU).  ``slaney_mel_filterbank`` restates
 ``librosa.filters.mel(sr=16000, n_fft=400, n_mels=80)`` (whisper/audio.py:65) from librosa's published algorithm --
-librosa is an un-vendored dependency that is not installed here, so this one matrix is PARITY UNPINNED (SURVEY.md 8c);
-everything downstream of it is pinned against the reference function by oracle/make_golden.py (tests/golden/logmel_*.npz).
+librosa is an un-vendored dependency that is not installed here, so this one matrix cannot be compared with librosa's own
+output; since round 5 it is pinned against an INDEPENDENT implementation of the same published construction,
+``transformers.audio_utils.mel_filter_bank(201, 80, 0, 8000, 16000, norm="slaney", mel_scale="slaney")`` (9.2e-10 max-abs,
+tests/test_independent_pins.py).  Everything downstream of it is pinned against the reference function by oracle/make_golden.py
+(tests/golden/logmel_*.npz).
 """
 import math
 

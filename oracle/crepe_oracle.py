@@ -8,7 +8,9 @@ Restates, with every random draw as an explicit argument:
   * pitch/inference.py:74-99 compute_f0_sing (noise 1e-3, hop 320, batches of 512 frames, repeat x2, mean-5)
 Pinned against the reference package by oracle/make_golden.py, EXCEPT the Viterbi routine: the reference calls
 ``librosa.sequence.viterbi`` (un-vendored, not installed) -- restated below from its documented algorithm and injected
-into the reference when the fixture is made, i.e. PARITY UNPINNED for that one function (like the mel filterbank).
+into the reference when the fixture is made, i.e. not comparable with librosa's own output.  Since round 5 the dynamic programme is
+pinned against GROUND TRUTH instead: every path of small trellises enumerated (S <= 5 states, T <= 6 frames, random and banded
+transitions, exact ties), tests/test_independent_pins.py.
 """
 import numpy as np
 import torch

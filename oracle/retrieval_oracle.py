@@ -4,8 +4,9 @@ Follows feature_retrieval/index.py:57-62 (``retriv``) and :75-94 (``_weight_near
 faiss (faiss-cpu 1.7.4, requirements.txt:17, NOT installed here): ``search_and_reconstruct`` on a
 METRIC_L2 index returns the k smallest SQUARED L2 distances in ascending order with the stored vectors.  This restatement
 does the exhaustive search (IVF with nprobe = nlist); the reference's nprobe = 1 (index.py:150) approximates it.
-Parity unpinned: no faiss here, so there is no reference output for this row; the weighting lines are numpy and are
-restated operation by operation.
+No faiss here, so there is no reference output for this row (parity unpinned against faiss itself); the weighting lines are
+numpy and are restated operation by operation, and since round 5 the search semantics (exact kNN; nearest-centroid cell + exact kNN inside
+it for nprobe = 1) are cross-checked against scikit-learn's brute-force NearestNeighbors (tests/test_independent_pins.py).
 
 ``ivf_*`` / ``kmeans_faiss`` restate what the reference actually runs -- faiss-cpu 1.7.4 (requirements.txt:17) IndexIVFFlat with
 nprobe = 1 (index.py:145-151) and its k-means trainer (Clustering.cpp) -- from faiss's published sources, equally unpinned.

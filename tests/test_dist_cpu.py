@@ -195,3 +195,74 @@ def test_pack_arena_round_trip_single_process():
             assert torch.equal(a[k], b[k]) and b[k].data_ptr() % 16 == 0
     assert torch.equal(w.pos, w2.pos) and torch.equal(w.conv2_w, w2.conv2_w)
     assert D.broadcast_packed(w) is w                             # world size 1: identity
+
+
+def test_packed_arena_broadcast_and_config3_plan_world8():
+    """BASELINE.json configs[3] at its real world size -- 8 ranks over gloo, ONE packed-arena broadcast, 512
+    utterances -> 64 per rank -> 4 batches of 16, every utterance exactly once, bit-identical weights everywhere."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_packed_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[0] for r in res] == list(range(8))
+    assert len({r[1] for r in res}) == 1 and res[0][1] > 500 and len({r[2] for r in res}) == 1      # tensor count and digest agree
+    assert all(r[3] == [16] * 4 for r in res)
+    assert sorted(i for r in res for i in r[4]) == list(range(512))
+
+
+def _half_wire_worker(rank, world, port, q):
+    """An f16 Whisper's wire format (configs[4]): large GEMM operands as fp16 in a side arena, everything else fp32."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    D.init_from_env(backend="gloo")
+    from svcmi import weights as PW
+    from workload import config as C, weights as W
+    ck = W.make_whisper_state(C.WHISPER_TINY_TEST)
+    w = PW.WhisperWeights(ck, "cpu") if rank == 0 else None
+    flt = D.gemm_operands(min_elements=1 << 10)
+    got = D.broadcast_packed(w, src=0, device="cpu", fp16_filter=flt)
+    ref = PW.WhisperWeights(ck, "cpu")                      # (every rank can rebuild the seeded weights: the expected values)
+    n_half = n_full = 0
+    for a, b in zip(ref.blocks, got.blocks):
+        for k in a:
+            if flt(k, a[k]):
+                assert torch.equal(b[k], a[k].half().float())          # the fp16-rounded operand, on EVERY rank incl. the source
+                n_half += 1
+            else:
+                assert torch.equal(b[k], a[k])
+                n_full += 1
+            assert b[k].dtype == torch.float32 and b[k].data_ptr() % 16 == 0
+    assert torch.equal(got.pos, ref.pos)
+    q.put((rank, n_half, n_full))
+    torch.distributed.destroy_process_group()
+
+
+def test_fp16_wire_format_of_the_packed_broadcast_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_half_wire_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1:] == res[1][1:] and res[0][1] >= 4 and res[0][2] >= 4
+
+
+def test_fp16_side_arena_halves_the_wire_bytes_single_process():
+    from svcmi import weights as PW
+    from workload import config as C, weights as W
+    w = PW.WhisperWeights(W.make_whisper_state(C.WHISPER_TINY_TEST), "cpu")
+    _, full = D.pack_arena(w)
+    skel, arena, arena16 = D.pack_arena(w, fp16_filter=D.gemm_operands(min_elements=1 << 10))
+    assert arena16.dtype == torch.float16 and arena.numel() + arena16.numel() <= full.numel() + 64 * 1024
+    assert 4 * arena.numel() + 2 * arena16.numel() < 0.75 * 4 * full.numel()
+    w2 = D.unpack_arena(skel, arena, arena16)
+    assert torch.equal(w2.blocks[0]["qkv_w"], w.blocks[0]["qkv_w"].half().float()) and torch.equal(w2.blocks[0]["qkv_b"], w.blocks[0]["qkv_b"])

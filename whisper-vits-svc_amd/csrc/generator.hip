@@ -57,7 +57,7 @@ __global__ __launch_bounds__(TPB) void snake_alias_kernel(SnakeArgs p) {
         // base, advanced by ld per row -- the general form costs a clamp + a 64-bit multiply-add + a 64-bit add per load (ISA: 90 of the
         // ~520 vector instructions of a work item were address arithmetic)
         const float* xu = svcmi_opaque_uniform(p.x[gi] + (long long)b * n * ld);
-        const unsigned o = 4u * (unsigned)((t0 - 5) * ld + ch), step = 4u * (unsigned)ld;       // BYTE offsets < 2^32: tensors are < 2^29 bytes
+        const unsigned o = 4u * (unsigned)((t0 - 5) * ld + ch), step = 4u * (unsigned)ld;       // BYTE offsets inside one batch item: the entry point rejects len * ld * 4 >= 2^31
 #pragma unroll
         for (int i = 0; i < RT + 10; ++i) xw.set(i, svcmi_load_saddr(xu, o + (unsigned)i * step));
     } else {
@@ -190,6 +190,7 @@ extern "C" int svcmi_snake_alias_group_f32(const float* const* x, float* const* 
     if (y16 && svcmi_fmt16(y16_format) < 0) return SVCMI_EINVAL;
     if (batch <= 0 || len <= 0 || c <= 0 || ld < c) return SVCMI_EINVAL;
     if (batch > 65535) return SVCMI_EUNSUPPORTED;
+    if ((long long)len * ld * 4 >= (1LL << 31)) return SVCMI_EUNSUPPORTED;      // the interior runs form 32-bit byte offsets inside ONE batch item (int arithmetic)
     SnakeArgs a;
     for (int i = 0; i < SNAKE_GROUP; ++i) {
         const int j = i < count ? i : 0;

@@ -628,7 +628,8 @@ bool amp_stage_grouped(Ctx& c, const svcmi_synth_model& m, const svcmi_gen_stage
     const int64_t n = (int64_t)B * L * cp, bs = L * cp;
     if (fused && g_amp_block && svcmi_amp_block_group_supported(st.c, cp) && nd <= 3) {
         // narrow stages: every AMP block as ONE launch with its tile resident in LDS over all 2 * nd half-steps (csrc/amp_block.hip);
-        // bit-identical to the half-step launches below
+        // bit-identical to the VECTOR-ALU half-step launches below (the grouped entry point takes the fp32 matrix-core half-step at
+        // 20 channels and batch <= 2 -- amp_fused.hip, knob amp_mfma -- which sums in another order: 5e-6)
         bool ok = true;
         for (int j = 0; j < nb; ++j)
             for (int q = 0; q < nd; ++q) ok = ok && st.blocks[j].dil[q] >= 1 && st.blocks[j].dil[q] <= 5;
@@ -790,7 +791,7 @@ void generator_tile(Ctx& c, const svcmi_synth_model& m, const float* z, const fl
             nz.y = y; nz.y_bs = L * cp; nz.ldy = cp;
             conv(c, nz);
         }
-        c.prec = class_prec(m, SVCMI_CLASS_AMP0 + i);
+        c.prec = class_prec(m, SVCMI_CLASS_AMP0 + (i < SVCMI_AMP_CLASSES ? i : SVCMI_AMP_CLASSES - 1));   // a sixth stage shares the fifth stage's class
         if (!amp_stage_grouped(c, m, st, y, acc, B, L)) {
             c.ar.release(smark);
             float* xj = c.ar.f((int64_t)B * L * cp);

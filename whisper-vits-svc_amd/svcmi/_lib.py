@@ -15,6 +15,7 @@ PREC_F16W2, PREC_F16W2_A16 = 8, 9          # fp16 activations x split fp16 weigh
 PREC_MIXED = 7                     # svcmi_synth_model.precision only: per-class modes in class_prec[]
 PREC_CLASSES = 12
 CLASS_ENC, CLASS_FLOW, CLASS_UPS, CLASS_AMP0 = 0, 1, 2, 3
+AMP_CLASSES = 5                    # SVCMI_AMP_CLASSES
 CLASS_NAMES = {"enc": 0, "flow": 1, "ups": 2, "amp0": 3, "amp1": 4, "amp2": 5, "amp3": 6, "amp4": 7, "encattn": 8}
 # The default per-layer policy of the 16-bit synthesizer ("mixed"; scripts/precision_sensitivity.py ranks the classes on the CPU oracle,
 # tests/test_gpu_precision.py measures the candidates on MI355X -- profiles/r04e_precision_report.json): the layers every sample passes
@@ -38,9 +39,13 @@ def parse_precision(p):
     int code, or an already parsed tuple."""
     if isinstance(p, tuple):
         return p
-    if isinstance(p, int):
+    if isinstance(p, int) and not isinstance(p, bool):
+        if p == PREC_MIXED:
+            raise SvcmiError("precision code SVCMI_PREC_MIXED needs its per-class modes: pass \"mixed\", \"mixed:...\" or a dict")
+        if p not in set(PRECISIONS.values()):
+            raise SvcmiError(f"unknown precision code {p}")
         return (p, None)
-    if p in PRECISIONS:
+    if (p is None or isinstance(p, str)) and p in PRECISIONS:
         return (PRECISIONS[p], None)
     pol = dict(MIXED_DEFAULT)
     if isinstance(p, dict):
@@ -53,7 +58,7 @@ def parse_precision(p):
         raise SvcmiError(f"unknown precision {p!r}")
     bad = [k for k in pol if k not in CLASS_NAMES] + [v for v in pol.values() if v not in PRECISIONS]
     if bad:
-        raise SvcmiError(f"mixed precision policy: unknown class / mode {bad}; classes {sorted(CLASS_NAMES)}, modes f32 / bf16x3 / bf16 / f16")
+        raise SvcmiError(f"mixed precision policy: unknown class / mode {bad}; classes {sorted(CLASS_NAMES)}, modes f32 / bf16x3 / bf16 / f16 / f16w2")
     cls = [0] * PREC_CLASSES
     for k, v in pol.items():
         cls[CLASS_NAMES[k]] = PRECISIONS[v]

@@ -115,7 +115,7 @@ def synth_cmodel(w, ops, prec=PREC_F32):
         state["cls"] = _lib.CLASS_UPS
         W(s.up, st["up_w"], st["up_b"])
         W(s.nz, st["nz_w"], st["nz_b"])
-        state["cls"] = min(_lib.CLASS_AMP0 + i, _lib.PREC_CLASSES - 1)
+        state["cls"] = _lib.CLASS_AMP0 + min(i, _lib.AMP_CLASSES - 1)        # a sixth stage shares amp4 (never the encoder-attention class at index 8)
         for j, blk in enumerate(st["blocks"]):
             b = s.blocks[j]
             if len(blk["d"]) > _lib.MAX_AMP_DILATIONS:

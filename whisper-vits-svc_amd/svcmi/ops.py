@@ -76,7 +76,10 @@ class Ops:
         self._tls = threading.local()          # `precision` is per calling thread (worker threads of the folder driver share one Ops)
         self._lock = threading.Lock()          # guards the lazily built per-tensor 16-bit weight images
         self.lp_min_flops = 1.5e9
-        # development knobs of the library (svcmi_tune_set: tile variants, fused / unfused paths -- never change results):
+        # development knobs of the library (svcmi_tune_set: tile variants, fused / unfused paths).  Tile / split / launch-shape knobs
+        # leave every result bit-identical; three select another KERNEL FORM of the narrow generator stages and change the fp32
+        # summation order (<= 5e-6 on the waveform) or the operand precision: amp_mfma (fp32 matrix-core half-step at 20 channels and
+        # batch <= 2 -- so fp32 bits are reproducible per batch class, <= 2 clips vs more), amp_block, amp_lp (fp16 operands).
         # SVCMI_TUNE="amp_block=0,amp_block_variant=2" applies them to this process (A/B runs of bench.py on the GPU box)
         for item in filter(None, os.environ.get("SVCMI_TUNE", "").split(",")):
             k, _, v = item.partition("=")
@@ -675,8 +678,9 @@ class Ops:
         return y if out16 is None else (y, y16)
 
     def act16_format(self):
-        """The 16-bit activation format of the current precision mode (``out16`` of the producers), None in fp32."""
-        return {PREC_BF16: torch.bfloat16, PREC_F16: torch.float16, PREC_BF16X3: SPLIT16}.get(self.precision)
+        """The 16-bit activation format of the current precision mode (``out16`` of the producers), None in fp32 (f16w2 = fp16 rows, as
+        fmt16_of() on the C side)."""
+        return {PREC_BF16: torch.bfloat16, PREC_F16: torch.float16, _lib.PREC_F16W2: torch.float16, PREC_BF16X3: SPLIT16}.get(self.precision)
 
     def viterbi_decode(self, prob, log_trans, batch_frames, minidx, maxidx, band=0):
         """prob [frames, 360] (sigmoid outputs), log_trans [360, 360] float64 -> decoded bins int32 [frames].
