@@ -9,6 +9,9 @@ import os
 import re
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from workload.stamp import csrc_sha  # noqa: E402
+
 
 def short(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
@@ -47,7 +50,7 @@ def main():
         if c.get("SQ_LDS_IDX_ACTIVE", 0.0) > 0:
             e["lds_bank_conflict_share"] = round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"], 4)
         res[k] = e
-    json.dump({"source": "rocprofv3 --pmc (two passes, --kernel-trace only) over `bench.py --steps 1 --warmup 1 --eager`",
+    json.dump({"csrc_sha": csrc_sha(), "source": "rocprofv3 --pmc (two passes, --kernel-trace only) over `bench.py --steps 1 --warmup 1 --eager`",
                "note": "mfma_pipe_utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs): cycle-based, i.e. "
                        "relative to the clock the chip actually ran at",
                "kernels": res}, open(out, "w"), indent=1)

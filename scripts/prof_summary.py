@@ -8,6 +8,9 @@ import os
 import re
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from workload.stamp import csrc_sha  # noqa: E402
+
 
 def short(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
@@ -42,7 +45,7 @@ def main():
     total = sum(a[1] for k, a in agg.items() if "spin_kernel" not in k and not a[2])
     with open(out, "w") as o:
         o.write(f"# rocprofv3 --kernel-trace --stats summary; durations in us; {steps:g} traced steps; "
-                f"total kernel time per step {total / steps / 1e3:.3f} ms (spin_kernel and one-time model-load dispatches excluded)\n")
+                f"total kernel time per step {total / steps / 1e3:.3f} ms (spin_kernel and one-time model-load dispatches excluded); csrc_sha {csrc_sha()}\n")
         o.write("kernel,calls,calls_per_step,total_us,avg_us,percent\n")
         for k, (n, d, setup) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             if setup:
@@ -51,7 +54,8 @@ def main():
                 o.write(f"{k},{n},{n / steps:.1f},{d:.1f},{d / n:.2f},{100 * d / total:.2f}\n")
         o.write("\n# per (kernel, grid in workgroups, block) -- top 50 by time\n")
         o.write("kernel,grid_x,grid_y,grid_z,block,vgpr,agpr,sgpr,lds,calls_per_step,avg_us,ms_per_step\n")
-        for key, (n, d) in sorted(by_grid.items(), key=lambda kv: -kv[1][1])[:50]:
+        setup = {k for k, a in agg.items() if a[2]} | {k for k in agg if "spin_kernel" in k}      # one-time dispatches are not per-step rows
+        for key, (n, d) in sorted(((k, v) for k, v in by_grid.items() if k[0] not in setup), key=lambda kv: -kv[1][1])[:50]:
             o.write(",".join(str(x) for x in key) + f",{n / steps:.1f},{d / n:.2f},{d / steps / 1e3:.3f}\n")
     print(open(out).read()[:6000])
 

@@ -12,6 +12,9 @@ import os
 import re
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from workload.stamp import csrc_sha  # noqa: E402
+
 
 def short(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
@@ -62,7 +65,7 @@ def main():
                                        "hbm_write_GB_per_step": round(wr / 1e9, 3), "note": "single + grouped launches"}
     total_r = sum(v["hbm_read_GB_per_step"] for k, v in kernels.items() if "(part)" not in k)
     total_w = sum(v["hbm_write_GB_per_step"] for k, v in kernels.items() if "(part)" not in k)
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) over "
+    json.dump({"csrc_sha": csrc_sha(), "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) over "
                          f"`bench.py --steps 2 --warmup 1 --eager`; {steps:g} traced steps (scripts/pmc_traffic.sh)",
                "units": "KB counters; fetched bytes = 2 x FETCH_SIZE x 1024 (gfx950: 128-B streaming requests tallied at 64 B), "
                         "written bytes = WRITE_SIZE x 1024",
