@@ -5,11 +5,13 @@ set -e
 NAME=$1; shift
 cd "$(dirname "$0")/../whisper-vits-svc_amd"
 mkdir -p _obj/$NAME svcmi/exp
+rm -f _obj/$NAME/*.o svcmi/exp/libsvcmi_$NAME.so
 for f in csrc/*.hip; do
   EXTRA=""
   [ "$(basename $f)" = amp_fused.hip ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form=1"      # (build.py FILE_FLAGS)
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $EXTRA "$@" -c $f -o _obj/$NAME/$(basename $f).o &
 done
 wait
+for f in csrc/*.hip; do [ -s _obj/$NAME/$(basename $f).o ] || { echo "build_variant: $f did not compile" >&2; exit 1; }; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o svcmi/exp/libsvcmi_$NAME.so _obj/$NAME/*.o
 echo svcmi/exp/libsvcmi_$NAME.so

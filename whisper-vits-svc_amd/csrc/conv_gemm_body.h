@@ -647,9 +647,15 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
     }
 }
 
+// Build experiment (scripts/build_variant.sh nst2 -DSVCMI_GEMM_NST=2): ring depth of the single-launch fp32 kernels.  The default 3-deep
+// ring of the 64x80 / 64x64 tiles is 61 / 49 KB of LDS = 2 / 3 resident blocks per CU; 2-deep is 41 / 33 KB = 3 / 4 blocks, and leaves
+// room for another lane's vector-ALU blocks beside two GEMM blocks when clips are in flight.
+#ifndef SVCMI_GEMM_NST
+#define SVCMI_GEMM_NST 0
+#endif
 template <int WM, int WN, int MODE, bool P16, int PREC = PREC_F32>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
-    conv_gemm_body<WM, WN, MODE, P16, 0, PREC>(p, (int)gridDim.x, (int)blockIdx.x);
+    conv_gemm_body<WM, WN, MODE, P16, (PREC == PREC_F32 && WM * WN <= 5 ? SVCMI_GEMM_NST : 0), PREC>(p, (int)gridDim.x, (int)blockIdx.x);
 }
 
 // Grouped launch: up to GROUP_MAX problems of identical tile policy / gather mode in ONE grid, blocks of problem 0 first.  The
