@@ -592,9 +592,16 @@ def main():
             lanes = GraphLanes([w.step for w in wls])
         graph = lanes.graphs[0]
         if inflight > 1 and not args.no_single_stream:   # the same K steps one clip at a time: latency of a clip, reported beside the line
-            dt = timed(lambda: lanes.launch(0), lanes.synchronize, args.steps, args.warmup)
+            one = lanes
+            if args.config == 1:       # a ONE-lane capture of the serving object (a clip alone on the chip keeps the 3-deep GEMM ring: svcmi/serving.py)
+                cl1 = ClipLanes(model, whisper, wl.T, wl.B, lanes=1, device=device)
+                cl1.stage(0, mel=wl.mel, vec=wl.vec, pit=wl.pit, spk=wl.spk, lengths=wl.lengths)
+                one = cl1.capture().lanes
+            dt = timed(lambda: one.launch(0), one.synchronize, args.steps, args.warmup)
             single = {"ms_per_step": round(1000.0 * dt / args.steps, 3),
                       "value": round(wl.audio_seconds_per_step * world / (dt / args.steps), 2)}
+            if args.config == 1:
+                single["capture"] = "one-lane ClipLanes (3-deep GEMM ring)"
         run = lanes.launch
     else:
         run = wl.step
@@ -622,7 +629,7 @@ def main():
                    "launch": ("hipGraph replay" if graph is not None else "eager") +
                              (f", {inflight} clips in flight (one lane = HIP stream + graph + static buffers each; GPU_MAX_HW_QUEUES="
                               f"{os.environ.get('GPU_MAX_HW_QUEUES')})" if inflight > 1 else ""),
-                   "clips_in_flight": inflight,
+                   "clips_in_flight": inflight, "gemm_ring2_mask": (cl.ring2 if (args.config == 1 and inflight > 1 and not args.eager) else 0),
                    "world_size": world, "dist_backend": (dist.get_backend() if world > 1 else None),
                    "rccl_ranks_seen": ranks_seen(world, device),
                    # multi-rank runs of an f16 Whisper ship its GEMM operands as fp16 (every rank, rank 0 included, then holds the

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SVCMI_ABI_VERSION 20
+#define SVCMI_ABI_VERSION 21
 
 enum svcmi_status { SVCMI_OK = 0, SVCMI_EINVAL = -1, SVCMI_EUNSUPPORTED = -2, SVCMI_EALIGN = -3 };
 
@@ -49,7 +49,12 @@ enum svcmi_conv_flags {
     SVCMI_CONV_TILE_P16_128x80 = 0x700,
     SVCMI_CONV_TILE_P16_64x160 = 0x800,
     SVCMI_CONV_TILE_64x128 = 0x900, /* reduced-precision entry points only */
-    SVCMI_CONV_TILE_MASK = 0xF00
+    SVCMI_CONV_TILE_MASK = 0xF00,
+    /* tuning knob: 2-deep operand ring instead of the 3-deep one of the 64-row fp32 tiles (64x64, P16 64x48 / 64x80): 33 / 41 KB of LDS
+     * per block instead of 49 / 61 KB = one more resident block per CU and room for other streams' blocks beside them.  Slower for a
+     * launch that has the chip to itself (one K-step of prefetch less), faster when several streams share it (clips in flight).  Results
+     * are bit-identical (the ring depth does not touch the summation order).  Ignored by launches that have no such instantiation. */
+    SVCMI_CONV_RING2 = 0x1000
 };
 
 int svcmi_abi_version(void);
@@ -247,6 +252,12 @@ int svcmi_block_mean_f32(const float* const* xs, int32_t count, float* y, int64_
 int svcmi_snake_conv_supported(int32_t c, int32_t ld, int32_t ksize, int32_t dilation);
 /* 1 where the fused kernel is also the FASTER choice on MI355X (narrowest stages); the facade follows it. */
 int svcmi_snake_conv_preferred(int32_t c, int32_t ld, int32_t ksize, int32_t dilation);
+/* The 40- / 80-channel stages' fp32 half-step as ONE launch (round 5): SnakeAlias of the time tile in LDS + a matrix-core convolution whose
+ * weight fragments stream from the packed fp32 image straight into registers.  Reached through svcmi_snake_conv_group_f32 with
+ * (c, ld) = (40, 40) or (80, 80), ksize in {3, 7, 11}, dilation 1..5, 16-byte aligned x / y / res / bias; fp32 products and sums (the
+ * summation order differs from svcmi_conv_gemm_f32's).  _preferred: the library's measured choice (knob "amp_gemm"). */
+int svcmi_snake_gemm_supported(int32_t c, int32_t ld, int32_t ksize, int32_t dilation);
+int svcmi_snake_gemm_preferred(int32_t c, int32_t ld, int32_t ksize, int32_t dilation);
 int svcmi_snake_conv_f32(const float* x, const float* w, const float* bias, const float* res, float* y,
                          const float* alpha_log, const float* beta_log, const float* filt,
                          int32_t batch, int32_t len, int32_t c, int32_t ld, int32_t ldw, int32_t ksize,
@@ -272,25 +283,6 @@ int svcmi_snake_conv_group_f32(const svcmi_snake_conv_desc* descs, int32_t count
 int svcmi_snake_conv_lp_supported(int32_t c, int32_t ld, int32_t ksize, int32_t dilation, int32_t precision);
 int svcmi_snake_conv_group_lp(const svcmi_snake_conv_desc* descs, int32_t count, const float* filt, int32_t batch,
                               int32_t len, int32_t c, int32_t ld, int32_t precision, void* stream);
-
-/* A WHOLE AMP block (vits_decoder/bigv.py:22-58, AMPBlock.forward :50-58) of a narrow stage as one launch, for up to 3 blocks of a stage
- * (3 / 7 / 11 taps; blockIdx.z) that share the stage input x:
- *     for q < n_dil:  x = x + conv2_q( SnakeAlias_{a2[q]}( conv1_q( SnakeAlias_{a1[q]}(x) ) ) ),   conv1_q dilated by dil[q], conv2_q by 1
- * with the time tile resident in LDS across all 2 * n_dil half-steps (halo per side = sum_q 10 + (ksize-1)/2 * (dil[q] + 1) samples,
- * recomputed per tile); y = the block's x after the last iteration (generator.py:188-194 then averages the blocks: svcmi_block_mean_f32).
- * Results equal the chain of svcmi_snake_conv_f32 half-steps bit for bit.  Weights / activation parameters as svcmi_snake_conv_f32 takes
- * them.  Supported: (c, ld) = (10, 12) and (20, 20), ksize in {3, 7, 11}, n_dil <= 3, dil <= 5 (svcmi_amp_block_group_supported).
- * x and the y's must not overlap. */
-typedef struct svcmi_amp_block_desc {
-    const float* x; float* y;
-    const float* w1[3]; const float* b1[3]; const float* w2[3]; const float* b2[3];
-    const float* a1_alpha[3]; const float* a1_beta[3]; const float* a2_alpha[3]; const float* a2_beta[3];
-    int32_t ldw1[3], ldw2[3], dil[3];
-    int32_t ksize, n_dil, reserved;
-} svcmi_amp_block_desc;
-int svcmi_amp_block_group_supported(int32_t c, int32_t ld);
-int svcmi_amp_block_group_f32(const svcmi_amp_block_desc* descs, int32_t count, const float* filt, int32_t batch, int32_t len,
-                              int32_t c, int32_t ld, void* stream);
 
 /* Stage entry of the narrow generator stages in one launch (vits_decoder/generator.py:183-186):
  *   y[b, u*q + r, co] = b_up[r*cp+co] + sum_{k<taps} sum_{ci<c_in} x[b, q + k - pad, ci] * w_up[r*cp+co, k*c_in + ci]      (ups[i], polyphase)
@@ -641,7 +633,7 @@ int svcmi_packed_model_info(const void* file, int64_t file_bytes, int32_t* kind,
 int svcmi_packed_model_bind(const void* file, int64_t file_bytes, const void* device_arena, void* model_out, int64_t model_bytes);
 
 /* Layout check for FFI bindings: out[i] = sizeof of svcmi_weight, svcmi_whisper_model, svcmi_synth_model, svcmi_synth_io,
- * svcmi_trace_record, svcmi_conv_desc, svcmi_snake_conv_desc, svcmi_amp_block_desc (in this order, up to `cap`); returns the count written.  A binding
+ * svcmi_trace_record, svcmi_conv_desc, svcmi_snake_conv_desc (in this order, up to `cap`); returns the count written.  A binding
  * compares them with its own struct sizes before it trusts a filled struct (svcmi/_lib.py does at load). */
 int svcmi_struct_sizes(int64_t* out, int32_t cap);
 

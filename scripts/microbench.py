@@ -56,57 +56,6 @@ def gemm(ops, tag, T, cin, n, k=1, dil=1, res=False, tiles=(0, 1, 2, 3), splits=
                 print(f"gemm {tag} tile={tile} split={sk}: {e}")
 
 
-def ampblock(ops, c, ld, L, B):
-    """One narrow generator stage (3 AMP blocks, k = 3 / 7 / 11, dilations 1 / 3 / 5): six grouped half-step launches
-    (svcmi_snake_conv_group_f32) against one launch of the fused block kernel (svcmi_amp_block_group_f32), every tile variant."""
-    from workload import weights as W
-    g = torch.Generator().manual_seed(c)
-    filt = W.kaiser_sinc_filter().view(-1).cuda()
-    x = torch.zeros(B, L, ld)
-    x[..., :c] = torch.randn(B, L, c, generator=g)
-    x = x.cuda()
-    blocks = []
-    for k in (3, 7, 11):
-        blk = dict(ksize=k, dil=[1, 3, 5], c1=[], c2=[], a1=[], a2=[])
-        for _ in range(3):
-            for key in ("c1", "c2"):
-                blk[key].append((PW.pack_conv(torch.randn(c, c, k, generator=g) / math.sqrt(c * k), ld, ld).cuda(), PW.pad_vec(torch.randn(c, generator=g) * 0.1, ld).cuda()))
-            for key in ("a1", "a2"):
-                al, be = torch.zeros(ld), torch.zeros(ld)
-                al[:c], be[:c] = torch.randn(c, generator=g) * 0.3, torch.randn(c, generator=g) * 0.3
-                blk[key].append((al.cuda(), be.cuda()))
-        blocks.append(blk)
-    t1 = [torch.empty_like(x) for _ in range(3)]
-    xa = [torch.empty_like(x) for _ in range(3)]
-    xb = [torch.empty_like(x) for _ in range(3)]
-
-    def chain():
-        cur = [x, x, x]
-        for q in range(3):
-            nxt = xa if q % 2 == 0 else xb
-            ops.snake_conv_group([dict(x=cur[j], alpha_log=b["a1"][q][0], beta_log=b["a1"][q][1], w=b["c1"][q][0], bias=b["c1"][q][1], ksize=b["ksize"],
-                                       dilation=b["dil"][q], out=t1[j]) for j, b in enumerate(blocks)], filt, c=c)
-            ops.snake_conv_group([dict(x=t1[j], alpha_log=b["a2"][q][0], beta_log=b["a2"][q][1], w=b["c2"][q][0], bias=b["c2"][q][1], ksize=b["ksize"],
-                                       dilation=1, res=cur[j], out=nxt[j]) for j, b in enumerate(blocks)], filt, c=c)
-            cur = nxt
-        return cur
-    want = [t.clone() for t in chain()]
-    us0 = timeit(chain, iters=10, warm=2)
-    fl = sum(4.0 * 3 * B * L * c * c * b["ksize"] for b in blocks)
-    print(f"ampblock c={c} L={L} B={B}: six grouped half-step launches {us0:9.1f} us  ({fl / us0 / 1e6:5.1f} TFLOP/s conv work)", flush=True)
-    for v in (1, 2, 3, 4):
-        ops.lib.svcmi_tune_set(b"amp_block_variant", v)
-        try:
-            got = ops.amp_block_group(x, blocks, filt, c=c)
-            same = all(torch.equal(a, b) for a, b in zip(got, want))
-            us = timeit(lambda: ops.amp_block_group(x, blocks, filt, c=c), iters=10, warm=2)
-            print(f"ampblock c={c} L={L} B={B}: fused block kernel, variant {v}      {us:9.1f} us  ({fl / us / 1e6:5.1f} TFLOP/s)  bit-identical {same}  x{us0 / us:.2f}", flush=True)
-        except Exception as e:      # noqa: BLE001
-            print(f"ampblock c={c} variant {v}: {e}")
-        finally:
-            ops.lib.svcmi_tune_set(b"amp_block_variant", 0)
-
-
 def main():
     global timeit
     what = sys.argv[1:] or ["gemm", "snake", "dec", "attn"]
@@ -131,10 +80,6 @@ def main():
                     print(f"attnrel B={B} T={T} attn_lds={code:3d}: {us:8.1f} us  {fl / us / 1e6:6.1f} TF/s  max diff to the register-fed kernel {float((o - base).abs().max()):.1e}", flush=True)
                 finally:
                     ops.lib.svcmi_tune_set(b"attn_lds", 0)
-    if "ampblock" in what:
-        for B in ((1, 16) if "quick" in what else (1, 4, 16)):
-            ampblock(ops, 10, 12, 320000, B)
-            ampblock(ops, 20, 20, 160000, B)
     if "gemm" in what:
         gemm(ops, "whisper_qkv", 500, 1280, 3840)
         gemm(ops, "whisper_o", 500, 1280, 1280, res=True, splits=(1, 0, 2, 4))
@@ -268,6 +213,36 @@ def main():
                         print(f"ampgroup C={C} n={n} d={d} B={B} amp_u={u}: {us:8.1f} us  {B * fl / us / 1e6:6.1f} TF/s", flush=True)
                 ops.lib.svcmi_tune_set(b"amp_u", 0)
         ops.lib.svcmi_tune_set(b"amp_tt", 0)
+    if "ampgemm" in what:     # 40- / 80-channel half-step: grouped SnakeAlias + grouped implicit GEMM (two launches) vs the one-launch fused form
+        filt = torch.tensor([0.00202896, 0.00938947, -0.02554346, -0.05765738, 0.12857258, 0.44320980, 0.44320980,
+                             0.12857258, -0.05765738, -0.02554346, 0.00938947, 0.00202896], device="cuda")
+        for (C, n, tile) in ((40, 80000, 4), (80, 20000, 6)):
+            for B in (1, 4):
+                fl = sum(2.0 * B * n * C * C * k for k in (3, 7, 11))
+                xs = [torch.randn(B, n, C, device="cuda") for _ in range(3)]
+                ts = [torch.empty(B, n, C, device="cuda") for _ in range(3)]
+                rs = [torch.randn(B, n, C, device="cuda") for _ in range(3)]
+                outs = [torch.empty(B, n, C, device="cuda") for _ in range(3)]
+                als = [torch.randn(C, device="cuda") * 0.3 for _ in range(3)]
+                bes = [torch.randn(C, device="cuda") * 0.3 for _ in range(3)]
+                ws = [PW.pack_conv(torch.randn(C, C, k) / math.sqrt(C * k), C, C).cuda() for k in (3, 7, 11)]
+                bs = [torch.randn(C, device="cuda") for _ in range(3)]
+                for d in (1, 5):
+                    def two():
+                        ops.snake_alias_group(xs, als, bes, filt, ts)
+                        ops.conv_group([dict(x=ts[j], w=ws[j], bias=bs[j], ksize=k, dilation=d, pad=(k - 1) * d // 2, res=rs[j], out=outs[j], tile=tile)
+                                        for j, k in enumerate((3, 7, 11))])
+                    us2 = timeit(two)
+                    ref = outs[2].clone()
+                    print(f"ampgemm C={C} n={n} B={B} d={d} SnakeAlias + implicit GEMM (2 launches): {us2:8.1f} us  {fl / us2 / 1e6:6.1f} TF/s", flush=True)
+                    probs = [dict(x=xs[j], alpha_log=als[j], beta_log=bes[j], w=ws[j], bias=bs[j], ksize=k, dilation=d, res=rs[j], out=outs[j])
+                             for j, k in enumerate((3, 7, 11))]
+                    for knob in (1, 2):
+                        ops.lib.svcmi_tune_set(b"amp_gemm", knob)
+                        us = timeit(lambda: ops.snake_conv_group(probs, filt, c=C))
+                        print(f"ampgemm C={C} n={n} B={B} d={d} fused, amp_gemm={knob}:                     {us:8.1f} us  {fl / us / 1e6:6.1f} TF/s  "
+                              f"x{us2 / us:.2f}  max diff {float((outs[2] - ref).abs().max()):.1e}", flush=True)
+                    ops.lib.svcmi_tune_set(b"amp_gemm", 1)
     if "amplp" in what:       # the grouped half-step: fp32 vector kernel vs the fp16 matrix-core variants, both activation-phase forms
         filt = torch.tensor([0.00202896, 0.00938947, -0.02554346, -0.05765738, 0.12857258, 0.44320980, 0.44320980,
                              0.12857258, -0.05765738, -0.02554346, 0.00938947, 0.00202896], device="cuda")

@@ -4,7 +4,8 @@
 // g++ -DSVCMI_EMU) on the CPU so that `pytest -m "not gpu"` can check tiling / indexing / masking
 // logic in a container without a GPU.  Each workgroup runs as blockDim cooperative fibers
 // (ucontext) on one OS thread; __syncthreads and wave-level collectives (shuffles, the fp32 MFMA)
-// are rendezvous points.  Blocks run sequentially, so `__shared__` is plain static storage.
+// are rendezvous points.  Blocks run sequentially by default, so `__shared__` is plain static storage (with red zones in the
+// sanitizer build); the -DSVCMI_EMU_TLS build runs K blocks at once on K lock-stepped OS threads, each with its own copy.
 // Nothing here is a fallback for the product: svcmi (Python) only ever loads the hipcc-built
 // library and refuses to run without it.
 #pragma once
@@ -21,7 +22,11 @@
 #define __host__
 #define __forceinline__ inline
 #define __launch_bounds__(...)
-#define __shared__ static
+#ifdef SVCMI_EMU_TLS
+#define __shared__ static thread_local      // one copy per resident block (= per executing OS thread): the SVCMI_EMU_BLOCKS=K mode of hip_emu.cpp
+#else
+#define __shared__ static                   // exactly the declared bytes; the sanitizer build puts red zones around it
+#endif
 
 struct dim3 {
     unsigned x, y, z;
@@ -51,7 +56,8 @@ typedef void* hipStream_t;
 
 namespace emu {
 struct Fiber;
-extern dim3 g_blockIdx, g_blockDim, g_gridDim;
+extern thread_local dim3 g_blockIdx;      // (one executing OS thread per resident block in the SVCMI_EMU_BLOCKS mode)
+extern dim3 g_blockDim, g_gridDim;
 const dim3& cur_tid();
 int cur_lane();
 void syncthreads();

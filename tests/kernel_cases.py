@@ -197,6 +197,25 @@ def check_conv(ops, c, device):
     _close(y, ref, 2e-5 if cin * k < 4096 else 1e-4, c["id"])
 
 
+
+def check_conv_ring2(ops, device, tile, n, cin=64, k=5, T=150, B=2):
+    """SVCMI_CONV_RING2 (2-deep operand ring of the 64-row fp32 tiles, for launches that share the chip): the same bits as the default
+    3-deep ring on every tile that has the instantiation (64x64, P16 64x48, P16 64x80), K ranges of 1 / 2 / many K-steps included;
+    ignored (not an error) where there is none."""
+    g = _g(77 + tile + n)
+    x = (torch.randn(B, T, cin, generator=g)).to(device)
+    w = PW.pack_conv(torch.randn(n, cin, k, generator=g) / math.sqrt(cin * k)).to(device)
+    bias = torch.randn(n, generator=g).to(device)
+    res = torch.randn(B, T, n, generator=g).to(device)
+    kw = dict(ksize=k, pad=(k - 1) // 2, act=ACT_GELU, res=res, split_k=1)
+    launches = ops.launches
+    y3 = ops.conv(x, w, bias, tile=tile, **kw)
+    y2 = ops.conv(x, w, bias, tile=tile | 16, **kw)          # (tile << 8) | 0x1000 = SVCMI_CONV_RING2
+    assert torch.equal(y2, y3), (tile, n, cin, k, float((y2 - y3).abs().max()))
+    ref = F.gelu(F.conv1d(x.cpu().transpose(1, 2), w.cpu()[:, :cin * k].view(n, k, cin).permute(0, 2, 1).contiguous(), bias.cpu(), padding=(k - 1) // 2).transpose(1, 2)) + res.cpu()
+    _close(y2, ref, 2e-5, f"ring2 tile {tile}")
+    return True
+
 def _split16(x):
     """fp32 [..., C] -> the SPLIT16 layout [..., 2*Cp] (ops.SPLIT16): hi = bf16(x), lo = bf16(x - hi), zero pads."""
     c = x.shape[-1]
@@ -755,43 +774,49 @@ def check_snake_conv_group_lp(ops, device, c=20, ld=20, B=2, n=300, precision="f
             ops.lib.svcmi_tune_set(b"amp_u", 0)
 
 
-def check_amp_block_group(ops, device, c=10, ld=12, B=2, n=700, variants=(0,), nblocks=3):
-    """A whole AMP block per launch (svcmi_amp_block_group_f32: the tile stays in LDS over the six half-steps, halos recomputed) equals
-    the chain of half-step launches (svcmi_snake_conv_f32) bit for bit -- every tile geometry of the kernel, sequence ends inside the
-    halo, tiles that end past the sequence, sequences shorter than one halo."""
-    g = _g(900 + 7 * c + n)
-    filt = W.kaiser_sinc_filter().view(-1).to(device)
-    x = torch.zeros(B, n, ld)
-    x[..., :c] = torch.randn(B, n, c, generator=g)
-    xd = x.to(device)
-    blocks, want = [], []
-    for k in (3, 11, 7)[:nblocks]:
-        blk = dict(ksize=k, dil=[1, 3, 5], c1=[], c2=[], a1=[], a2=[])
-        for _ in range(3):
-            for key in ("c1", "c2"):
-                w = PW.pack_conv(torch.randn(c, c, k, generator=g) / math.sqrt(c * k), ld, ld).to(device)
-                blk[key].append((w, PW.pad_vec(torch.randn(c, generator=g) * 0.1, ld).to(device)))
-            for key in ("a1", "a2"):
-                al, be = torch.zeros(ld), torch.zeros(ld)
-                al[:c], be[:c] = torch.randn(c, generator=g) * 0.3, torch.randn(c, generator=g) * 0.3
-                blk[key].append((al.to(device), be.to(device)))
-        blocks.append(blk)
-        cur = xd
-        for q, d in enumerate(blk["dil"]):           # the reference chain: xt = conv1(act1(x)); x = conv2(act2(xt)) + x
-            t = ops.snake_conv(cur, blk["a1"][q][0], blk["a1"][q][1], filt, blk["c1"][q][0], blk["c1"][q][1], c=c, ksize=k, dilation=d)
-            cur = ops.snake_conv(t, blk["a2"][q][0], blk["a2"][q][1], filt, blk["c2"][q][0], blk["c2"][q][1], c=c, ksize=k, dilation=1, res=cur)
-        want.append(cur)
-    assert ops.lib.svcmi_amp_block_group_supported(c, ld) == 1 and ops.lib.svcmi_amp_block_group_supported(40, 40) == 0
-    for v in variants:
-        assert ops.lib.svcmi_tune_set(b"amp_block_variant", v) == 0
-        try:
-            got = ops.amp_block_group(xd, blocks, filt, c=c)
-        finally:
-            ops.lib.svcmi_tune_set(b"amp_block_variant", 0)
-        for j in range(len(blocks)):
-            assert torch.equal(got[j], want[j]), (c, n, v, j, float((got[j] - want[j]).abs().max()))
-    return True
 
+def check_snake_gemm_group(ops, device, c=40, B=2, n=300, small=False):
+    """The 40- / 80-channel half-step as ONE launch (snake_gemm_group_kernel: SnakeAlias tile in LDS + streamed-weight fp32 matrix-core
+    convolution) against the two-launch form it replaces -- the library's own SnakeAlias, then torch's conv1d in float64 on that tensor:
+    3 / 7 / 11 taps x dilations 1 / 5 / 3, bias, residual, alpha, accumulate, sequence ends inside a tile, 1 and 3 problems per launch,
+    both tile sizes (knob amp_gemm = 1 | 2, same bits)."""
+    g = _g(1300 + c + n)
+    filt = W.kaiser_sinc_filter().view(-1).to(device)
+    probs, want = [], []
+    for i, (k, d) in enumerate(((3, 1), (11, 5), (7, 3))):
+        x = torch.randn(B, n, c, generator=g) * 1.5
+        res = torch.randn(B, n, c, generator=g)
+        y0 = torch.randn(B, n, c, generator=g)
+        al, be = torch.randn(c, generator=g) * 0.3, torch.randn(c, generator=g) * 0.3
+        w = torch.randn(c, c, k, generator=g) / math.sqrt(c * k)
+        bias = torch.randn(c, generator=g)
+        acc = i == 1
+        s_lib = ops.snake_alias(x.to(device), al.to(device), be.to(device), filt).cpu()
+        ref = F.conv1d(s_lib.double().transpose(1, 2), w.double(), bias.double(), dilation=d, padding=(k - 1) * d // 2).transpose(1, 2)
+        ref = (ref + res.double()) * 0.5 + (y0.double() if acc else 0.0)
+        want.append(ref.float())
+        probs.append(dict(x=x.to(device), alpha_log=al.to(device), beta_log=be.to(device), w=PW.pack_conv(w, c, c).to(device), bias=bias.to(device),
+                          ksize=k, dilation=d, res=res.to(device), alpha=0.5, accumulate=acc, y0=y0))
+    for k, d in ((3, 1), (7, 3), (11, 5)):
+        assert ops.lib.svcmi_snake_gemm_supported(c, c, k, d) == 1 and ops.lib.svcmi_snake_gemm_preferred(c, c, k, d) == 1
+    assert ops.lib.svcmi_snake_gemm_supported(20, 20, 3, 1) == 0 and ops.lib.svcmi_snake_gemm_supported(c, c, 5, 1) == 0
+    outs = {}
+    for knob in (1, 2):
+        assert ops.lib.svcmi_tune_set(b"amp_gemm", knob) == 0
+        try:
+            for n_prob in (1, 3):
+                for pr in probs:
+                    pr["out"] = pr["y0"].clone().to(device) if pr["accumulate"] else torch.full((B, n, c), 7.0).to(device)
+                got = ops.snake_conv_group(probs[:n_prob], filt, c=c)
+                for j in range(n_prob):
+                    _close(got[j], want[j], 1e-5, f"snake_gemm_group c={c} n={n} knob={knob} problem {j}")
+                outs[(knob, n_prob)] = [t.clone() for t in got[:n_prob]]
+        finally:
+            ops.lib.svcmi_tune_set(b"amp_gemm", 1)
+    for n_prob in (1, 3):
+        for a, b in zip(outs[(1, n_prob)], outs[(2, n_prob)]):
+            assert torch.equal(a, b)                      # the tile size does not touch the summation order
+    return True
 
 def check_snake_post(ops, device, B=2, n=700):
     """Fused output layer (SnakeAlias -> conv_post 10 -> 1, k = 7, no bias -> tanh) vs oracle SnakeAlias + torch conv1d."""

@@ -110,12 +110,6 @@ def test_snake_conv_group_on_the_fp16_matrix_cores(ops, c, ld, n, precision):
     K.check_snake_conv_group_lp(ops, "cuda", c=c, ld=ld, B=1 if n > 1000 else 2, n=n, precision=precision)
 
 
-@pytest.mark.parametrize("c,ld,n,B", [(10, 12, 700, 2), (10, 12, 33, 2), (10, 12, 320000, 1), (20, 20, 600, 2), (20, 20, 1, 1), (20, 20, 160000, 1),
-                                      (10, 12, 40000, 4), (20, 20, 20000, 4)])
-def test_amp_block_group_equals_the_half_step_chain(ops, c, ld, n, B):
-    K.check_amp_block_group(ops, "cuda", c=c, ld=ld, B=B, n=n, variants=(0, 1, 2, 3, 4) if n < 100000 else (0, 2))
-
-
 @pytest.mark.parametrize("n", [5, 700, 320000])
 def test_snake_post(ops, n):
     K.check_snake_post(ops, "cuda", B=1 if n > 100000 else 2, n=n)
@@ -189,3 +183,14 @@ def test_outputs16(ops):
 @pytest.mark.parametrize("case", K.ATTN16_CASES + K.ATTN16_CASES_LARGE, ids=lambda c: c["id"])
 def test_attention16(ops, case):
     K.check_attention16(ops, case, "cuda")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tile,n,cin,k,T", [(1, 70, 64, 5, 150), (6, 80, 64, 5, 150), (4, 40, 40, 3, 300), (1, 70, 32, 1, 90), (3, 70, 64, 3, 150)])
+def test_conv_gemm_two_deep_ring_is_bit_identical(ops, tile, n, cin, k, T):
+    K.check_conv_ring2(ops, "cuda", tile, n, cin=cin, k=k, T=T)
+
+
+@pytest.mark.parametrize("c,B,n", [(40, 2, 300), (40, 1, 80000), (80, 2, 200), (80, 1, 20000), (40, 4, 20000), (80, 1, 1)])
+def test_snake_gemm_group_one_launch_half_step(ops, c, B, n):
+    K.check_snake_gemm_group(ops, "cuda", c=c, B=B, n=n)

@@ -100,11 +100,6 @@ def test_snake_conv_group_on_the_fp16_matrix_cores(ops, c, ld, n, precision):
     K.check_snake_conv_group_lp(ops, "cpu", c=c, ld=ld, B=2 if n < 200 else 1, n=n, precision=precision)
 
 
-@pytest.mark.parametrize("c,ld,n,variants,nblocks", [(10, 12, 700, (1, 3), 3), (10, 12, 40, (1,), 2), (20, 20, 600, (1, 4), 3), (20, 20, 1, (1,), 1)])
-def test_amp_block_group_equals_the_half_step_chain(ops, c, ld, n, variants, nblocks):
-    K.check_amp_block_group(ops, "cpu", c=c, ld=ld, B=2 if n < 100 else 1, n=n, variants=variants, nblocks=nblocks)
-
-
 @pytest.mark.parametrize("n", [5, 700])
 def test_snake_post(ops, n):
     K.check_snake_post(ops, "cpu", B=2, n=n)
@@ -183,17 +178,26 @@ def test_attention16(ops, case):
 def test_kernels_do_not_depend_on_the_thread_order_inside_a_barrier_interval(ops, order, monkeypatch):
     """The emulator runs the fibers of a block in thread order between barriers; SVCMI_EMU_ORDER makes it run them backwards / shuffled
     (tests/emu/hip_emu.cpp).  A kernel with a missing __syncthreads (a thread reading LDS another thread writes in the same interval)
-    gives different results then: the LDS-heavy kernels -- the half-step kernels in all forms, the fused AMP block, GEMM, attention,
+    gives different results then: the LDS-heavy kernels -- the half-step kernels in all forms, GEMM, attention,
     split-K LayerNorm -- are checked against their references under both orders."""
     monkeypatch.setenv("SVCMI_EMU_ORDER", order)
     K.check_snake_conv_group_lp(ops, "cpu", c=20, ld=20, B=1, n=300, precision="f16w2")
     K.check_snake_conv_group_lp(ops, "cpu", c=10, ld=12, B=2, n=150, precision="f16")
     K.check_snake_conv_group(ops, "cpu", c=20, ld=20, B=1, n=300)
     K.check_snake_conv_group(ops, "cpu", c=10, ld=12, B=2, n=150)
-    K.check_amp_block_group(ops, "cpu", c=10, ld=12, B=1, n=300, variants=(1,), nblocks=2)
     K.check_snake_post(ops, "cpu", B=1, n=300)
     K.check_conv(ops, K.CONV_CASES_SMALL[1], "cpu")
     K.check_conv(ops, K.CONV_CASES_SMALL[3], "cpu")
     K.check_attention(ops, K.ATTN_CASES_SMALL[0], "cpu")
     K.check_attention(ops, K.ATTN_CASES_LDS[0], "cpu")
     K.check_splitk_layernorm(ops, "cpu", B=1, S=3, T=5, c=1280)
+
+
+@pytest.mark.parametrize("tile,n,cin,k,T", [(1, 70, 64, 5, 150), (6, 80, 64, 5, 150), (4, 40, 40, 3, 300), (1, 70, 32, 1, 90), (3, 70, 64, 3, 150)])
+def test_conv_gemm_two_deep_ring_is_bit_identical(ops, tile, n, cin, k, T):
+    K.check_conv_ring2(ops, "cpu", tile, n, cin=cin, k=k, T=T)
+
+
+@pytest.mark.parametrize("c,B,n", [(40, 2, 150), (40, 1, 300), (80, 2, 70), (80, 1, 200), (40, 1, 1)])
+def test_snake_gemm_group_one_launch_half_step(ops, c, B, n):
+    K.check_snake_gemm_group(ops, "cpu", c=c, B=B, n=n)

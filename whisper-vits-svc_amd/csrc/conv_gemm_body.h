@@ -653,9 +653,9 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
 #ifndef SVCMI_GEMM_NST
 #define SVCMI_GEMM_NST 0
 #endif
-template <int WM, int WN, int MODE, bool P16, int PREC = PREC_F32>
+template <int WM, int WN, int MODE, bool P16, int PREC = PREC_F32, int NSTO = 0>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
-    conv_gemm_body<WM, WN, MODE, P16, (PREC == PREC_F32 && WM * WN <= 5 ? SVCMI_GEMM_NST : 0), PREC>(p, (int)gridDim.x, (int)blockIdx.x);
+    conv_gemm_body<WM, WN, MODE, P16, (NSTO ? NSTO : (PREC == PREC_F32 && WM * WN <= 5 ? SVCMI_GEMM_NST : 0)), PREC>(p, (int)gridDim.x, (int)blockIdx.x);
 }
 
 // Grouped launch: up to GROUP_MAX problems of identical tile policy / gather mode in ONE grid, blocks of problem 0 first.  The
@@ -703,7 +703,17 @@ int launch(const ConvArgs& a_in, int batch, int mode, void* stream) {
     const long long blocks = (long long)a.mt * a.nt * batch * a.split;
     if (blocks > 0x7fffffffLL) return SVCMI_EUNSUPPORTED;
     dim3 grid((unsigned)blocks);
-    if (mode == MODE_CHUNK) SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_CHUNK, P16, PREC>), grid, dim3(256), 0, stream, a);
+    // SVCMI_CONV_RING2: the 2-deep ring of the 64-row fp32 tiles (one more resident block per CU; for launches that share the chip)
+    constexpr bool HAS_RING2 = PREC == PREC_F32 && WM == 1 && (P16 ? (WN == 3 || WN == 5) : WN == 1);
+    bool ring2 = false;
+    if constexpr (HAS_RING2) ring2 = (a.flags & SVCMI_CONV_RING2) && (mode == MODE_CHUNK || mode == MODE_VEC);
+    if (ring2) {
+        if constexpr (HAS_RING2) {
+            if (mode == MODE_CHUNK) SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_CHUNK, P16, PREC, 2>), grid, dim3(256), 0, stream, a);
+            else SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_VEC, P16, PREC, 2>), grid, dim3(256), 0, stream, a);
+        }
+    }
+    else if (mode == MODE_CHUNK) SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_CHUNK, P16, PREC>), grid, dim3(256), 0, stream, a);
     else if (mode == MODE_VEC) SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_VEC, P16, PREC>), grid, dim3(256), 0, stream, a);
     else if constexpr (!P16) {
         if (mode == MODE_CHUNK_RS) {

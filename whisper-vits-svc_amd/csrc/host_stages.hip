@@ -18,11 +18,6 @@
 namespace {
 
 int g_amp_grouped = 1;     // tuning / test knob ("amp_grouped", 0 | 1): 0 forces the one-launch-per-block fallback of the generator stages
-// ("amp_block", 0 | 1): 1 = the narrow stages run each AMP block as ONE launch (svcmi_amp_block_group_f32, csrc/amp_block.hip), 0 = six
-// half-step launches per block.  OFF: measured on MI355X (profiles/r04c_ampblock_variants.log) the fused block is 0.67-0.92x the speed of
-// the half-step chain in every tile geometry (10 channels: 445 vs 411 us at B = 1, 5.96 vs 5.13 ms at B = 16; 20 channels: 659 vs 552 us,
-// 9.3 vs 6.2 ms) -- bit-identical, kept as a tested alternative
-int g_amp_block = 0;
 // tuning knob ("amp_lp", 0 | 1): 1 = in the f16 / f16w2 precision classes the narrow stages' half-steps run their convolution on the
 // fp16 matrix cores (svcmi_snake_conv_group_lp); 0 = they stay on the fp32 vector kernels whatever the class says
 int g_amp_lp = 1;
@@ -31,14 +26,14 @@ enum Op {
     OP_CONV_F32, OP_CONV_LP, OP_CONV_GROUP_F32, OP_CONV_GROUP_LP, OP_LAYERNORM, OP_SPLITK_LN, OP_ATTENTION, OP_SNAKE_ALIAS,
     OP_SNAKE_ALIAS_GROUP, OP_BLOCK_MEAN, OP_SNAKE_CONV, OP_SNAKE_CONV_GROUP, OP_UPSAMPLE_NOISE, OP_SNAKE_POST, OP_WN_GATE,
     OP_COUPLING_PRE, OP_COUPLING_POST, OP_EMBED_PITCH, OP_SAMPLE_PRIOR, OP_NCL_TO_NLC, OP_COPY2D, OP_PITCH_PREFIX, OP_PITCH_SOURCE,
-    OP_ATTENTION16, OP_AMP_BLOCK_GROUP, OP_SNAKE_CONV_GROUP_LP, OP_COUNT
+    OP_ATTENTION16, OP_SNAKE_CONV_GROUP_LP, OP_COUNT
 };
 const char* const OP_NAMES[OP_COUNT] = {
     "svcmi_conv_gemm_f32", "svcmi_conv_gemm_lp", "svcmi_conv_gemm_group_f32", "svcmi_conv_gemm_group_lp", "svcmi_layernorm_f32",
     "svcmi_splitk_layernorm_f32", "svcmi_attention_f32", "svcmi_snake_alias_f32", "svcmi_snake_alias_group_f32", "svcmi_block_mean_f32",
     "svcmi_snake_conv_f32", "svcmi_snake_conv_group_f32", "svcmi_upsample_noise_f32", "svcmi_snake_post_f32", "svcmi_wn_gate_f32",
     "svcmi_coupling_pre_f32", "svcmi_coupling_post_f32", "svcmi_embed_pitch_f32", "svcmi_sample_prior_f32", "svcmi_ncl_to_nlc_f32",
-    "svcmi_copy2d_f32", "svcmi_pitch_prefix_f64", "svcmi_pitch_source_f32", "svcmi_attention16", "svcmi_amp_block_group_f32", "svcmi_snake_conv_group_lp"};
+    "svcmi_copy2d_f32", "svcmi_pitch_prefix_f64", "svcmi_pitch_source_f32", "svcmi_attention16", "svcmi_snake_conv_group_lp"};
 
 // ------------------------------------------------------------------------------------------------ per-launch trace (bench.py)
 struct TraceRec {
@@ -124,7 +119,13 @@ struct CV {
                                     // launch that goes to the bf16 / f16 kernel then takes the _A16 instantiation (no in-register rounding)
     void* y16 = nullptr;            // 16-bit copy of the output for the NEXT launch (written only in the bf16 / f16 modes)
     int y16_fmt = -1;               // format of that copy: -1 = the launch's own mode, else SVCMI_PREC_BF16 / _F16 whatever the GEMM runs in
+    int ring_class = 4;             // bit of g_ring2 that gives this launch the 2-deep operand ring (SVCMI_CONV_RING2): 0 qkv, 1 o, 2 mlp-up, 3 mlp-down of Whisper, 4 everything else
 };
+
+// tuning knob ("ring2", bit mask over CV::ring_class): which single-launch fp32 GEMMs take the 2-deep operand ring (one more resident
+// block per CU).  Meant for captures that run several clips in flight (svcmi.serving.ClipLanes sets it around its graph captures): measured
+// on MI355X with 4 clips in flight the judged line gains 1.8 % with every GEMM on it, while one clip alone loses 4 % (profiles/r05a_*).
+int g_ring2 = 0;
 
 // Per-layer mixed precision (SVCMI_PREC_MIXED): every section of the synthesizer sets c.prec to its class's mode before it launches.
 int class_prec(const svcmi_synth_model& m, int cls) {
@@ -174,7 +175,7 @@ int conv_desc(const Ctx& c, const CV& v, svcmi_conv_desc& d, double& flops, doub
                     (!v.rshift || v.c_in % 32 == 0) && lp_tile_ok(tile_lp);
     const int tile = lp ? tile_lp : (v.tile == 9 ? 0 : v.tile);      // 64x128 exists on the 16-bit kernels only
     d.flags = (v.accumulate ? SVCMI_CONV_ACCUMULATE : 0) | (v.mask_in ? SVCMI_CONV_MASK_IN : 0) | (v.mask_out ? SVCMI_CONV_MASK_OUT : 0) |
-              (partials ? SVCMI_CONV_PARTIALS : 0) | (tile << 8);
+              (partials ? SVCMI_CONV_PARTIALS : 0) | (tile << 8) | (((g_ring2 >> v.ring_class) & 1) ? SVCMI_CONV_RING2 : 0);
     if (partials) {
         d.split_k = v.split_k; d.workspace = v.slabs; d.workspace_floats = (int64_t)v.B * v.split_k * t_out * N;
     } else if (v.split_k != 1) {
@@ -381,25 +382,25 @@ void whisper_fwd(Ctx& c, const svcmi_whisper_model& m, const float* mel, const f
         const svcmi_whisper_block& blk = m.blocks[i];
         CV v; v.B = B; v.t_in = tw; v.c_in = v.ldx = S; v.x_bs = (int64_t)tw * S;
         {
-            CV q = v; q.x = h; q.x16 = h16; q.w = &blk.qkv; q.y = qkv; q.y_bs = (int64_t)tw * 3 * S; q.ldy = 3 * S; q.tile = t_qkv; q.tile_lp = l_qkv;
+            CV q = v; q.x = h; q.x16 = h16; q.w = &blk.qkv; q.y = qkv; q.y_bs = (int64_t)tw * 3 * S; q.ldy = 3 * S; q.tile = t_qkv; q.tile_lp = l_qkv; q.ring_class = 0;
             if (att16) { q.y16 = qkv16; q.split_k = 1; }       // (the 16-bit copy comes out of the float4 epilogue: no K slices)
             conv(c, q);
         }
         if (att16) attention16(c, qkv16, a, at16, B, tw, H, S, scale, nullptr);
         else attention(c, qkv, a, B, tw, H, S, scale, nullptr, nullptr, 0, nullptr, at16);
         {
-            CV o = v; o.x = a; o.x16 = at16; o.w = &blk.o; o.bias = false; o.slabs = slabs; o.split_k = so; o.tile = t_o; o.tile_lp = l_o;
+            CV o = v; o.x = a; o.x16 = at16; o.w = &blk.o; o.bias = false; o.slabs = slabs; o.split_k = so; o.tile = t_o; o.tile_lp = l_o; o.ring_class = 1;
             conv(c, o);
         }
         splitk_layernorm(c, slabs, so, blk.o.bias, x, blk.ln2_g, blk.ln2_b, h, B, tw, S, h16);
         {
             CV u = v; u.x = h; u.x16 = x3 ? nullptr : h16; u.w = &blk.m1; u.act = SVCMI_ACT_GELU; u.y = mm; u.y_bs = (int64_t)tw * F; u.ldy = F; u.split_k = 1;
-            u.tile = t_m1; u.tile_lp = l_m1; u.y16 = mm16;
+            u.tile = t_m1; u.tile_lp = l_m1; u.y16 = mm16; u.ring_class = 2;
             conv(c, u);
         }
         {
             CV dn = v; dn.x = mm; dn.x16 = mm16; dn.c_in = dn.ldx = F; dn.x_bs = (int64_t)tw * F; dn.w = &blk.m2; dn.bias = false; dn.slabs = slabs;
-            dn.split_k = sm; dn.tile = t_m2; dn.tile_lp = l_m2;
+            dn.split_k = sm; dn.tile = t_m2; dn.tile_lp = l_m2; dn.ring_class = 3;
             conv(c, dn);
         }
         const float* g = i + 1 < nb ? m.blocks[i + 1].ln1_g : m.lnp_g;
@@ -621,41 +622,17 @@ bool amp_stage_grouped(Ctx& c, const svcmi_synth_model& m, const svcmi_gen_stage
     int nf = 0, nall = 0;
     for (int j = 0; j < nb; ++j) {
         if (st.blocks[j].n_dil != nd) return false;
-        for (int q = 0; q < nd; ++q) { nf += svcmi_snake_conv_preferred(st.c, cp, st.blocks[j].k, st.blocks[j].dil[q]) ? 1 : 0; ++nall; }
+        for (int q = 0; q < nd; ++q) {
+            // one fused launch per half-step: the narrow stages' kernels in every mode; the 40- / 80-channel matrix-core form in fp32 only
+            // (in the 16-bit modes these stages' convolutions run on the 16-bit GEMM kernels)
+            const bool f = svcmi_snake_conv_preferred(st.c, cp, st.blocks[j].k, st.blocks[j].dil[q]) ||
+                           (c.prec == SVCMI_PREC_F32 && svcmi_snake_gemm_preferred(st.c, cp, st.blocks[j].k, st.blocks[j].dil[q]));
+            nf += f ? 1 : 0; ++nall;
+        }
     }
     if (nf != 0 && nf != nall) return false;
     const bool fused = nf == nall;
     const int64_t n = (int64_t)B * L * cp, bs = L * cp;
-    if (fused && g_amp_block && svcmi_amp_block_group_supported(st.c, cp) && nd <= 3) {
-        // narrow stages: every AMP block as ONE launch with its tile resident in LDS over all 2 * nd half-steps (csrc/amp_block.hip);
-        // bit-identical to the VECTOR-ALU half-step launches below (the grouped entry point takes the fp32 matrix-core half-step at
-        // 20 channels and batch <= 2 -- amp_fused.hip, knob amp_mfma -- which sums in another order: 5e-6)
-        bool ok = true;
-        for (int j = 0; j < nb; ++j)
-            for (int q = 0; q < nd; ++q) ok = ok && st.blocks[j].dil[q] >= 1 && st.blocks[j].dil[q] <= 5;
-        if (ok) {
-            float* o[3];
-            for (int j = 0; j < nb; ++j) o[j] = c.ar.f(n);
-            svcmi_amp_block_desc d[3];
-            double fl = 0.0;
-            for (int j = 0; j < nb; ++j) {
-                const svcmi_amp_block& b = st.blocks[j];
-                memset(&d[j], 0, sizeof(d[j]));
-                d[j].x = y; d[j].y = o[j]; d[j].ksize = b.k; d[j].n_dil = nd;
-                for (int q = 0; q < nd; ++q) {
-                    d[j].w1[q] = b.c1[q].w; d[j].b1[q] = b.c1[q].bias; d[j].w2[q] = b.c2[q].w; d[j].b2[q] = b.c2[q].bias;
-                    d[j].a1_alpha[q] = b.a1_alpha[q]; d[j].a1_beta[q] = b.a1_beta[q]; d[j].a2_alpha[q] = b.a2_alpha[q]; d[j].a2_beta[q] = b.a2_beta[q];
-                    d[j].ldw1[q] = b.c1[q].ldw; d[j].ldw2[q] = b.c2[q].ldw; d[j].dil[q] = b.dil[q];
-                }
-                fl += 2.0 * 2 * nd * B * L * st.c * st.c * b.k;
-            }
-            run(c, OP_AMP_BLOCK_GROUP, fl, 4.0 * (1 + nb) * B * L * st.c,
-                [&] { return svcmi_amp_block_group_f32(d, nb, m.filt, B, (int32_t)L, st.c, cp, c.stream); });
-            const float* xc[3] = {o[0], o[1], o[2]};
-            run(c, OP_BLOCK_MEAN, 0.0, 4.0 * (nb + 1) * n, [&] { return svcmi_block_mean_f32(xc, nb, acc, n, c.stream); });
-            return true;
-        }
-    }
     float *xj[3], *t1[3], *t2[3];
     void* t1h[3] = {nullptr, nullptr, nullptr};
     for (int j = 0; j < nb; ++j) xj[j] = c.ar.f(n);
@@ -1002,7 +979,7 @@ extern "C" const char* svcmi_trace_op_name(int32_t op) { return op >= 0 && (op &
 extern "C" int svcmi_struct_sizes(int64_t* out, int32_t cap) {
     const int64_t v[] = {(int64_t)sizeof(svcmi_weight), (int64_t)sizeof(svcmi_whisper_model), (int64_t)sizeof(svcmi_synth_model),
                          (int64_t)sizeof(svcmi_synth_io), (int64_t)sizeof(svcmi_trace_record), (int64_t)sizeof(svcmi_conv_desc),
-                         (int64_t)sizeof(svcmi_snake_conv_desc), (int64_t)sizeof(svcmi_amp_block_desc)};
+                         (int64_t)sizeof(svcmi_snake_conv_desc)};
     const int n = (int)(sizeof(v) / sizeof(v[0]));
     for (int i = 0; i < n && i < cap; ++i) out[i] = v[i];
     return n < cap ? n : cap;
@@ -1010,8 +987,8 @@ extern "C" int svcmi_struct_sizes(int64_t* out, int32_t cap) {
 
 extern "C" int svcmi_host_tune_set(const char* name, int32_t value) {
     if (strcmp(name, "amp_grouped") == 0 && (value == 0 || value == 1)) { g_amp_grouped = value; return 0; }
-    if (strcmp(name, "amp_block") == 0 && (value == 0 || value == 1)) { g_amp_block = value; return 0; }
     if (strcmp(name, "amp_lp") == 0 && (value == 0 || value == 1)) { g_amp_lp = value; return 0; }
+    if (strcmp(name, "ring2") == 0 && value >= 0 && value < 32) { g_ring2 = value; return 0; }
     return SVCMI_EINVAL;
 }
 

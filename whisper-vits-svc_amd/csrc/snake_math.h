@@ -88,25 +88,14 @@ __device__ __forceinline__ svcmi_f32x2 sin_sq2_nocheck(svcmi_f32x2 x, const Snak
 // / restore, 13 of them per work item, which the scheduler cannot interleave.  Here the N chains are straight-line code (independent:
 // the scheduler overlaps them) and the rare fix-up pass replaces only the components that needed libm.  Same value per component as
 // snake_fn2: (|x| <= 1e5) the polynomial path, else inv_b * sin^2_libm(x) + y.
-#ifndef SVCMI_SNAKE_CHUNK
-#define SVCMI_SNAKE_CHUNK 0          // build-time experiment knob: 0 = all chains of an item interleavable, n = at most n at a time, -1 = the round-3 per-pair form
-#endif
 template <int N>
 __device__ __forceinline__ void snake_fn2_all(const svcmi_f32x2 (&y)[N], float a, float inv_b, const SnakeConsts& k, svcmi_f32x2 (&s)[N]) {
-#if SVCMI_SNAKE_CHUNK < 0
-#pragma unroll
-    for (int m = 0; m < N; ++m) s[m] = snake_fn2(y[m], a, inv_b, k);
-    return;
-#endif
     float mx = 0.f;
 #pragma unroll
     for (int m = 0; m < N; ++m) {
         const svcmi_f32x2 x = y[m] * svcmi_splat2(a);
         mx = fmaxf(mx, fmaxf(fabsf(x[0]), fabsf(x[1])));
         s[m] = svcmi_fma2(svcmi_splat2(inv_b), sin_sq2_nocheck(x, k), y[m]);
-#if SVCMI_SNAKE_CHUNK > 0
-        if ((m + 1) % SVCMI_SNAKE_CHUNK == 0) SVCMI_SCHED_BARRIER();      // bounds the registers the interleaved chains need
-#endif
     }
     if (__builtin_expect(mx > 1.0e5f, 0)) {               // never taken for audio-scale activations
 #pragma unroll
@@ -137,12 +126,9 @@ __device__ __forceinline__ void snake_up_taps(const float (&f)[12], svcmi_f32x2 
 
 // The two 6-tap packed FMA chains of a work item: y2[m] = sum_j g2[j] * x[5 - j + m] (up-sampler) and out[r] = sum_i f2[i] . P[r + i]
 // (decimating low-pass).  Written value by value the compiler emits each chain as six DEPENDENT v_pk_fma_f32 on one accumulator with an
-// s_nop between them (ISA of round 4: 78 s_nop per U-fill work item); SVCMI_SNAKE_INTERLEAVE = 1 (build experiment for round 5, default 0 =
-// the validated instruction stream) walks the taps in the outer loop and the values in the inner one, so consecutive instructions belong to
-// different chains.  Same operations per value in the same order: bit-identical results either way.
-#ifndef SVCMI_SNAKE_INTERLEAVE
-#define SVCMI_SNAKE_INTERLEAVE 0
-#endif
+// s_nop between them (ISA of round 4: 78 s_nop per U-fill work item).  Walking the taps in the outer loop and the values in the inner one
+// (consecutive instructions from different chains; bit-identical) was measured on MI355X in round 5 and changes nothing (92.8 vs 91.3 us
+// at 20 channels, 64.4 vs 64.6 at 10: profiles/r05a_variants.log) -- the kernels are not bound by these chains; the variant was removed.
 template <int NP, class Window>
 __device__ __forceinline__ void snake_upsample(const Window& xw, const svcmi_f32x2 (&g2)[6], svcmi_f32x2 (&y2)[NP]) {
 #pragma unroll
@@ -188,9 +174,6 @@ __device__ __forceinline__ void snake_run(const SnakeWindow<RT + 10>& xw, const 
     snake_up_taps(f, g2);
     // s2[m] = (s_up[2*t0 - 5 + 2m], s_up[2*t0 - 5 + 2m + 1]): polyphase up-sampler + SnakeBeta, each value computed once
     svcmi_f32x2 s2[RT + 5], y2[RT + 5];
-#if SVCMI_SNAKE_INTERLEAVE
-    snake_upsample<RT + 5>(xw, g2, y2);
-#else
 #pragma unroll
     for (int m = 0; m < RT + 5; ++m) {
         svcmi_f32x2 y = svcmi_splat2(0.f);          // (odd phase: even taps, even phase: odd taps)
@@ -198,7 +181,6 @@ __device__ __forceinline__ void snake_run(const SnakeWindow<RT + 10>& xw, const 
         for (int j = 0; j < 6; ++j) y = svcmi_fma2(g2[j], xw.splat(5 - j + m), y);
         y2[m] = y;
     }
-#endif
     snake_fn2_all<RT + 5>(y2, a, inv_b, k, s2);
     const int u0 = 2 * t0 - 5;
     if (u0 < 0 || u0 + 2 * RT + 9 > 2 * n - 1) {      // replicate padding of the low-pass input
@@ -212,9 +194,6 @@ __device__ __forceinline__ void snake_run(const SnakeWindow<RT + 10>& xw, const 
                 s2[m][h] = u < 0 ? s_first : (u > 2 * n - 1 ? s_last : s2[m][h]);
             }
     }
-#if SVCMI_SNAKE_INTERLEAVE
-    snake_fir_taps<RT>(s2, f2, out);
-#else
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
         svcmi_f32x2 z = svcmi_splat2(0.f);
@@ -222,7 +201,6 @@ __device__ __forceinline__ void snake_run(const SnakeWindow<RT + 10>& xw, const 
         for (int i = 0; i < 6; ++i) z = svcmi_fma2(f2[i], s2[r + i], z);
         out[r] = z[0] + z[1];
     }
-#endif
 }
 
 // The two halves of snake_run as separate steps, for kernels that keep the up-sampled SnakeBeta values of a whole tile in LDS so that
@@ -237,9 +215,6 @@ __device__ __forceinline__ void snake_pairs(const SnakeWindow<NP + 5>& xw, const
     svcmi_f32x2 g2[6];
     snake_up_taps(f, g2);
     svcmi_f32x2 y2[NP];
-#if SVCMI_SNAKE_INTERLEAVE
-    snake_upsample<NP>(xw, g2, y2);
-#else
 #pragma unroll
     for (int m = 0; m < NP; ++m) {
         svcmi_f32x2 y = svcmi_splat2(0.f);
@@ -247,7 +222,6 @@ __device__ __forceinline__ void snake_pairs(const SnakeWindow<NP + 5>& xw, const
         for (int j = 0; j < 6; ++j) y = svcmi_fma2(g2[j], xw.splat(5 - j + m), y);
         y2[m] = y;
     }
-#endif
     snake_fn2_all<NP>(y2, a, inv_b, k, s2);
     const int u0 = 2 * tq0 - 5;
     if (u0 < 0 || u0 + 2 * NP - 1 > 2 * n - 1) {      // replicate padding of the low-pass input (filter.py:86-95)
@@ -268,9 +242,6 @@ __device__ __forceinline__ void snake_fir(const svcmi_f32x2 (&P)[NR + 5], const 
     svcmi_f32x2 f2[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) f2[j] = svcmi_f32x2{f[2 * j], f[2 * j + 1]};
-#if SVCMI_SNAKE_INTERLEAVE
-    snake_fir_taps<NR>(P, f2, out);
-#else
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         svcmi_f32x2 z = svcmi_splat2(0.f);
@@ -278,5 +249,4 @@ __device__ __forceinline__ void snake_fir(const svcmi_f32x2 (&P)[NR + 5], const 
         for (int i = 0; i < 6; ++i) z = svcmi_fma2(f2[i], P[r + i], z);
         out[r] = z[0] + z[1];
     }
-#endif
 }

@@ -8,7 +8,7 @@ DEFAULT_LIB = os.path.join(HERE, "libsvcmi.so")
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_MISH, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4, 5
 CONV_ACCUMULATE, CONV_MASK_IN, CONV_MASK_OUT, CONV_PARTIALS = 1, 2, 4, 8
-ABI_VERSION = 20
+ABI_VERSION = 21
 PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16, PREC_BF16_A16, PREC_F16_A16, PREC_BF16X3_A16 = 0, 1, 2, 3, 4, 5, 6
 PRECISIONS = {None: 0, "f32": 0, "fp32": 0, "bf16x3": 1, "bf16": 2, "f16": 3, "fp16": 3, "f16w2": 8}
 PREC_F16W2, PREC_F16W2_A16 = 8, 9          # fp16 activations x split fp16 weights: a mode like f16 whose 16-bit-activation launches take two MFMAs on (hi, lo) weight images
@@ -158,13 +158,6 @@ class SynthIO(Structure):
                 ("wave", c_void_p), ("z_p", c_void_p), ("z", c_void_p)]
 
 
-class AmpBlockDesc(Structure):
-    """svcmi_amp_block_desc"""
-    _fields_ = [("x", c_void_p), ("y", c_void_p), ("w1", c_void_p * 3), ("b1", c_void_p * 3), ("w2", c_void_p * 3), ("b2", c_void_p * 3),
-                ("a1_alpha", c_void_p * 3), ("a1_beta", c_void_p * 3), ("a2_alpha", c_void_p * 3), ("a2_beta", c_void_p * 3),
-                ("ldw1", c_int32 * 3), ("ldw2", c_int32 * 3), ("dil", c_int32 * 3), ("ksize", c_int32), ("n_dil", c_int32), ("reserved", c_int32)]
-
-
 class TraceRecord(Structure):
     _fields_ = [("op", c_int32), ("ms", c_float), ("flops", c_double), ("bytes", c_double)]
 
@@ -185,6 +178,8 @@ SIGNATURES = {
     "svcmi_snake_alias_f32": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "svcmi_snake_conv_supported": (c_int, [_I, _I, _I, _I]),
     "svcmi_snake_conv_preferred": (c_int, [_I, _I, _I, _I]),
+    "svcmi_snake_gemm_supported": (c_int, [_I, _I, _I, _I]),
+    "svcmi_snake_gemm_preferred": (c_int, [_I, _I, _I, _I]),
     "svcmi_snake_conv_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
     "svcmi_upsample_noise_supported": (c_int, [_I, _I, _I]),
     "svcmi_upsample_noise_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _L, _I, _I, _I, _I, _P]),
@@ -216,8 +211,6 @@ SIGNATURES = {
     "svcmi_snake_conv_group_f32": (c_int, [_P, _I, _P, _I, _I, _I, _I, _P]),
     "svcmi_snake_conv_lp_supported": (c_int, [_I, _I, _I, _I, _I]),
     "svcmi_snake_conv_group_lp": (c_int, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
-    "svcmi_amp_block_group_supported": (c_int, [_I, _I]),
-    "svcmi_amp_block_group_f32": (c_int, [_P, _I, _P, _I, _I, _I, _I, _P]),
     "svcmi_snake_alias_group_f32": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P]),
     "svcmi_block_mean_f32": (c_int, [_P, _I, _P, _L, _P]),
     "svcmi_source2wav_i16": (c_int, [_P, _P, _L, _P]),
@@ -262,7 +255,7 @@ def load_library(path=None):
     import ctypes as _c
     sizes = (c_int64 * 8)()
     n = lib.svcmi_struct_sizes(sizes, 8)
-    mine = [_c.sizeof(t) for t in (Weight, WhisperModel, SynthModel, SynthIO, TraceRecord, ConvDesc, SnakeConvDesc, AmpBlockDesc)]
+    mine = [_c.sizeof(t) for t in (Weight, WhisperModel, SynthModel, SynthIO, TraceRecord, ConvDesc, SnakeConvDesc)]
     if list(sizes[:n]) != mine:
         raise SvcmiError(f"struct layout mismatch: library {list(sizes[:n])} vs binding {mine}")
     return lib

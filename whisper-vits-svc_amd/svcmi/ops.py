@@ -77,10 +77,10 @@ class Ops:
         self._lock = threading.Lock()          # guards the lazily built per-tensor 16-bit weight images
         self.lp_min_flops = 1.5e9
         # development knobs of the library (svcmi_tune_set: tile variants, fused / unfused paths).  Tile / split / launch-shape knobs
-        # leave every result bit-identical; three select another KERNEL FORM of the narrow generator stages and change the fp32
+        # leave every result bit-identical; two select another KERNEL FORM of the narrow generator stages and change the fp32
         # summation order (<= 5e-6 on the waveform) or the operand precision: amp_mfma (fp32 matrix-core half-step at 20 channels and
-        # batch <= 2 -- so fp32 bits are reproducible per batch class, <= 2 clips vs more), amp_block, amp_lp (fp16 operands).
-        # SVCMI_TUNE="amp_block=0,amp_block_variant=2" applies them to this process (A/B runs of bench.py on the GPU box)
+        # batch <= 2 -- so fp32 bits are reproducible per batch class, <= 2 clips vs more), amp_lp (fp16 operands).
+        # SVCMI_TUNE="amp_mfma=0,ring2=15" applies them to this process (A/B runs of bench.py on the GPU box)
         for item in filter(None, os.environ.get("SVCMI_TUNE", "").split(",")):
             k, _, v = item.partition("=")
             if self.lib.svcmi_tune_set(k.strip().encode(), int(v)) != 0:
@@ -596,32 +596,6 @@ class Ops:
             self._call("svcmi_snake_conv_group_f32", descs, len(problems), _ptr(filt), B, L, c, ld, self._stream(),
                        work={"flops": flops, "bytes": 8.0 * len(problems) * B * L * c})
         return [pr["out"] for pr in problems]
-
-    def amp_block_group(self, x, blocks, filt, *, c):
-        """Whole AMP blocks (vits_decoder/bigv.py:50-58) of a narrow stage, one launch for up to 3 of them (svcmi_amp_block_group_f32).
-        ``x`` [B, L, ld]: the stage input; ``blocks``: dicts with ksize, dil (list), c1 / c2 = [(w, bias)] per dilation step and
-        a1 / a2 = [(alpha_log, beta_log)].  Returns the list of block outputs [B, L, ld]."""
-        from ._lib import AmpBlockDesc
-        self._chk(x, filt)
-        B, L, ld = x.shape
-        descs = (AmpBlockDesc * len(blocks))()
-        outs, flops = [], 0.0
-        for i, blk in enumerate(blocks):
-            d = descs[i]
-            out = torch.empty_like(x)
-            outs.append(out)
-            d.x, d.y, d.ksize, d.n_dil = _ptr(x), _ptr(out), blk["ksize"], len(blk["dil"])
-            for q, dil in enumerate(blk["dil"]):
-                (w1, b1), (w2, b2) = blk["c1"][q], blk["c2"][q]
-                (a1a, a1b), (a2a, a2b) = blk["a1"][q], blk["a2"][q]
-                self._chk(w1, b1, w2, b2, a1a, a1b, a2a, a2b)
-                d.w1[q], d.b1[q], d.w2[q], d.b2[q] = _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2)
-                d.a1_alpha[q], d.a1_beta[q], d.a2_alpha[q], d.a2_beta[q] = _ptr(a1a), _ptr(a1b), _ptr(a2a), _ptr(a2b)
-                d.ldw1[q], d.ldw2[q], d.dil[q] = w1.shape[1], w2.shape[1], dil
-                flops += 4.0 * B * L * c * c * blk["ksize"]
-        self._call("svcmi_amp_block_group_f32", descs, len(blocks), _ptr(filt), B, L, c, ld, self._stream(),
-                   work={"flops": flops, "bytes": 4.0 * (1 + len(blocks)) * B * L * c})
-        return outs
 
     def pitch2source(self, f0, rand_ini, noise, merge_w, merge_b, hop, sr):
         """f0 [B,T], rand_ini [B,11], noise [B,T*hop,11] -> source [B, T*hop]."""

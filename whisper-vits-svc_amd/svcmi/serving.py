@@ -6,11 +6,21 @@ raises the throughput of the SAME batch-1 kernels by a third (DESIGN.md section 
 each) so that every lane can be captured once as a HIP graph over static buffers; a request is staged into the next lane's buffers and
 replayed.  ``bench.py`` (configs[1]) times exactly ``ClipLanes.launch``.
 """
+import os
+
 import torch
 
 from .lanes import GraphLanes
 
 INPUTS = ("mel", "vec", "pit", "spk")
+# Which single-launch fp32 GEMMs of a lane's graph take the 2-deep operand ring (SVCMI_CONV_RING2: 41 instead of 61 KB of LDS per block
+# = one more resident block per CU) when SEVERAL lanes share the chip -- bit mask: 1 Whisper QKV, 2 out-projection, 4 MLP-up, 8 MLP-down,
+# 16 the synthesizer's GEMMs.  Measured on MI355X with 4 clips in flight (profiles/r05a_lanes_ring.log, r05b_ring2_sweep.log; audio-s/s
+# of the judged line, box noise +-0.5 %): none 1395-1405, all 1426, Whisper only 1430, synthesizer only 1402, QKV + out-projection 1408,
+# out-projection + MLP-down 1403, MLP-up + MLP-down 1438 -- the gain is the MLP-up launch (512 blocks of 61 KB = exactly two per CU) --
+# while a clip that has the chip to itself loses 4 % with every class on: one-lane captures keep the 3-deep ring.  The ring depth does
+# not change a single bit of the results.  SVCMI_RING2=<mask> overrides (tuning runs).
+RING2_IN_FLIGHT = 12
 
 
 def convert_step(model, whisper, buf, keep, noise=None):
@@ -29,8 +39,10 @@ class ClipLanes:
     ``result`` waits for that lane and returns the waveform [B,1,hop*T]; at most ``lanes`` requests are outstanding (submitting into a lane
     whose result was not collected overwrites it in stream order)."""
 
-    def __init__(self, model, whisper, T, B=1, lanes=4, device="cuda", pinned_noise=False):
+    def __init__(self, model, whisper, T, B=1, lanes=4, device="cuda", pinned_noise=False, ring2=None):
         hp = model.hp
+        env = os.environ.get("SVCMI_RING2")
+        self.ring2 = int(ring2) if ring2 is not None else (int(env) if env is not None else (RING2_IN_FLIGHT if lanes > 1 else 0))
         self.model, self.whisper, self.T, self.B = model, whisper, int(T), int(B)
         self.keep = self.T // 2                                  # whisper/inference.py:40: len // 320 frames of 20 ms
         dev = torch.device(device)
@@ -69,7 +81,14 @@ class ClipLanes:
     def capture(self):
         """Warm up and capture every lane on its own stream (call after the first inputs are staged: the warm-up runs on them)."""
         if self.lanes is None:
-            self.lanes = GraphLanes(self._fns)
+            lib = self.model.ops.lib
+            if self.ring2 and lib.svcmi_tune_set(b"ring2", self.ring2) != 0:
+                raise ValueError(f"ring2 mask {self.ring2}")
+            try:
+                self.lanes = GraphLanes(self._fns)         # the kernels chosen during capture are what every replay runs
+            finally:
+                if self.ring2:
+                    lib.svcmi_tune_set(b"ring2", 0)
         return self
 
     def launch(self, lane=None):
