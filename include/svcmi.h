@@ -252,12 +252,6 @@ int svcmi_block_mean_f32(const float* const* xs, int32_t count, float* y, int64_
 int svcmi_snake_conv_supported(int32_t c, int32_t ld, int32_t ksize, int32_t dilation);
 /* 1 where the fused kernel is also the FASTER choice on MI355X (narrowest stages); the facade follows it. */
 int svcmi_snake_conv_preferred(int32_t c, int32_t ld, int32_t ksize, int32_t dilation);
-/* The 40- / 80-channel stages' fp32 half-step as ONE launch (round 5): SnakeAlias of the time tile in LDS + a matrix-core convolution whose
- * weight fragments stream from the packed fp32 image straight into registers.  Reached through svcmi_snake_conv_group_f32 with
- * (c, ld) = (40, 40) or (80, 80), ksize in {3, 7, 11}, dilation 1..5, 16-byte aligned x / y / res / bias; fp32 products and sums (the
- * summation order differs from svcmi_conv_gemm_f32's).  _preferred: the library's measured choice (knob "amp_gemm"). */
-int svcmi_snake_gemm_supported(int32_t c, int32_t ld, int32_t ksize, int32_t dilation);
-int svcmi_snake_gemm_preferred(int32_t c, int32_t ld, int32_t ksize, int32_t dilation);
 int svcmi_snake_conv_f32(const float* x, const float* w, const float* bias, const float* res, float* y,
                          const float* alpha_log, const float* beta_log, const float* filt,
                          int32_t batch, int32_t len, int32_t c, int32_t ld, int32_t ldw, int32_t ksize,

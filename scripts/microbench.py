@@ -213,36 +213,6 @@ def main():
                         print(f"ampgroup C={C} n={n} d={d} B={B} amp_u={u}: {us:8.1f} us  {B * fl / us / 1e6:6.1f} TF/s", flush=True)
                 ops.lib.svcmi_tune_set(b"amp_u", 0)
         ops.lib.svcmi_tune_set(b"amp_tt", 0)
-    if "ampgemm" in what:     # 40- / 80-channel half-step: grouped SnakeAlias + grouped implicit GEMM (two launches) vs the one-launch fused form
-        filt = torch.tensor([0.00202896, 0.00938947, -0.02554346, -0.05765738, 0.12857258, 0.44320980, 0.44320980,
-                             0.12857258, -0.05765738, -0.02554346, 0.00938947, 0.00202896], device="cuda")
-        for (C, n, tile) in ((40, 80000, 4), (80, 20000, 6)):
-            for B in (1, 4):
-                fl = sum(2.0 * B * n * C * C * k for k in (3, 7, 11))
-                xs = [torch.randn(B, n, C, device="cuda") for _ in range(3)]
-                ts = [torch.empty(B, n, C, device="cuda") for _ in range(3)]
-                rs = [torch.randn(B, n, C, device="cuda") for _ in range(3)]
-                outs = [torch.empty(B, n, C, device="cuda") for _ in range(3)]
-                als = [torch.randn(C, device="cuda") * 0.3 for _ in range(3)]
-                bes = [torch.randn(C, device="cuda") * 0.3 for _ in range(3)]
-                ws = [PW.pack_conv(torch.randn(C, C, k) / math.sqrt(C * k), C, C).cuda() for k in (3, 7, 11)]
-                bs = [torch.randn(C, device="cuda") for _ in range(3)]
-                for d in (1, 5):
-                    def two():
-                        ops.snake_alias_group(xs, als, bes, filt, ts)
-                        ops.conv_group([dict(x=ts[j], w=ws[j], bias=bs[j], ksize=k, dilation=d, pad=(k - 1) * d // 2, res=rs[j], out=outs[j], tile=tile)
-                                        for j, k in enumerate((3, 7, 11))])
-                    us2 = timeit(two)
-                    ref = outs[2].clone()
-                    print(f"ampgemm C={C} n={n} B={B} d={d} SnakeAlias + implicit GEMM (2 launches): {us2:8.1f} us  {fl / us2 / 1e6:6.1f} TF/s", flush=True)
-                    probs = [dict(x=xs[j], alpha_log=als[j], beta_log=bes[j], w=ws[j], bias=bs[j], ksize=k, dilation=d, res=rs[j], out=outs[j])
-                             for j, k in enumerate((3, 7, 11))]
-                    for knob in (1, 2):
-                        ops.lib.svcmi_tune_set(b"amp_gemm", knob)
-                        us = timeit(lambda: ops.snake_conv_group(probs, filt, c=C))
-                        print(f"ampgemm C={C} n={n} B={B} d={d} fused, amp_gemm={knob}:                     {us:8.1f} us  {fl / us / 1e6:6.1f} TF/s  "
-                              f"x{us2 / us:.2f}  max diff {float((outs[2] - ref).abs().max()):.1e}", flush=True)
-                    ops.lib.svcmi_tune_set(b"amp_gemm", 1)
     if "amplp" in what:       # the grouped half-step: fp32 vector kernel vs the fp16 matrix-core variants, both activation-phase forms
         filt = torch.tensor([0.00202896, 0.00938947, -0.02554346, -0.05765738, 0.12857258, 0.44320980, 0.44320980,
                              0.12857258, -0.05765738, -0.02554346, 0.00938947, 0.00202896], device="cuda")

@@ -775,49 +775,6 @@ def check_snake_conv_group_lp(ops, device, c=20, ld=20, B=2, n=300, precision="f
 
 
 
-def check_snake_gemm_group(ops, device, c=40, B=2, n=300, small=False):
-    """The 40- / 80-channel half-step as ONE launch (snake_gemm_group_kernel: SnakeAlias tile in LDS + streamed-weight fp32 matrix-core
-    convolution) against the two-launch form it replaces -- the library's own SnakeAlias, then torch's conv1d in float64 on that tensor:
-    3 / 7 / 11 taps x dilations 1 / 5 / 3, bias, residual, alpha, accumulate, sequence ends inside a tile, 1 and 3 problems per launch,
-    both tile sizes (knob amp_gemm = 1 | 2, same bits)."""
-    g = _g(1300 + c + n)
-    filt = W.kaiser_sinc_filter().view(-1).to(device)
-    probs, want = [], []
-    for i, (k, d) in enumerate(((3, 1), (11, 5), (7, 3))):
-        x = torch.randn(B, n, c, generator=g) * 1.5
-        res = torch.randn(B, n, c, generator=g)
-        y0 = torch.randn(B, n, c, generator=g)
-        al, be = torch.randn(c, generator=g) * 0.3, torch.randn(c, generator=g) * 0.3
-        w = torch.randn(c, c, k, generator=g) / math.sqrt(c * k)
-        bias = torch.randn(c, generator=g)
-        acc = i == 1
-        s_lib = ops.snake_alias(x.to(device), al.to(device), be.to(device), filt).cpu()
-        ref = F.conv1d(s_lib.double().transpose(1, 2), w.double(), bias.double(), dilation=d, padding=(k - 1) * d // 2).transpose(1, 2)
-        ref = (ref + res.double()) * 0.5 + (y0.double() if acc else 0.0)
-        want.append(ref.float())
-        probs.append(dict(x=x.to(device), alpha_log=al.to(device), beta_log=be.to(device), w=PW.pack_conv(w, c, c).to(device), bias=bias.to(device),
-                          ksize=k, dilation=d, res=res.to(device), alpha=0.5, accumulate=acc, y0=y0))
-    for k, d in ((3, 1), (7, 3), (11, 5)):
-        assert ops.lib.svcmi_snake_gemm_supported(c, c, k, d) == 1 and ops.lib.svcmi_snake_gemm_preferred(c, c, k, d) == 1
-    assert ops.lib.svcmi_snake_gemm_supported(20, 20, 3, 1) == 0 and ops.lib.svcmi_snake_gemm_supported(c, c, 5, 1) == 0
-    outs = {}
-    for knob in (1, 2):
-        assert ops.lib.svcmi_tune_set(b"amp_gemm", knob) == 0
-        try:
-            for n_prob in (1, 3):
-                for pr in probs:
-                    pr["out"] = pr["y0"].clone().to(device) if pr["accumulate"] else torch.full((B, n, c), 7.0).to(device)
-                got = ops.snake_conv_group(probs[:n_prob], filt, c=c)
-                for j in range(n_prob):
-                    _close(got[j], want[j], 1e-5, f"snake_gemm_group c={c} n={n} knob={knob} problem {j}")
-                outs[(knob, n_prob)] = [t.clone() for t in got[:n_prob]]
-        finally:
-            ops.lib.svcmi_tune_set(b"amp_gemm", 1)
-    for n_prob in (1, 3):
-        for a, b in zip(outs[(1, n_prob)], outs[(2, n_prob)]):
-            assert torch.equal(a, b)                      # the tile size does not touch the summation order
-    return True
-
 def check_snake_post(ops, device, B=2, n=700):
     """Fused output layer (SnakeAlias -> conv_post 10 -> 1, k = 7, no bias -> tanh) vs oracle SnakeAlias + torch conv1d."""
     g = _g(4242 + n)

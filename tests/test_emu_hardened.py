@@ -25,7 +25,7 @@ from tests.emu.build_emu import asan_runtime, build_emu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LEVEL = os.environ.get("SVCMI_HARDENED", "quick")
 # the kernels with LDS tiles, halos and multi-problem launches
-QUICK = "snake_conv or snake_post or thread_order or grouped"
+QUICK = "snake_conv_group or two_deep or snake_post"
 SAN_ENV = {"ASAN_OPTIONS": "detect_leaks=0:halt_on_error=1:abort_on_error=0:redzone=128", "UBSAN_OPTIONS": "print_stacktrace=1:halt_on_error=1"}
 
 

@@ -189,8 +189,3 @@ def test_attention16(ops, case):
 @pytest.mark.parametrize("tile,n,cin,k,T", [(1, 70, 64, 5, 150), (6, 80, 64, 5, 150), (4, 40, 40, 3, 300), (1, 70, 32, 1, 90), (3, 70, 64, 3, 150)])
 def test_conv_gemm_two_deep_ring_is_bit_identical(ops, tile, n, cin, k, T):
     K.check_conv_ring2(ops, "cuda", tile, n, cin=cin, k=k, T=T)
-
-
-@pytest.mark.parametrize("c,B,n", [(40, 2, 300), (40, 1, 80000), (80, 2, 200), (80, 1, 20000), (40, 4, 20000), (80, 1, 1)])
-def test_snake_gemm_group_one_launch_half_step(ops, c, B, n):
-    K.check_snake_gemm_group(ops, "cuda", c=c, B=B, n=n)

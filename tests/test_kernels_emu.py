@@ -196,8 +196,3 @@ def test_kernels_do_not_depend_on_the_thread_order_inside_a_barrier_interval(ops
 @pytest.mark.parametrize("tile,n,cin,k,T", [(1, 70, 64, 5, 150), (6, 80, 64, 5, 150), (4, 40, 40, 3, 300), (1, 70, 32, 1, 90), (3, 70, 64, 3, 150)])
 def test_conv_gemm_two_deep_ring_is_bit_identical(ops, tile, n, cin, k, T):
     K.check_conv_ring2(ops, "cpu", tile, n, cin=cin, k=k, T=T)
-
-
-@pytest.mark.parametrize("c,B,n", [(40, 2, 150), (40, 1, 300), (80, 2, 70), (80, 1, 200), (40, 1, 1)])
-def test_snake_gemm_group_one_launch_half_step(ops, c, B, n):
-    K.check_snake_gemm_group(ops, "cpu", c=c, B=B, n=n)

@@ -38,8 +38,8 @@ constexpr int DMAX = 5;      // largest dilation (bigv.py dilations 1, 3, 5)
 // 20 channels 75.0 -> 71.6 (fp32 matrix-core form) / 47.2 -> 44.4 (fp16 form), 10 channels 64.6 -> 63.0 / 47.1 -> 44.9; B = 4: -2.6 / -5 %.
 template <int CP>
 __device__ __forceinline__ int tile_row_offset(int t) {
-    static_assert(CP == 12 || CP == 20 || CP == 40 || CP == 80, "widths of the fused kernels");
-    return CP == 12 ? (t << 3) + (t << 2) : CP == 20 ? (t << 4) + (t << 2) : CP == 40 ? (t << 5) + (t << 3) : (t << 6) + (t << 4);
+    static_assert(CP == 12 || CP == 20 || CP == 40, "widths of the fused kernels");
+    return CP == 12 ? (t << 3) + (t << 2) : CP == 20 ? (t << 4) + (t << 2) : (t << 5) + (t << 3);
 }
 __device__ __forceinline__ const float* tile_column(const float* xc) {
 #ifndef SVCMI_EMU
@@ -600,124 +600,6 @@ __global__ __launch_bounds__(TPB) void snake_convm_group_kernel(AmpGroupArgs g) 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// The same fp32 matrix-core half-step for the 40- and 80-channel stages (round 5), where the weights of a problem no longer fit in LDS
-// beside the activated tile (70 / 280 KB at 11 taps): S = SnakeAlias(x) of a time tile + halo is built in LDS exactly as above (row
-// stride CP + 4 floats = 4 * odd: conflict-free ds_read_b128), and the WEIGHT fragments -- static data, wave-independent -- are loaded
-// straight from the packed fp32 image [co][tap * CP + ci] into registers, one 16-byte global load per (16-channel tile, K group) and lane
-// (lane = (output channel co, 4-channel K slice): the same (lane group <-> slice, instruction <-> component) K mapping), software-
-// prefetched one K group ahead.  After the tile barrier the K loop has NO barrier and no LDS writes: a wave streams its weight fragments
-// from L2 (each feeds NT MFMAs per component) and its S fragments from LDS.  Replaces, per half-step, the grouped SnakeAlias launch
-// (8 bytes per element through HBM) AND the grouped implicit-GEMM launch that re-fetched every input row once per tap through the
-// LDS-DMA ring: the activated tensor never exists in HBM.  Products and sums are fp32; the summation order differs from the
-// implicit GEMM's (K groups of 16 in tap-major order): 5e-6 on the waveform.
-//   40 channels: N tiles 3 x 16 (48, 17 % padded), TB = 256 output rows per block (halo recomputation <= 20 %), 54 KB of LDS;
-//   80 channels: N tiles 5 x 16 (exact),           TB = 128 (<= 39 %),                                          60 KB of LDS.
-template <int CP, int CR, int TB_>
-struct AmpG {
-    static constexpr int LS = CP + 4;
-    static constexpr int NC4 = CP / 4, NCT = (CR + 15) / 16;
-    static constexpr int TB = TB_, NT = TB_ / 64;            // 16-row time tiles per wave (4 waves)
-    static constexpr int ROWS = TB_ + 10 * DMAX;
-    static constexpr int S_FLOATS = ROWS * LS;
-    static_assert(CP % 4 == 0 && CR % 4 == 0 && (LS / 4) % 2 == 1 && TB_ % 64 == 0, "S row stride = 4 * odd floats; whole float4 channel slices");
-};
-
-template <int CP, int CR, int TB_>
-__global__ __launch_bounds__(TPB) void snake_gemm_group_kernel(AmpGroupArgs g) {
-    using TL = AmpG<CP, CR, TB_>;
-    constexpr int NC4 = TL::NC4, NCT = TL::NCT, NT = TL::NT, LS = TL::LS, TB = TL::TB;
-    __shared__ __attribute__((aligned(16))) float smem[TL::S_FLOATS];
-    const AmpArgs& p = g.p[blockIdx.z];
-    const int KS = p.ks;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = SVCMI_UNIFORM((int)(tid >> 6));
-    const int b = blockIdx.y;
-    const int n = p.n, ld = p.ld, d = p.dil;
-    const int halo = (KS - 1) * d / 2;
-    const int t_blk = blockIdx.x * TB;
-    const int rows = TB + 2 * halo;
-    const float* xb = p.x + (long long)b * n * ld;
-    snake_tile<CP, CR, LS>(smem, xb, p.alpha_log, p.beta_log, p.filt, n, ld, t_blk, halo, rows, tid);
-    __syncthreads();
-
-    const int nq = (KS * NC4 + 3) / 4;                       // K groups of 4 slices x 4 channels
-    const int tq = lane & 15, kq = lane >> 4;
-    svcmi_f32x4 acc[NT][NCT];
-#pragma unroll
-    for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) acc[tt][ct] = svcmi_f32x4{0.f, 0.f, 0.f, 0.f};
-    const int row0 = wave * (16 * NT) + tq;
-    // this lane's weight fragment of K group q, channel tile ct: w[co = 16 ct + tq][tap * CP + 4 c4 .. + 3], (tap, c4) = slice 4 q + kq
-    const float* wrow[NCT];
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) wrow[ct] = p.w + (long long)(ct * 16 + tq < CR ? ct * 16 + tq : 0) * p.ldw;
-    auto load_w = [&](int q, svcmi_f32x4 (&af)[NCT]) {
-        const int sl = 4 * q + kq;
-        const int tap = sl / NC4, c4 = sl - tap * NC4;
-        const int off = (tap < KS ? tap : KS - 1) * CP + 4 * c4;          // always a valid address: dead lanes load and discard (no branches)
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-            const float4 v = *reinterpret_cast<const float4*>(wrow[ct] + off);
-            const bool live = ct * 16 + tq < CR && tap < KS;
-            af[ct] = svcmi_f32x4{live ? v.x : 0.f, live ? v.y : 0.f, live ? v.z : 0.f, live ? v.w : 0.f};
-        }
-    };
-    auto k_group = [&](int q, const svcmi_f32x4 (&aq)[NCT]) {
-        const int sl = 4 * q + kq;
-        int tap = sl / NC4;
-        const int c4 = sl - tap * NC4;
-        tap = tap < KS ? tap : KS - 1;                      // (a slice past the last tap: any finite row, its weights are zero)
-        const float* sp = smem + (row0 + tap * d) * LS + 4 * c4;
-        svcmi_f32x4 bf[NT];
-#pragma unroll
-        for (int tt = 0; tt < NT; ++tt) bf[tt] = *reinterpret_cast<const svcmi_f32x4*>(sp + tt * 16 * LS);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-                for (int tt = 0; tt < NT; ++tt) acc[tt][ct] = svcmi_mfma_16x16x4(aq[ct][e], bf[tt][e], acc[tt][ct]);
-    };
-    // two K groups per trip, the weight fragments of the next group requested before the MFMAs of the current one (static register
-    // buffers: a run-time buffer index would send the fragments through scratch memory)
-    svcmi_f32x4 a0[NCT], a1[NCT];
-    load_w(0, a0);
-    for (int q = 0; q < nq; q += 2) {
-        if (q + 1 < nq) load_w(q + 1, a1);
-        k_group(q, a0);
-        if (q + 1 < nq) {
-            if (q + 2 < nq) load_w(q + 2, a0);
-            k_group(q + 1, a1);
-        }
-    }
-
-    // ---- epilogue: lane = (time tq of the tile, output channels ct * 16 + 4 kq .. + 3); the arithmetic of snake_conv_body per value
-    float* yb = p.y + (long long)b * n * ld;
-    const float* rb = p.res ? p.res + (long long)b * n * ld : nullptr;
-#pragma unroll
-    for (int tt = 0; tt < NT; ++tt) {
-        const int t = t_blk + wave * (16 * NT) + tt * 16 + tq;
-        if (t >= n) continue;
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-            const int co4 = ct * 16 + 4 * kq;
-            if (co4 >= CR) continue;
-            float v[4] = {acc[tt][ct][0], acc[tt][ct][1], acc[tt][ct][2], acc[tt][ct][3]};
-            float* yr = yb + (long long)t * ld + co4;
-            float4 bq = make_float4(0.f, 0.f, 0.f, 0.f), rq = bq, oq = bq;
-            if (p.bias) bq = *reinterpret_cast<const float4*>(p.bias + co4);
-            if (rb) rq = *reinterpret_cast<const float4*>(rb + (long long)t * ld + co4);
-            if (p.accumulate) oq = *reinterpret_cast<const float4*>(yr);
-            const float bv[4] = {bq.x, bq.y, bq.z, bq.w}, rv[4] = {rq.x, rq.y, rq.z, rq.w}, ov[4] = {oq.x, oq.y, oq.z, oq.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (v[e] + bv[e] + rv[e]) * p.alpha + ov[e];
-            *reinterpret_cast<float4*>(yr) = make_float4(v[0], v[1], v[2], v[3]);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // Stage entry of the two narrowest generator stages in one launch: polyphase transposed convolution of x plus the strided
 // "noise" convolution of the harmonic source (vits_decoder/generator.py:183-186: `x = ups[i](x); x = x + noise_convs[i](src)`).
 // As two padded implicit-GEMM launches these cost 84 + 105 us (10 channels) and 41 + 63 us (20 channels) for < 0.2 GFLOP:
@@ -856,19 +738,6 @@ extern "C" int svcmi_snake_conv_preferred(int32_t c, int32_t ld, int32_t ksize, 
     return svcmi_snake_conv_supported(c, ld, ksize, dilation) && c <= 20;
 }
 
-// tuning knob ("amp_gemm", 0..3): the grouped fp32 half-step of the 40- / 80-channel stages as ONE launch with SnakeAlias fused in front of a
-// streamed-weight matrix-core convolution (snake_gemm_group_kernel) instead of a grouped SnakeAlias launch + a grouped implicit-GEMM launch.
-// 0 = off (the two-launch form), 1 = on with the default tiles (256 rows at 40 channels, 128 at 80), 2 = the smaller tiles (128 / 64),
-// 3 = 40 channels only
-int g_amp_gemm = 1;
-// The 40- / 80-channel stages' one-launch half-step (snake_gemm_group_kernel, fp32 only, grouped entry point only).
-extern "C" int svcmi_snake_gemm_supported(int32_t c, int32_t ld, int32_t ksize, int32_t dilation) {
-    return ((c == 40 && ld == 40) || (c == 80 && ld == 80)) && (ksize == 3 || ksize == 7 || ksize == 11) && dilation >= 1 && dilation <= DMAX;
-}
-extern "C" int svcmi_snake_gemm_preferred(int32_t c, int32_t ld, int32_t ksize, int32_t dilation) {
-    return g_amp_gemm != 0 && svcmi_snake_gemm_supported(c, ld, ksize, dilation) && (g_amp_gemm != 3 || c == 40);
-}
-
 extern "C" int svcmi_snake_conv_f32(const float* x, const float* w, const float* bias, const float* res, float* y,
                                     const float* alpha_log, const float* beta_log, const float* filt,
                                     int32_t batch, int32_t len, int32_t c, int32_t ld, int32_t ldw, int32_t ksize,
@@ -944,7 +813,7 @@ extern "C" int svcmi_snake_conv_group_f32(const svcmi_snake_conv_desc* descs, in
     for (int i = 0; i < count; ++i) {
         const svcmi_snake_conv_desc& d = descs[order[i]];
         if (!d.x || !d.w || !d.y || !d.alpha_log || !d.beta_log || d.x == d.y) return SVCMI_EINVAL;
-        if (!svcmi_snake_conv_supported(c, ld, d.ksize, d.dilation) && !svcmi_snake_gemm_supported(c, ld, d.ksize, d.dilation)) return SVCMI_EUNSUPPORTED;
+        if (!svcmi_snake_conv_supported(c, ld, d.ksize, d.dilation)) return SVCMI_EUNSUPPORTED;
         if (d.ldw < d.ksize * ld || d.ldw % 4 != 0) return SVCMI_EINVAL;
         if (((uintptr_t)d.w & 15) || ((uintptr_t)d.x & 7) || ((uintptr_t)d.y & 7) || ((uintptr_t)d.res & 7)) return SVCMI_EALIGN;
         AmpArgs& a = g.p[i];
@@ -953,21 +822,6 @@ extern "C" int svcmi_snake_conv_group_f32(const svcmi_snake_conv_desc* descs, in
         a.ks = d.ksize;
     }
     for (int i = count; i < AMP_GROUP; ++i) g.p[i] = g.p[0];
-    if (c >= 40 && (g_amp_gemm != 0 || c == 80)) {
-        // 40 / 80 channels: SnakeAlias tile in LDS + streamed-weight matrix-core convolution (every batch size: the bits do not depend on it)
-        bool al = true;                                   // float4 accesses: 16-byte aligned rows
-        for (int i = 0; i < count; ++i) al = al && !(((uintptr_t)g.p[i].x | (uintptr_t)g.p[i].y | (uintptr_t)g.p[i].res | (uintptr_t)g.p[i].bias) & 15);
-        if (!al) return SVCMI_EALIGN;
-        const bool small = g_amp_gemm == 2;
-        if (c == 40) {
-            if (small) SVCMI_LAUNCH((snake_gemm_group_kernel<40, 40, 128>), dim3((unsigned)((len + 127) / 128), (unsigned)batch, (unsigned)count), dim3(TPB), 0, stream, g);
-            else SVCMI_LAUNCH((snake_gemm_group_kernel<40, 40, 256>), dim3((unsigned)((len + 255) / 256), (unsigned)batch, (unsigned)count), dim3(TPB), 0, stream, g);
-        } else {
-            if (small) SVCMI_LAUNCH((snake_gemm_group_kernel<80, 80, 64>), dim3((unsigned)((len + 63) / 64), (unsigned)batch, (unsigned)count), dim3(TPB), 0, stream, g);
-            else SVCMI_LAUNCH((snake_gemm_group_kernel<80, 80, 128>), dim3((unsigned)((len + 127) / 128), (unsigned)batch, (unsigned)count), dim3(TPB), 0, stream, g);
-        }
-        return SVCMI_LAST_ERROR();
-    }
     // measured choice (profiles/r04r_amplp.log): the matrix-core form wins where ONE clip's launch has the chip to itself and the vector
     // pipe is the bottleneck -- 20 channels, B = 1: 92.7 -> 75.7 us; from B = 4 on (284 vs 280 us) and at 10 channels (67 vs 64) the padded
     // tile's extra arithmetic costs what the freed vector issue slots buy
@@ -1093,10 +947,6 @@ extern "C" int svcmi_tune_set(const char* name, int32_t value) {
     i = 0;
     while (km[i] && name[i] == km[i]) ++i;
     if (km[i] == 0 && name[i] == 0 && value >= 0 && value <= 3) { g_amp_mfma = value; return 0; }
-    const char* kg = "amp_gemm";
-    i = 0;
-    while (kg[i] && name[i] == kg[i]) ++i;
-    if (kg[i] == 0 && name[i] == 0 && value >= 0 && value <= 3) { g_amp_gemm = value; return 0; }
     const char* ku = "amp_u";
     i = 0;
     while (ku[i] && name[i] == ku[i]) ++i;

@@ -622,13 +622,7 @@ bool amp_stage_grouped(Ctx& c, const svcmi_synth_model& m, const svcmi_gen_stage
     int nf = 0, nall = 0;
     for (int j = 0; j < nb; ++j) {
         if (st.blocks[j].n_dil != nd) return false;
-        for (int q = 0; q < nd; ++q) {
-            // one fused launch per half-step: the narrow stages' kernels in every mode; the 40- / 80-channel matrix-core form in fp32 only
-            // (in the 16-bit modes these stages' convolutions run on the 16-bit GEMM kernels)
-            const bool f = svcmi_snake_conv_preferred(st.c, cp, st.blocks[j].k, st.blocks[j].dil[q]) ||
-                           (c.prec == SVCMI_PREC_F32 && svcmi_snake_gemm_preferred(st.c, cp, st.blocks[j].k, st.blocks[j].dil[q]));
-            nf += f ? 1 : 0; ++nall;
-        }
+        for (int q = 0; q < nd; ++q) { nf += svcmi_snake_conv_preferred(st.c, cp, st.blocks[j].k, st.blocks[j].dil[q]) ? 1 : 0; ++nall; }
     }
     if (nf != 0 && nf != nall) return false;
     const bool fused = nf == nall;

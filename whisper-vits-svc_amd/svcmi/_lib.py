@@ -178,8 +178,6 @@ SIGNATURES = {
     "svcmi_snake_alias_f32": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "svcmi_snake_conv_supported": (c_int, [_I, _I, _I, _I]),
     "svcmi_snake_conv_preferred": (c_int, [_I, _I, _I, _I]),
-    "svcmi_snake_gemm_supported": (c_int, [_I, _I, _I, _I]),
-    "svcmi_snake_gemm_preferred": (c_int, [_I, _I, _I, _I]),
     "svcmi_snake_conv_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
     "svcmi_upsample_noise_supported": (c_int, [_I, _I, _I]),
     "svcmi_upsample_noise_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _L, _I, _I, _I, _I, _P]),
