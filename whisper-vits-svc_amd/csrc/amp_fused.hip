@@ -247,6 +247,23 @@ __device__ __forceinline__ void snake_conv_body(const AmpArgs& p, float* S) {
         for (int j = 0; j < TT; ++j) acc[j][c] = bv;
     }
     const int tl0 = tsub * 64 * TT + lane;             // tile-local time of this lane's first step; steps are 64 apart
+    // the residual values of this lane's outputs are requested before the convolution and consumed by the epilogue (round 5: the epilogue
+    // used to start its dependent load -> store round trip only after the last FMA).  Measured (profiles/r05h_residual_prefetch.log): one
+    // time step per thread (the 10-channel tile) 62.7 -> 59.8 us, two (20 channels) 90.5 -> 95.7 -- so only where TT == 1
+    constexpr bool PRE = TT == 1;
+    const float* rb = p.res ? p.res + (long long)b * n * ld : nullptr;
+    float2 rpre[PRE ? TT : 1][NCO / 2];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int j = 0; j < TT; ++j) {
+            const int t = t_blk + tl0 + 64 * j;
+#pragma unroll
+            for (int c = 0; c < NCO; c += 2) {
+                rpre[j][c / 2] = make_float2(0.f, 0.f);
+                if (rb && t < n && co0 + c < CR) rpre[j][c / 2] = *reinterpret_cast<const float2*>(rb + (long long)t * ld + co0 + c);
+            }
+        }
+    }
     const float* wg = p.w + (long long)co0 * p.ldw;
     for (int tap = 0; tap < KS; ++tap) {
         const float* srow = S + (tl0 + tap * d) * LS;  // S row of output tl0 at this tap: tl0 + halo + (tap - (KS-1)/2)*d
@@ -274,19 +291,22 @@ __device__ __forceinline__ void snake_conv_body(const AmpArgs& p, float* S) {
 
     // ---- epilogue: + res, * alpha, (+ y_old); pad channels of the last group are written as zero
     float* yb = p.y + (long long)b * n * ld;
-    const float* rb = p.res ? p.res + (long long)b * n * ld : nullptr;
 #pragma unroll
     for (int j = 0; j < TT; ++j) {
         const int t = t_blk + tl0 + 64 * j;
         if (t >= n) continue;
         float* yr = yb + (long long)t * ld + co0;
-        const float* rr = rb ? rb + (long long)t * ld + co0 : nullptr;
 #pragma unroll
         for (int c = 0; c < NCO; c += 2) {
             float v0 = acc[j][c], v1 = acc[j][c + 1];
             if (co0 + c >= CR) { v0 = 0.f; v1 = 0.f; }
             else {
-                if (rr) { const float2 r2 = *reinterpret_cast<const float2*>(rr + c); v0 += r2.x; v1 += r2.y; }
+                if (rb) {
+                    float2 r2;
+                    if constexpr (PRE) r2 = rpre[j][c / 2];
+                    else r2 = *reinterpret_cast<const float2*>(rb + (long long)t * ld + co0 + c);
+                    v0 += r2.x; v1 += r2.y;
+                }
                 v0 *= p.alpha; v1 *= p.alpha;
                 if (p.accumulate) { const float2 o2 = *reinterpret_cast<const float2*>(yr + c); v0 += o2.x; v1 += o2.y; }
             }
@@ -426,6 +446,21 @@ __device__ __forceinline__ void snake_conv16_body(const AmpArgs& p, float* smem,
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) acc[tt][ct] = svcmi_f32x4{0.f, 0.f, 0.f, 0.f};
     const int row0 = wave * (16 * NT) + tq;                 // S row of this lane's time step in tile 0 at tap 0
+    // the residual rows of this lane's outputs are requested HERE, before the MFMA loop, and consumed by the epilogue: at B = 16 the launch is
+    // bound by its memory-level parallelism (48 % of wave-cycles parked, profiles/r04zzzz_pmc_c2_mixed.json), and the epilogue used to start
+    // a dependent load -> store round trip per time tile only after the last MFMA
+    const float* rb = p.res ? p.res + (long long)b * n * ld : nullptr;
+    float4 rpre[NT][NCT];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+        const int t = t_blk + wave * (16 * NT) + tt * 16 + tq;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const int co4 = ct * 16 + 4 * kq;
+            rpre[tt][ct] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rb && t < n && co4 < CP) rpre[tt][ct] = *reinterpret_cast<const float4*>(rb + (long long)t * ld + co4);
+        }
+    }
     for (int step = 0; step < nsteps; ++step) {
         const int s = 4 * step + kq;
         int tap = s / CK;
@@ -449,11 +484,10 @@ __device__ __forceinline__ void snake_conv16_body(const AmpArgs& p, float* smem,
 
     // ---- epilogue: lane = (time tq of the tile, output channels ct * 16 + 4 kq .. + 3)
     float* yb = p.y + (long long)b * n * ld;
-    const float* rb = p.res ? p.res + (long long)b * n * ld : nullptr;
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) {
         const int t = t_blk + wave * (16 * NT) + tt * 16 + tq;
-        asm volatile("" ::: "memory");      // one time tile's residual / old-output loads in flight at a time (all of them hoisted: 190 VGPRs)
+        asm volatile("" ::: "memory");      // one time tile's old-output loads in flight at a time (all of them hoisted: 190 VGPRs)
         if (t >= n) continue;
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
@@ -461,9 +495,9 @@ __device__ __forceinline__ void snake_conv16_body(const AmpArgs& p, float* smem,
             if (co4 >= CP) continue;
             float v[4] = {acc[tt][ct][0], acc[tt][ct][1], acc[tt][ct][2], acc[tt][ct][3]};
             float* yr = yb + (long long)t * ld + co4;
-            float4 bq = make_float4(0.f, 0.f, 0.f, 0.f), rq = bq, oq = bq;
+            float4 bq = make_float4(0.f, 0.f, 0.f, 0.f), oq = bq;
+            const float4 rq = rpre[tt][ct];
             if (p.bias) bq = *reinterpret_cast<const float4*>(p.bias + co4);
-            if (rb) rq = *reinterpret_cast<const float4*>(rb + (long long)t * ld + co4);
             if (p.accumulate) oq = *reinterpret_cast<const float4*>(yr);
             const float bv[4] = {bq.x, bq.y, bq.z, bq.w}, rv[4] = {rq.x, rq.y, rq.z, rq.w}, ov[4] = {oq.x, oq.y, oq.z, oq.w};
 #pragma unroll
@@ -546,6 +580,19 @@ __device__ __forceinline__ void snake_convm_body(const AmpArgs& p, float* smem, 
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) acc[tt][ct] = svcmi_f32x4{0.f, 0.f, 0.f, 0.f};
     const int row0 = wave * (16 * NT) + tq;
+    // (the residual rows requested before the MFMA loop: see snake_conv16_body)
+    const float* rb = p.res ? p.res + (long long)b * n * ld : nullptr;
+    float4 rpre[NT][NCT];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+        const int t = t_blk + wave * (16 * NT) + tt * 16 + tq;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const int co4 = ct * 16 + 4 * kq;
+            rpre[tt][ct] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rb && t < n && co4 < CP) rpre[tt][ct] = *reinterpret_cast<const float4*>(rb + (long long)t * ld + co4);
+        }
+    }
     for (int q = 0; q < nq; ++q) {
         const int sl = 4 * q + kq;
         int tap = sl / NC4;
@@ -567,7 +614,6 @@ __device__ __forceinline__ void snake_convm_body(const AmpArgs& p, float* smem, 
 
     // ---- epilogue: lane = (time tq of the tile, output channels ct * 16 + 4 kq .. + 3); the arithmetic of snake_conv_body per value
     float* yb = p.y + (long long)b * n * ld;
-    const float* rb = p.res ? p.res + (long long)b * n * ld : nullptr;
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) {
         const int t = t_blk + wave * (16 * NT) + tt * 16 + tq;
@@ -579,9 +625,9 @@ __device__ __forceinline__ void snake_convm_body(const AmpArgs& p, float* smem, 
             if (co4 >= CP) continue;
             float v[4] = {acc[tt][ct][0], acc[tt][ct][1], acc[tt][ct][2], acc[tt][ct][3]};
             float* yr = yb + (long long)t * ld + co4;
-            float4 bq = make_float4(0.f, 0.f, 0.f, 0.f), rq = bq, oq = bq;
+            float4 bq = make_float4(0.f, 0.f, 0.f, 0.f), oq = bq;
+            const float4 rq = rpre[tt][ct];
             if (p.bias) bq = *reinterpret_cast<const float4*>(p.bias + co4);
-            if (rb) rq = *reinterpret_cast<const float4*>(rb + (long long)t * ld + co4);
             if (p.accumulate) oq = *reinterpret_cast<const float4*>(yr);
             const float bv[4] = {bq.x, bq.y, bq.z, bq.w}, rv[4] = {rq.x, rq.y, rq.z, rq.w}, ov[4] = {oq.x, oq.y, oq.z, oq.w};
 #pragma unroll

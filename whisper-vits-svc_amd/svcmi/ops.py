@@ -81,10 +81,12 @@ class Ops:
         # summation order (<= 5e-6 on the waveform) or the operand precision: amp_mfma (fp32 matrix-core half-step at 20 channels and
         # batch <= 2 -- so fp32 bits are reproducible per batch class, <= 2 clips vs more), amp_lp (fp16 operands).
         # SVCMI_TUNE="amp_mfma=0,ring2=15" applies them to this process (A/B runs of bench.py on the GPU box)
+        self.tune = {}                         # what SVCMI_TUNE set for this process (a scoped change restores to these, not to the defaults)
         for item in filter(None, os.environ.get("SVCMI_TUNE", "").split(",")):
             k, _, v = item.partition("=")
             if self.lib.svcmi_tune_set(k.strip().encode(), int(v)) != 0:
                 raise SvcmiError(f"SVCMI_TUNE: unknown knob or value {item!r}")
+            self.tune[k.strip()] = int(v)
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):

@@ -88,7 +88,7 @@ class ClipLanes:
                 self.lanes = GraphLanes(self._fns)         # the kernels chosen during capture are what every replay runs
             finally:
                 if self.ring2:
-                    lib.svcmi_tune_set(b"ring2", 0)
+                    lib.svcmi_tune_set(b"ring2", getattr(self.model.ops, "tune", {}).get("ring2", 0))
         return self
 
     def launch(self, lane=None):
