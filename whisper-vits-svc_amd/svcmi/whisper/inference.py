@@ -6,6 +6,7 @@ like whisper/inference.py:11-29, keeps only the audio encoder truncated to the f
 Arithmetic is fp32 (the reference runs fp16 on CUDA, fp32 on CPU -- :22-23; fp32 is the parity default,
 SURVEY.md section 0).
 """
+import os
 import threading
 
 import numpy as np
@@ -30,6 +31,12 @@ class AudioEncoder:
         self.split_o = self.split_mlp = 0
         self.tile_qkv = self.tile_o = self.tile_mlp1 = self.tile_mlp2 = 0
         self.small_m_rows = 0                    # above this many GEMM rows (0 = 1024) the library's own tile heuristic takes over
+        # tuning runs: SVCMI_WHISPER_TUNE="split_o=1,tile_mlp1=1,..." overrides the fields above for this process (A/B runs of bench.py)
+        for item in filter(None, os.environ.get("SVCMI_WHISPER_TUNE", "").split(",")):
+            k, _, v = item.partition("=")
+            if k.strip() not in ("split_o", "split_mlp", "tile_qkv", "tile_o", "tile_mlp1", "tile_mlp2", "small_m_rows"):
+                raise ValueError(f"SVCMI_WHISPER_TUNE: unknown field {k!r}")
+            setattr(self, k.strip(), int(v))
         # GEMM operand precision of this encoder: None = fp32 (parity default); "bf16x3" / "bf16" / "f16" (the reference's
         # own accelerator path is fp16: whisper/inference.py:22-23,43-44) route the linear layers through
         # svcmi_conv_gemm_lp.  LayerNorm, softmax, GELU, residual stream and accumulation stay fp32 in every mode.
