@@ -145,3 +145,28 @@ def test_ivf_nprobe1_restatement_against_scikit_learn_per_cell():
         assert np.array_equal(labels[i, :m], ids[ii[0]])
         assert np.allclose(dist[i, :m], dd[0], rtol=1e-5, atol=1e-6)
         assert np.array_equal(recons[i, :m], vec[ii[0]])
+
+
+@pytest.mark.parametrize("rate", [32000, 44100, 48000, 22050])
+def test_loader_resampler_against_analytically_sampled_tones(tmp_path, rate):
+    """``load_audio`` on a non-16 kHz file (librosa.load's job, whisper/audio.py:24-26; librosa uses soxr, we use scipy's polyphase
+    filter: a documented divergence, so no parity claim) must at least BE a band-limited resampler: tones below 6 kHz written at
+    ``rate`` come back at 16 kHz as the same tones sampled at 16 kHz (interior samples, 2e-3 of full scale), int16 PCM in."""
+    from scipy.io import wavfile
+    from svcmi.whisper.audio import load_audio
+    dur = 0.5
+    t_in = np.arange(int(rate * dur)) / rate
+    freqs, amps = (220.0, 1730.0, 5900.0), (0.4, 0.25, 0.1)
+    x = sum(a * np.sin(2 * np.pi * f * t_in) for f, a in zip(freqs, amps))
+    path = tmp_path / f"tones_{rate}.wav"
+    wavfile.write(path, rate, np.round(x * 32767.0).astype(np.int16))
+    y = load_audio(str(path))
+    assert y.dtype == np.float32 and abs(len(y) - int(round(16000 * dur))) <= 1
+    t_out = np.arange(len(y)) / 16000.0
+    want = sum(a * np.sin(2 * np.pi * f * t_out) for f, a in zip(freqs, amps))
+    edge = 400                                                   # filter transients at both ends
+    assert float(np.abs(y[edge:-edge] - want[edge:-edge]).max()) <= 2e-3
+    # and a 16 kHz file is passed through exactly (int16 / 32768)
+    wavfile.write(tmp_path / "same.wav", 16000, np.round(want * 32767.0).astype(np.int16))
+    z = load_audio(str(tmp_path / "same.wav"))
+    assert np.array_equal(z, np.round(want * 32767.0).astype(np.int16).astype(np.float32) / 32768.0)

@@ -6,9 +6,12 @@ implicit-GEMM kernel, the rest is csrc/audio_frontend.hip.
 
 Pinned vs the reference: STFT framing (n_fft 400, hop 160, periodic hann, center=True / reflect, last frame
 dropped), |.|^2, log10 / (max - 8) / (x + 4) / 4 -- checked against the reference function itself
-(oracle/make_golden.py, tests/golden/logmel_*.npz).  NOT pinned: the filterbank (``librosa.filters.mel``, an
-un-vendored dependency that is not installed here; restated below from its published algorithm: Slaney mel scale,
-Slaney area normalisation) and ``librosa.load``'s resampler for non-16 kHz files.
+(oracle/make_golden.py, tests/golden/logmel_*.npz).  The filterbank (``librosa.filters.mel``, an un-vendored dependency
+that is not installed here; restated below from its published algorithm: Slaney mel scale, Slaney area normalisation) is
+pinned against an independent implementation instead (transformers.audio_utils.mel_filter_bank, 9.2e-10:
+tests/test_independent_pins.py).  A DOCUMENTED DIVERGENCE remains for non-16 kHz files: ``librosa.load`` resamples with soxr,
+``load_audio`` with scipy's polyphase filter -- both band-limited resamplers, not the same taps; the test file checks ours
+against analytically sampled tones (16 kHz PCM input, what the reference's own preprocessing writes, is bit-exact).
 """
 import math
 from functools import lru_cache
