@@ -29,6 +29,10 @@ def asan_runtime():
 def build_emu(force=False, sanitize=False, tls=False, harness_only=False):
     """harness_only: hip_emu.cpp alone (the scheduler + its self-test kernels, tests/test_emu_hardened.py) -- seconds instead of minutes."""
     kind = "san" if sanitize else ("tls" if tls else "")
+    extra = os.environ.get("SVCMI_EMU_CXXFLAGS", "").split()      # build experiments (-DSVCMI_...=...): the same switches as scripts/build_variant.sh
+    if extra:
+        kind += "x"                                                # its own library / object directory, rebuilt every time
+        force = True
     out = os.path.join(OUT_DIR, f"lib{'emu_harness' if harness_only else 'svcmi_emu'}{'_' + kind if kind else ''}.so")
     objdir = os.path.join(OUT_DIR, ("h" if harness_only else "") + kind) if (kind or harness_only) else OUT_DIR
     srcs = [] if harness_only else sorted(glob.glob(os.path.join(CSRC, "*.hip")))
@@ -45,6 +49,7 @@ def build_emu(force=False, sanitize=False, tls=False, harness_only=False):
                  "-fsanitize=address,undefined", "-fno-sanitize=alignment,vptr", "-fno-sanitize-recover=undefined"]
     if tls:
         flags.append("-DSVCMI_EMU_TLS")
+    flags += extra
     jobs = [(flags + ["-DSVCMI_EMU", "-I", HERE, "-I", CSRC, "-x", "c++", "-c", s, "-o", os.path.join(objdir, os.path.basename(s) + ".o")])
             for s in srcs]
     jobs.append(flags + ["-DSVCMI_EMU", "-I", HERE, "-c", os.path.join(HERE, "hip_emu.cpp"), "-o", os.path.join(objdir, "hip_emu.o")])

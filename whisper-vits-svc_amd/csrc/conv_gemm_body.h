@@ -59,6 +59,12 @@
 
 namespace {
 
+// Build switch of the fp32 K loop: 1 (default since round 5: judged line 1429-1433 -> 1446-1447 audio-s/s, one clip alone 9.48 -> 9.41 ms,
+// profiles/r05p_midbar.log) = the mid-barrier pipeline (conv_gemm_body, "MIDBAR"), 0 = barrier at the top of every K-step (what the
+// 16-bit kernels keep)
+#ifndef SVCMI_GEMM_MIDBAR
+#define SVCMI_GEMM_MIDBAR 1
+#endif
 constexpr int BK = 32;
 enum { MODE_CHUNK = 0, MODE_VEC = 1, MODE_SCALAR = 2, MODE_CHUNK_RS = 3 };   // _RS: CHUNK with x_row_shift != 0
 
@@ -391,8 +397,10 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
     constexpr int PIECES = APCS + NB * B_PER;             // pieces per tile per wave ...
     constexpr int DMAS = (MODE == MODE_SCALAR ? 4 * A_PER : APCS) + NB * B_PER;   // ... and the DMA instructions they take
     // prologue: tiles it_beg .. it_beg+NST-2 into slots 0 .. NST-2
+    // (the mid-barrier loop below -- fp32, MIDBAR -- fills ALL NST slots up front: it refills a slot right after the barrier that retires it)
+    constexpr bool MIDBAR = SVCMI_GEMM_MIDBAR != 0 && !LP && !A16;
 #pragma unroll
-    for (int s0 = 0; s0 < NST - 1; ++s0) {
+    for (int s0 = 0; s0 < (MIDBAR ? NST : NST - 1); ++s0) {
         if (it_beg + s0 < it_end) {
             stage_prep(it_beg + s0);
 #pragma unroll
@@ -529,7 +537,91 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
             }
         }
     };
-    {
+    if constexpr (MIDBAR) {
+        // Mid-barrier pipeline (round 5).  The loop above opens every K-step with [wait DMA, barrier, fragment reads of sub-step 0,
+        // s_waitcnt lgkmcnt(0)]: an exposed LDS round trip per K-step in which the wave issues no MFMA (the ISA of the 64x80 tile: 6
+        // ds_read_b128 and their wait between the barrier and the first of 40 MFMAs).  Here the barrier that publishes tile it+1 sits
+        // BEFORE THE LAST SUB-STEP of tile it -- by then every wave holds all of tile it's fragments in registers -- and the first
+        // fragments of tile it+1 are requested right behind it, so they land under the last sub-step's MFMAs; the slot of tile it is
+        // refilled (tile it+NST) right after that barrier, a whole NST-1 K-steps before it is needed.  Same MFMAs in the same order:
+        // bit-identical results.
+        auto wait_tiles = [&](int k) {            // at most k later tiles' DMAs of this wave may still be in flight
+            if (k <= 0) svcmi_dma_wait_n<0>();
+            else if (k == 1) svcmi_dma_wait_n<DMAS>();
+            else svcmi_dma_wait_n<(NST >= 3 ? 2 : 1) * DMAS>();
+        };
+        if (it_beg < it_end) {
+            svcmi_f32x4 a4[2][FA], b4[2][FB];
+            svcmi_f32x4 tie0 = {0.f, 0.f, 0.f, 0.f};
+            {
+                const int issued = it_end - it_beg < NST ? it_end - it_beg : NST;
+                wait_tiles(issued - 1);
+                __syncthreads();
+                load_frags(As0 + a_off, Bs0 + b_off, 0, a4[0], b4[0], tie0);
+                frags_arrive(a4[0], b4[0]);
+            }
+            // one K-step; NEXT / REFILL are compile-time so that the steady state is ONE basic block (three loops below: steady, drain, last)
+            auto step = [&](int it, int slot, int nslot, auto next_tag, auto refill_tag) {
+                constexpr bool NEXT = decltype(next_tag)::value, REFILL = decltype(refill_tag)::value;
+                const float* Ab = As0 + slot * NA * BM * BK + a_off;
+                const float* Bb = Bs0 + slot * NB * BTILE + b_off;
+#pragma unroll
+                for (int sb = 0; sb < NSUB; ++sb) {
+                    svcmi_f32x4(&af)[FA] = a4[sb & 1];
+                    svcmi_f32x4(&bf)[FB] = b4[sb & 1];
+                    if (sb + 1 < NSUB) {
+                        load_frags(Ab, Bb, sb + 1, a4[(sb + 1) & 1], b4[(sb + 1) & 1], af[0]);
+                    } else if constexpr (NEXT) {
+                        if constexpr (REFILL) {
+                            wait_tiles(NST - 2);                     // steady state: tiles it+2 .. it+NST-1 may still be in flight
+                        } else {
+                            const int last = it + NST - 1 < it_end - 1 ? it + NST - 1 : it_end - 1;      // newest tile issued
+                            wait_tiles(last - (it + 1));
+                        }
+                        __syncthreads();         // tile it+1 has landed for every wave; every wave holds all of tile it in registers
+                        load_frags(As0 + nslot * NA * BM * BK + a_off, Bs0 + nslot * NB * BTILE + b_off, 0, a4[0], b4[0], af[0]);
+                        if constexpr (REFILL) {
+                            stage_prep(it + NST);
+#pragma unroll
+                            for (int q = 0; q < PIECES; ++q) {
+                                if (q < APCS) stage_a(it + NST, slot, q);
+                                else stage_b(slot, q - APCS);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < WM; ++i)
+#pragma unroll
+                        for (int j = 0; j < WN; ++j) mma(acc[i][j], af[i][0], bf[j][0]);
+#pragma unroll
+                    for (int i = 0; i < WM; ++i)
+#pragma unroll
+                        for (int j = 0; j < WN; ++j) mma(acc[i][j], af[i][1], bf[j][1]);
+#pragma unroll
+                    for (int i = 0; i < WM; ++i)
+#pragma unroll
+                        for (int j = 0; j < WN; ++j) mma(acc[i][j], af[i][2], bf[j][2]);
+#pragma unroll
+                    for (int i = 0; i < WM; ++i)
+#pragma unroll
+                        for (int j = 0; j < WN; ++j) mma(acc[i][j], af[i][3], bf[j][3]);
+                    if (sb + 1 < NSUB || NEXT) {
+#pragma unroll
+                        for (int i = 0; i < WM; ++i)
+#pragma unroll
+                            for (int j = 0; j < WN; ++j) svcmi_pin(acc[i][j]);
+                        frags_arrive(a4[(sb + 1) & 1], b4[(sb + 1) & 1]);
+                    }
+                }
+            };
+            int it = it_beg, slot = 0;
+            auto advance = [&] { ++it; if (++slot == NST) slot = 0; };
+            auto nxt = [&] { return slot + 1 == NST ? 0 : slot + 1; };
+            for (; it + NST < it_end; advance()) step(it, slot, nxt(), std::true_type(), std::true_type());       // steady state
+            for (; it + 1 < it_end; advance()) step(it, slot, nxt(), std::true_type(), std::false_type());       // drain: nothing left to request
+            step(it, slot, nxt(), std::false_type(), std::false_type());                                          // last tile
+        }
+    } else {
         int it = it_beg, slot = 0;
         for (; it + NST - 1 < it_end; ++it) {             // steady state: NST-2 later tiles in flight
             k_step(it, slot, NST - 2, std::true_type());
