@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-5 validation at the final HEAD, ONE session: GPU test suite, smoke, the judged line (+ cpu_baseline), the other precisions / configs,
 # then rocprofv3 kernel stats of the single-stream run, PMC HBM traffic and MFMA / wave-state counters -- the files profiles/r05z_* come from.
-TAG=${1:-r05zz}
+TAG=${1:-r05zzz}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT; cd $ROOT; export TMPDIR=/tmp
 timeout 1800 python -m pytest tests -m gpu -q -x -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $OUT/pytest_gpu.log
 cp gpurun_out/precision_report.json $OUT/precision_report.json 2>/dev/null
