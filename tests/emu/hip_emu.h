@@ -234,7 +234,10 @@ static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((un
 #define SVCMI_ACQUIRE_AGENT() ((void)0)
 static inline int svcmi_ticket(int* counter) { return (*counter)++; }   // blocks run one after another in the emulator
 static inline void svcmi_lds_read16(svcmi_f32x4& dst, const float* p, svcmi_f32x4&) { memcpy(&dst, p, 16); }
+static inline void svcmi_lds_read16(svcmi_f32x4& dst, const float* p, svcmi_f32x4&, svcmi_f32x4&) { memcpy(&dst, p, 16); }
 static inline void svcmi_lds_arrive(svcmi_f32x4&) {}
+static inline void svcmi_lds_arrive(svcmi_f32x4&, svcmi_f32x4&) {}
+static inline void svcmi_lds_arrive(svcmi_f32x4&, svcmi_f32x4&, svcmi_f32x4&) {}
 static inline void svcmi_lds_landed(svcmi_f32x4&) {}
 static inline void svcmi_pin(svcmi_f32x16&) {}
 static inline void svcmi_pin(svcmi_f32x4&) {}
@@ -250,6 +253,9 @@ static inline void svcmi_bdma16(unsigned voff, float* lds_wave_base, svcmi_rsrc 
     float* dst = lds_wave_base + 4 * emu::cur_lane();
     if ((unsigned long long)voff + 16 <= r.bytes) memcpy(dst, r.base + voff, 16); else memset(dst, 0, 16);
 }
+static inline void svcmi_bdma16_at(unsigned voff, float* lds_wave_base, svcmi_rsrc r) { svcmi_bdma16(voff, lds_wave_base, r); }
+static inline void svcmi_bdma16_at(unsigned voff, float* lds_wave_base, svcmi_rsrc r, svcmi_f32x4&) { svcmi_bdma16(voff, lds_wave_base, r); }
+static inline void svcmi_bdma16_at(unsigned voff, float* lds_wave_base, svcmi_rsrc r, svcmi_f32x4&, svcmi_f32x4&) { svcmi_bdma16(voff, lds_wave_base, r); }
 static inline void svcmi_bdma4(unsigned voff, float* lds_wave_base, svcmi_rsrc r) {
     float* dst = lds_wave_base + emu::cur_lane();
     if ((unsigned long long)voff + 4 <= r.bytes) memcpy(dst, r.base + voff, 4); else memset(dst, 0, 4);

@@ -65,6 +65,17 @@ namespace {
 #ifndef SVCMI_GEMM_MIDBAR
 #define SVCMI_GEMM_MIDBAR 1
 #endif
+// Build switch of the mid-barrier loop's instruction placement ("SPREAD", round 5): 1 = every LDS fragment request and every LDS-DMA issue of
+// a K-step is pinned between two MFMAs by register ties (svcmi_lds_read16 / svcmi_bdma16_at name the A fragment the MFMAs consume), one
+// request per MFMA and the refill's DMA pieces spread over the last sub-step, so that no gap between consecutive matrix instructions holds
+// more issue slots than an MFMA covers (the ISA of the 64x80 tile: gaps of 23 / 15 / 27 / 14 instructions -> at most 11; an in-order wave
+// issues nothing to the matrix pipe inside such a gap).  0 = requests in front of a sub-step's MFMAs, the refill DMAs wherever the
+// scheduler leaves them.  Same MFMAs in the same order either way: bit-identical results.  conv_gemm.hip is built with its accumulators in
+// architectural registers (build.py FILE_FLAGS): with the ties in place the accumulator-file form rotates three accumulator tuples
+// through v_accvgpr copies at the top of every K-step.
+#ifndef SVCMI_GEMM_SPREAD
+#define SVCMI_GEMM_SPREAD 1
+#endif
 constexpr int BK = 32;
 enum { MODE_CHUNK = 0, MODE_VEC = 1, MODE_SCALAR = 2, MODE_CHUNK_RS = 3 };   // _RS: CHUNK with x_row_shift != 0
 
@@ -256,6 +267,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
     }
     const svcmi_ldsaddr lds_a = svcmi_lds_advance(svcmi_lds_addr(As0), wave * 8 * BK);
     const svcmi_ldsaddr lds_b = svcmi_lds_advance(svcmi_lds_addr(Bs0), wave * 8 * BK);
+    static_assert(WM <= 2, "the pinned placement names at most two A fragments");
     static_assert(!P16 || (MODE == MODE_CHUNK || MODE == MODE_VEC), "16x16x4 policy: vector gathers only");
 
     using acc_t = typename std::conditional<P16, svcmi_f32x4, svcmi_f32x16>::type;
@@ -287,7 +299,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
             a_koff = kk < p.ktot ? (unsigned)(tap_v * p.dil * p.ldx + ci_v) * ESZ : OOB;
         }
     };
-    auto stage_a = [&](int it, int buf, int i) {          // piece i of the A tile (X3A: i >= A_PER = the lo image)
+    auto stage_a = [&](int it, int buf, int i, auto&... tie) {          // piece i of the A tile (X3A: i >= A_PER = the lo image); tie: svcmi_bdma16_at
         if constexpr (X3A) {
             const int im = i >= A_PER, ii = i - im * A_PER;
             svcmi_bdma16(a_row[ii] + a_koff + (im ? (unsigned)p.ldx : 0u), svcmi_lds_advance(lds_a, (buf * NA + im) * BM * BK + 4 * ii * 8 * BK), xr);
@@ -310,13 +322,13 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
         } else if (MODE == MODE_CHUNK_RS) {               // fused np.repeat(x, 2, 0): rows are tin >> 1
             const int tin = a_tb[i] + tap_v * p.dil;
             const bool ok = (unsigned)tin < (unsigned)t_lim;
-            svcmi_bdma16(ok ? (unsigned)((tin >> p.rshift) * p.ldx + ci_v) * 4u : OOB, dst, xr);
+            svcmi_bdma16_at(ok ? (unsigned)((tin >> p.rshift) * p.ldx + ci_v) * 4u : OOB, dst, xr, tie...);
         } else {
-            svcmi_bdma16(a_row[i] + a_koff, dst, xr);
+            svcmi_bdma16_at(a_row[i] + a_koff, dst, xr, tie...);
         }
     };
-    auto stage_b = [&](int buf, int i) {                  // piece i of the B tile(s): i < B_PER hi (or fp32), then the lo image
-        if (i < B_PER) svcmi_bdma16(b_row[i] + b_koff, svcmi_lds_advance(lds_b, buf * NB * BTILE + 4 * i * 8 * BK), wr);
+    auto stage_b = [&](int buf, int i, auto&... tie) {                  // piece i of the B tile(s): i < B_PER hi (or fp32), then the lo image
+        if (i < B_PER) svcmi_bdma16_at(b_row[i] + b_koff, svcmi_lds_advance(lds_b, buf * NB * BTILE + 4 * i * 8 * BK), wr, tie...);
         else svcmi_bdma16(b_row[i - B_PER] + b_koff + (unsigned)p.ldw16 * 2u, svcmi_lds_advance(lds_b, (buf * NB + 1) * BTILE + 4 * (i - B_PER) * 8 * BK), wr);
     };
 
@@ -334,6 +346,14 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
         for (int i = 0; i < FA; ++i) svcmi_lds_read16(a4[i], Ab + (i / WM) * BM * BK + (i % WM) * FR * BK + pos, tie);
 #pragma unroll
         for (int j = 0; j < FB; ++j) svcmi_lds_read16(b4[j], Bb + (j / WN) * BTILE + (j % WN) * FR * BK + pos, tie);
+    };
+    // fragment request k of sub-step s (k < FA: the A fragments, then the B fragments) as ONE statement pinned by its ties (svcmi_lds_read16)
+    auto frag_src = [&](const float* Ab, const float* Bb, int s, int k) {
+        const int pos = ((((P16 ? 4 : 2) * s + fhi) ^ swz(frow)) << 2);
+        return k < FA ? Ab + (k / WM) * BM * BK + (k % WM) * FR * BK + pos : Bb + ((k - FA) / WN) * BTILE + ((k - FA) % WN) * FR * BK + pos;
+    };
+    auto load_frag_at = [&](const float* Ab, const float* Bb, int s, int k, svcmi_f32x4 (&a4)[FA], svcmi_f32x4 (&b4)[FB], auto&... tie) {
+        svcmi_lds_read16(k < FA ? a4[k < FA ? k : 0] : b4[k < FA ? 0 : k - FA], frag_src(Ab, Bb, s, k), tie...);
     };
     auto mma = [&](acc_t& c, float a, float b) {
         if constexpr (P16) c = svcmi_mfma_16x16x4(a, b, c);
@@ -399,6 +419,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
     // prologue: tiles it_beg .. it_beg+NST-2 into slots 0 .. NST-2
     // (the mid-barrier loop below -- fp32, MIDBAR -- fills ALL NST slots up front: it refills a slot right after the barrier that retires it)
     constexpr bool MIDBAR = SVCMI_GEMM_MIDBAR != 0 && !LP && !A16;
+    constexpr bool SPREAD = SVCMI_GEMM_SPREAD != 0 && MIDBAR && MODE != MODE_SCALAR;      // (the 4-byte gathers keep the plain placement)
 #pragma unroll
     for (int s0 = 0; s0 < (MIDBAR ? NST : NST - 1); ++s0) {
         if (it_beg + s0 < it_end) {
@@ -565,6 +586,79 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
                 constexpr bool NEXT = decltype(next_tag)::value, REFILL = decltype(refill_tag)::value;
                 const float* Ab = As0 + slot * NA * BM * BK + a_off;
                 const float* Bb = Bs0 + slot * NB * BTILE + b_off;
+                if constexpr (SPREAD) {
+                    // Pinned placement.  MFMA n of a sub-step is (c, i, j) = (n / (WM*WN), (n / WN) % WM, n % WN); a request "after MFMA n" names
+                    // the sub-step's A fragment(s) read-write: every MFMA consumes one of them, so the MFMAs issued before the statement
+                    // stay above it and the later ones below -- an exact position in the stream, at no cost in instructions or registers.
+                    // Fragment request k of the NEXT sub-step goes in front of MFMA k (k = 0: above the sub-step, as before); in the last
+                    // sub-step the refill's DMA pieces follow, spread evenly over the remaining MFMAs.  Nothing moves across the mid-step
+                    // barrier or across a wait: the requests of a barrier interval are the plain loop's, in the plain loop's order.
+                    constexpr int NACC = WM * WN, NM = 4 * NACC, NF = FA + FB;
+                    static_assert(NF <= NM, "one fragment request per MFMA");
+#pragma unroll
+                    for (int sb = 0; sb < NSUB; ++sb) {
+                        svcmi_f32x4(&af)[FA] = a4[sb & 1];
+                        svcmi_f32x4(&bf)[FB] = b4[sb & 1];
+                        svcmi_f32x4(&na)[FA] = a4[(sb + 1) & 1];
+                        svcmi_f32x4(&nb)[FB] = b4[(sb + 1) & 1];
+                        const bool last = sb + 1 == NSUB;
+                        const bool want = !last || NEXT;                          // fragments to request during this sub-step?
+                        const float* nAb = Ab;
+                        const float* nBb = Bb;
+                        int ns = sb + 1;
+                        if (last) {
+                            if constexpr (NEXT) {
+                                if constexpr (REFILL) {
+                                    wait_tiles(NST - 2);                     // steady state: tiles it+2 .. it+NST-1 may still be in flight
+                                } else {
+                                    const int lastt = it + NST - 1 < it_end - 1 ? it + NST - 1 : it_end - 1;      // newest tile issued
+                                    wait_tiles(lastt - (it + 1));
+                                }
+                                __syncthreads();         // tile it+1 has landed for every wave; every wave holds all of tile it in registers
+                                nAb = As0 + nslot * NA * BM * BK + a_off;
+                                nBb = Bs0 + nslot * NB * BTILE + b_off;
+                                ns = 0;
+                                if constexpr (REFILL) stage_prep(it + NST);
+                            }
+                        }
+                        if (want) svcmi_lds_read16(na[0], frag_src(nAb, nBb, ns, 0), af[0]);
+#pragma unroll
+                        for (int n = 0; n < NM; ++n) {
+                            const int c = n / NACC, i = (n / WN) % WM, j = n % WN;
+                            mma(acc[i][j], af[i][c], bf[j][c]);
+                            if (n + 1 < NM) {
+                                if (want && n + 1 < NF) {
+                                    if constexpr (WM == 1) load_frag_at(nAb, nBb, ns, n + 1, na, nb, af[0]);
+                                    else load_frag_at(nAb, nBb, ns, n + 1, na, nb, af[0], af[1]);
+                                }
+                                if constexpr (NEXT && REFILL) {
+                                    if (last) {
+#pragma unroll
+                                        for (int q = 0; q < PIECES; ++q) {
+                                            if ((NF - 1) + q * (NM - NF) / PIECES != n) continue;
+                                            if constexpr (WM == 1) {
+                                                if (q < APCS) stage_a(it + NST, slot, q, af[0]);
+                                                else stage_b(slot, q - APCS, af[0]);
+                                            } else {
+                                                if (q < APCS) stage_a(it + NST, slot, q, af[0], af[1]);
+                                                else stage_b(slot, q - APCS, af[0], af[1]);
+                                            }
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                        if (want) {             // one wait below this sub-step's MFMAs (they read af), every requested fragment pinned behind it
+                            if constexpr (WM == 1) svcmi_lds_arrive(na[0], af[0]);
+                            else svcmi_lds_arrive(na[0], af[0], af[1]);
+#pragma unroll
+                            for (int i = 1; i < FA; ++i) svcmi_lds_landed(na[i]);
+#pragma unroll
+                            for (int j = 0; j < FB; ++j) svcmi_lds_landed(nb[j]);
+                        }
+                    }
+                    return;
+                }
 #pragma unroll
                 for (int sb = 0; sb < NSUB; ++sb) {
                     svcmi_f32x4(&af)[FA] = a4[sb & 1];

@@ -135,6 +135,18 @@ __device__ __forceinline__ void svcmi_bdma16(unsigned voff, svcmi_ldsaddr lds_wa
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(lds_wave_base), "s"(rsrc) : "memory");
 }
+// The same DMA pinned inside an MFMA stream by register ties (svcmi_lds_read16: the A fragments the surrounding MFMAs consume)
+__device__ __forceinline__ void svcmi_bdma16_at(unsigned voff, svcmi_ldsaddr lds_wave_base, svcmi_rsrc rsrc, svcmi_f32x4& tie) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %4, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep), "+v"(tie) : "v"(voff), "s"(lds_wave_base), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ void svcmi_bdma16_at(unsigned voff, svcmi_ldsaddr lds_wave_base, svcmi_rsrc rsrc, svcmi_f32x4& tie, svcmi_f32x4& tie2) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %5, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep), "+v"(tie), "+v"(tie2) : "v"(voff), "s"(lds_wave_base), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ void svcmi_bdma16_at(unsigned voff, svcmi_ldsaddr lds_wave_base, svcmi_rsrc rsrc) { svcmi_bdma16(voff, lds_wave_base, rsrc); }
 __device__ __forceinline__ void svcmi_bdma4(unsigned voff, svcmi_ldsaddr lds_wave_base, svcmi_rsrc rsrc) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
@@ -159,14 +171,33 @@ __device__ __forceinline__ void svcmi_lds_read16(svcmi_f32x4& dst, const float* 
     const unsigned a = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)p;
     asm volatile("ds_read_b128 %0, %2" : "=v"(dst), "+v"(tie) : "v"(a) : "memory");
 }
+// Two ties (the 128-row tiles issue MFMAs on two A fragments): the statement sits below every earlier consumer of either register and
+// above every later one -- with both A fragments of a sub-step named, an exact position in its MFMA stream (conv_gemm_body.h, "SPREAD").
+__device__ __forceinline__ void svcmi_lds_read16(svcmi_f32x4& dst, const float* p, svcmi_f32x4& tie, svcmi_f32x4& tie2) {
+    const unsigned a = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)p;
+    asm volatile("ds_read_b128 %0, %3" : "=v"(dst), "+v"(tie), "+v"(tie2) : "v"(a) : "memory");
+}
 __device__ __forceinline__ void svcmi_lds_arrive(svcmi_f32x4& d) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d)::"memory"); }
+// ... with the register(s) the MFMAs of the running sub-step consume named too: they stay ABOVE the wait (they are earlier readers of a
+// register the statement rewrites), which is what the accumulator pins (svcmi_pin) do for the plain placement
+__device__ __forceinline__ void svcmi_lds_arrive(svcmi_f32x4& d, svcmi_f32x4& tie) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d), "+v"(tie)::"memory"); }
+__device__ __forceinline__ void svcmi_lds_arrive(svcmi_f32x4& d, svcmi_f32x4& tie, svcmi_f32x4& tie2) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d), "+v"(tie), "+v"(tie2)::"memory");
+}
 // The same ordering pin without the instruction: after ONE svcmi_lds_arrive every outstanding LDS read of the wave has landed, the
 // other fragment registers only need to be named so that no consumer floats above that wait.
 __device__ __forceinline__ void svcmi_lds_landed(svcmi_f32x4& d) { asm volatile("" : "+v"(d)::"memory"); }
 
 // Order fence for a register-only value: nothing that produces `v` is scheduled below, nothing that consumes it above.
+// (a translation unit built with -mllvm -amdgpu-mfma-vgpr-form=1 keeps its accumulators in architectural registers and says so with
+// -DSVCMI_ACC_IN_VGPRS=1: an "a" constraint there would cost a copy into the accumulator file and back at every pin -- build.py FILE_FLAGS)
+#ifdef SVCMI_ACC_IN_VGPRS
+__device__ __forceinline__ void svcmi_pin(svcmi_f32x16& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void svcmi_pin(svcmi_f32x4& v) { asm volatile("" : "+v"(v)); }
+#else
 __device__ __forceinline__ void svcmi_pin(svcmi_f32x16& v) { asm volatile("" : "+a"(v)); }   // "a": stays in the accumulator file
 __device__ __forceinline__ void svcmi_pin(svcmi_f32x4& v) { asm volatile("" : "+a"(v)); }
+#endif
 
 // Cross-workgroup hand-off inside one launch (cdna_hip_programming.md Guideline 16): agent-scope release by the
 // producer, a relaxed agent-scope ticket, agent-scope acquire by the consumer.  Workgroup scope is NOT enough.
