@@ -65,15 +65,14 @@ namespace {
 #ifndef SVCMI_GEMM_MIDBAR
 #define SVCMI_GEMM_MIDBAR 1
 #endif
-// Build switch of the mid-barrier loop's instruction placement ("SPREAD", round 5): 1 (default) = every LDS fragment request and every
-// LDS-DMA issue of a K-step is pinned between two MFMAs by register ties (svcmi_lds_read16 / svcmi_bdma16_at name the A fragment the MFMAs
-// consume), one request per MFMA and the refill's DMA pieces spread over the last sub-step, so that no gap between consecutive matrix
-// instructions holds more issue slots than an MFMA covers (the ISA of the 64x80 tile: gaps of 23 / 15 / 27 / 14 instructions -> at most 11;
-// an in-order wave issues nothing to the matrix pipe inside such a gap) -- on every tile but the 64x64 one (see SPREAD below); 2 = on that
-// tile too; 0 = requests in front of a sub-step's MFMAs, the refill DMAs wherever the scheduler leaves them.  Same MFMAs in the same order
-// in every form: bit-identical results (hardware: 307 launches of every tile / mode / ring depth / split, profiles/r05s_pinned_k_loop.log).
-// conv_gemm.hip is built with its accumulators in architectural registers (build.py FILE_FLAGS): with the ties in place the
-// accumulator-file form rotates three accumulator tuples through v_accvgpr copies at the top of every K-step.
+// Build switch of the mid-barrier loop's instruction placement ("SPREAD", round 5): 1 = every LDS fragment request and every LDS-DMA issue of
+// a K-step is pinned between two MFMAs by register ties (svcmi_lds_read16 / svcmi_bdma16_at name the A fragment the MFMAs consume), one
+// request per MFMA and the refill's DMA pieces spread over the last sub-step, so that no gap between consecutive matrix instructions holds
+// more issue slots than an MFMA covers (the ISA of the 64x80 tile: gaps of 23 / 15 / 27 / 14 instructions -> at most 11; an in-order wave
+// issues nothing to the matrix pipe inside such a gap).  0 = requests in front of a sub-step's MFMAs, the refill DMAs wherever the
+// scheduler leaves them.  Same MFMAs in the same order either way: bit-identical results.  conv_gemm.hip is built with its accumulators in
+// architectural registers (build.py FILE_FLAGS): with the ties in place the accumulator-file form rotates three accumulator tuples
+// through v_accvgpr copies at the top of every K-step.
 #ifndef SVCMI_GEMM_SPREAD
 #define SVCMI_GEMM_SPREAD 1
 #endif
@@ -420,10 +419,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
     // prologue: tiles it_beg .. it_beg+NST-2 into slots 0 .. NST-2
     // (the mid-barrier loop below -- fp32, MIDBAR -- fills ALL NST slots up front: it refills a slot right after the barrier that retires it)
     constexpr bool MIDBAR = SVCMI_GEMM_MIDBAR != 0 && !LP && !A16;
-    // (the 4-byte gathers keep the plain placement, and so does the 64x64 tile of the 32x32x2 policy: its sub-steps are FOUR matrix
-    // instructions long, a request issued behind the first of them has 192 instead of 256 cycles to land, and the launches that use it --
-    // QKV, the prior encoder / flow projections -- measured 1.5-3.5 % SLOWER pinned, profiles/r05s_pinned_k_loop.log)
-    constexpr bool SPREAD = (SVCMI_GEMM_SPREAD == 2 || (SVCMI_GEMM_SPREAD == 1 && (P16 || WM * WN > 1))) && MIDBAR && MODE != MODE_SCALAR;
+    constexpr bool SPREAD = SVCMI_GEMM_SPREAD != 0 && MIDBAR && MODE != MODE_SCALAR;      // (the 4-byte gathers keep the plain placement)
 #pragma unroll
     for (int s0 = 0; s0 < (MIDBAR ? NST : NST - 1); ++s0) {
         if (it_beg + s0 < it_end) {
