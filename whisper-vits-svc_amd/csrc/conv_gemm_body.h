@@ -61,15 +61,9 @@ namespace {
 
 // Build switch of the fp32 K loop: 1 (default since round 5: judged line 1429-1433 -> 1446-1447 audio-s/s, one clip alone 9.48 -> 9.41 ms,
 // profiles/r05p_midbar.log) = the mid-barrier pipeline (conv_gemm_body, "MIDBAR"), 0 = barrier at the top of every K-step (what the
-// 16-bit kernels with fp32 activations rounded in registers keep)
+// 16-bit kernels keep)
 #ifndef SVCMI_GEMM_MIDBAR
 #define SVCMI_GEMM_MIDBAR 1
-#endif
-// ... and of the 16-bit-ACTIVATION kernels (_A16: the fp32 kernel's tile geometry and data movement on 16-bit rows): 1 = the same mid-barrier
-// pipeline (plain placement), 0 = barrier at the top of every K-step.  Their K-step is 4-16 matrix instructions of 16-64 cycles, so the
-// exposed LDS round trip behind a top-of-step barrier weighs far more than in fp32.
-#ifndef SVCMI_GEMM_MIDBAR16
-#define SVCMI_GEMM_MIDBAR16 1
 #endif
 // Build switch of the mid-barrier loop's instruction placement ("SPREAD", round 5): 1 = every LDS fragment request and every LDS-DMA issue of
 // a K-step is pinned between two MFMAs by register ties (svcmi_lds_read16 / svcmi_bdma16_at name the A fragment the MFMAs consume), one
@@ -424,8 +418,8 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
     constexpr int DMAS = (MODE == MODE_SCALAR ? 4 * A_PER : APCS) + NB * B_PER;   // ... and the DMA instructions they take
     // prologue: tiles it_beg .. it_beg+NST-2 into slots 0 .. NST-2
     // (the mid-barrier loop below -- fp32, MIDBAR -- fills ALL NST slots up front: it refills a slot right after the barrier that retires it)
-    constexpr bool MIDBAR = !LP && (A16 ? SVCMI_GEMM_MIDBAR16 != 0 : SVCMI_GEMM_MIDBAR != 0);
-    constexpr bool SPREAD = SVCMI_GEMM_SPREAD != 0 && MIDBAR && !A16 && MODE != MODE_SCALAR;      // (the 4-byte gathers and the 16-bit kernels keep the plain placement)
+    constexpr bool MIDBAR = SVCMI_GEMM_MIDBAR != 0 && !LP && !A16;
+    constexpr bool SPREAD = SVCMI_GEMM_SPREAD != 0 && MIDBAR && MODE != MODE_SCALAR;      // (the 4-byte gathers keep the plain placement)
 #pragma unroll
     for (int s0 = 0; s0 < (MIDBAR ? NST : NST - 1); ++s0) {
         if (it_beg + s0 < it_end) {
@@ -689,51 +683,22 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
                             }
                         }
                     }
-                    if constexpr (X3A) {         // hi*hi + lo*hi + hi*lo; the lo fragments sit behind the hi ones (the products and their order: k_step)
 #pragma unroll
-                        for (int i = 0; i < WM; ++i)
+                    for (int i = 0; i < WM; ++i)
 #pragma unroll
-                            for (int j = 0; j < WN; ++j) mma16(acc[i][j], svcmi_as_u32x4(af[i]), svcmi_as_u32x4(bf[j]));
+                        for (int j = 0; j < WN; ++j) mma(acc[i][j], af[i][0], bf[j][0]);
 #pragma unroll
-                        for (int i = 0; i < WM; ++i)
+                    for (int i = 0; i < WM; ++i)
 #pragma unroll
-                            for (int j = 0; j < WN; ++j) mma16(acc[i][j], svcmi_as_u32x4(af[WM + i]), svcmi_as_u32x4(bf[j]));
+                        for (int j = 0; j < WN; ++j) mma(acc[i][j], af[i][1], bf[j][1]);
 #pragma unroll
-                        for (int i = 0; i < WM; ++i)
+                    for (int i = 0; i < WM; ++i)
 #pragma unroll
-                            for (int j = 0; j < WN; ++j) mma16(acc[i][j], svcmi_as_u32x4(af[i]), svcmi_as_u32x4(bf[WN + j]));
-                    } else if constexpr (W2A) {         // a*hi + a*lo
+                        for (int j = 0; j < WN; ++j) mma(acc[i][j], af[i][2], bf[j][2]);
 #pragma unroll
-                        for (int i = 0; i < WM; ++i)
+                    for (int i = 0; i < WM; ++i)
 #pragma unroll
-                            for (int j = 0; j < WN; ++j) mma16(acc[i][j], svcmi_as_u32x4(af[i]), svcmi_as_u32x4(bf[j]));
-#pragma unroll
-                        for (int i = 0; i < WM; ++i)
-#pragma unroll
-                            for (int j = 0; j < WN; ++j) mma16(acc[i][j], svcmi_as_u32x4(af[i]), svcmi_as_u32x4(bf[WN + j]));
-                    } else if constexpr (A16) {         // the fragment's 16 bytes are 8 consecutive 16-bit k: one MFMA per (i, j)
-#pragma unroll
-                        for (int i = 0; i < WM; ++i)
-#pragma unroll
-                            for (int j = 0; j < WN; ++j) mma16(acc[i][j], svcmi_as_u32x4(af[i]), svcmi_as_u32x4(bf[j]));
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < WM; ++i)
-#pragma unroll
-                            for (int j = 0; j < WN; ++j) mma(acc[i][j], af[i][0], bf[j][0]);
-#pragma unroll
-                        for (int i = 0; i < WM; ++i)
-#pragma unroll
-                            for (int j = 0; j < WN; ++j) mma(acc[i][j], af[i][1], bf[j][1]);
-#pragma unroll
-                        for (int i = 0; i < WM; ++i)
-#pragma unroll
-                            for (int j = 0; j < WN; ++j) mma(acc[i][j], af[i][2], bf[j][2]);
-#pragma unroll
-                        for (int i = 0; i < WM; ++i)
-#pragma unroll
-                            for (int j = 0; j < WN; ++j) mma(acc[i][j], af[i][3], bf[j][3]);
-                    }
+                        for (int j = 0; j < WN; ++j) mma(acc[i][j], af[i][3], bf[j][3]);
                     if (sb + 1 < NSUB || NEXT) {
 #pragma unroll
                         for (int i = 0; i < WM; ++i)
