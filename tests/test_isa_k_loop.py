@@ -3,7 +3,7 @@
 What the pinned placement of conv_gemm_body.h (SVCMI_GEMM_SPREAD) promises is a property of the INSTRUCTION STREAM: between two consecutive
 matrix instructions of a K-step there is never a longer run of other instructions than one MFMA can cover for long, and no accumulator is
 copied.  A compiler update or an innocent edit of the loop can silently undo that (round 5 saw both: 27-instruction clumps from the
-scheduler, accumulator tuples rotated through v_accvgpr copies by the register allocator) without changing a single result bit, so the stream itself is
+scheduler, 16 v_accvgpr copies per K-step from the register allocator) without changing a single result bit, so the stream itself is
 checked here.  Takes a few seconds; skipped where hipcc is absent."""
 import os
 import re
@@ -62,15 +62,13 @@ def asm(tmp_path_factory):
     return out.read_text()
 
 
-# (kernel, MFMAs per K-step, issue slots one MFMA covers: 32 / 64 cycles at one instruction per ~4 cycles, longest tolerated run, accumulator
-#  copies tolerated: in the accumulator-file form the five-accumulator tiles rotate three tuples at the top of the K-step -- 16 v_accvgpr
-#  copies in a 20-instruction run -- which measured FASTER than the copy-free architectural-register form, build.py; more than that is news)
-CASES = [("ILi1ELi5ELi0ELb1ELi0ELi0E", 40, 7, 21, 16), ("ILi1ELi5ELi0ELb1ELi0ELi2E", 40, 7, 21, 16),
-         ("ILi1ELi1ELi0ELb0ELi0ELi0E", 16, 15, 24, 0), ("ILi2ELi2ELi0ELb0ELi0ELi0E", 64, 15, 18, 0)]
+# (kernel, MFMAs per K-step, issue slots one MFMA covers: 32 / 64 cycles at one instruction per ~4 cycles, longest tolerated run)
+CASES = [("ILi1ELi5ELi0ELb1ELi0ELi0E", 40, 7, 14), ("ILi1ELi5ELi0ELb1ELi0ELi2E", 40, 7, 14),
+         ("ILi1ELi1ELi0ELb0ELi0ELi0E", 16, 15, 24), ("ILi2ELi2ELi0ELb0ELi0ELi0E", 64, 15, 18)]
 
 
-@pytest.mark.parametrize("kernel,n_mfma,slots,longest,copies", CASES, ids=["64x80", "64x80_ring2", "64x64", "128x128"])
-def test_k_loop_instruction_stream(asm, kernel, n_mfma, slots, longest, copies):
+@pytest.mark.parametrize("kernel,n_mfma,slots,longest", CASES, ids=["64x80", "64x80_ring2", "64x64", "128x128"])
+def test_k_loop_instruction_stream(asm, kernel, n_mfma, slots, longest):
     seg = _steady_loop(asm, kernel)
     seq = "".join("M" if s.startswith("v_mfma") else "x" for s in seg)
     assert seq.count("M") == n_mfma, "the steady K-step is one basic block holding every MFMA of the tile"
@@ -79,5 +77,5 @@ def test_k_loop_instruction_stream(asm, kernel, n_mfma, slots, longest, copies):
     assert max(gaps) <= longest, f"a run of {max(gaps)} non-MFMA instructions between two MFMAs (pinned placement lost?): {gaps}"
     overflow = sum(max(0, g - slots) for g in gaps)
     assert overflow * 4 <= 0.06 * n_mfma * (32 if slots == 7 else 64), f"issue-slot overflow {overflow} slots: {gaps}"
-    assert sum("accvgpr" in s for s in seg) <= copies, "accumulator copies inside the K loop"
+    assert not any("accvgpr" in s for s in seg), "accumulator copies inside the K loop"
     assert sum(s.startswith("s_barrier") for s in seg) == 1 and sum(s.startswith("buffer_load") for s in seg) >= 4

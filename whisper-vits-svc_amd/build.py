@@ -16,13 +16,12 @@ OUT = os.path.join(HERE, "svcmi", "libsvcmi.so")
 # Per-file compiler flags.  amp_fused.hip: MFMA accumulators in ARCHITECTURAL registers -- in snake_conv16_group_kernel they are dead
 # during the activation phase that sets the kernel's VGPR count, while accumulation registers come ON TOP of it in the unified file
 # (117 + 32 -> occupancy 3 instead of 4).  The file holds no other matrix-core kernel.
-# conv_gemm.hip (round 5, the pinned K loop of conv_gemm_body.h) keeps the DEFAULT accumulator-file form.  With the ties in place that form
-# rotates three accumulator tuples of the five-accumulator tiles through 16 v_accvgpr copies (+ s_nop 5) at the top of every K-step, and the
-# architectural-register form (-mllvm -amdgpu-mfma-vgpr-form=1 -DSVCMI_ACC_IN_VGPRS=1: nothing to rotate) was the first shipped build of the
-# pinned loop -- but measured side by side on one box it is 2-3 % SLOWER per launch on every M = 500 shape (QKV 54.4 vs 52.6 us, MLP-up 65.5
-# vs 63.9: source C then shares the VGPR banks with A and B), rotation included: profiles/r05w_acc_file_vs_vgpr.log.
-# scripts/build_variant.sh <name> with SVCMI_VARIANT_ACC_VGPR=1 rebuilds the other form.
-FILE_FLAGS = {"amp_fused.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+# conv_gemm.hip (round 5, the pinned K loop of conv_gemm_body.h): with the fragment requests and DMA issues tied into the MFMA stream the
+# accumulator-file form rotates three accumulator tuples through 16 v_accvgpr copies (+ s_nop 5) at the top of every K-step; in
+# architectural registers there is nothing to rotate and the unified register count is the same (92 / 123 against 100 / 124).
+# SVCMI_ACC_IN_VGPRS makes svcmi_pin name a "v" register there.  The 16-bit kernels (conv_gemm_lp.hip) keep the accumulator file.
+FILE_FLAGS = {"amp_fused.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+              "conv_gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-DSVCMI_ACC_IN_VGPRS=1"]}
 
 
 def sources():

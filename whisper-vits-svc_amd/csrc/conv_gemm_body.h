@@ -70,9 +70,9 @@ namespace {
 // request per MFMA and the refill's DMA pieces spread over the last sub-step, so that no gap between consecutive matrix instructions holds
 // more issue slots than an MFMA covers (the ISA of the 64x80 tile: gaps of 23 / 15 / 27 / 14 instructions -> at most 11; an in-order wave
 // issues nothing to the matrix pipe inside such a gap).  0 = requests in front of a sub-step's MFMAs, the refill DMAs wherever the
-// scheduler leaves them.  Same MFMAs in the same order either way: bit-identical results.  (With the ties in place the register allocator
-// renames three accumulator tuples of the five-accumulator tiles inside the K-step and rotates them back through 16 v_accvgpr copies at its
-// top; building the file with its accumulators in architectural registers avoids that and measured 2-3 % slower all the same: build.py.)
+// scheduler leaves them.  Same MFMAs in the same order either way: bit-identical results.  conv_gemm.hip is built with its accumulators in
+// architectural registers (build.py FILE_FLAGS): with the ties in place the accumulator-file form rotates three accumulator tuples
+// through v_accvgpr copies at the top of every K-step.
 #ifndef SVCMI_GEMM_SPREAD
 #define SVCMI_GEMM_SPREAD 1
 #endif
