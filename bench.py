@@ -607,6 +607,26 @@ def main():
         run = wl.step
     elapsed = timed(run, lanes.synchronize if lanes is not None else torch.cuda.synchronize, args.steps, args.warmup)
     ms_per_step = 1000.0 * elapsed / args.steps
+    if os.environ.get("SVCMI_KTRACE_CLOCK"):       # timing-probe library (-DSVCMI_PROBE_KTRACE=1) only: the shader clock the GEMM K loops see in THIS launch regime
+        import ctypes
+        plib = ctypes.CDLL(os.environ["SVCMI_LIB"])
+        cal = (ctypes.c_ulonglong * (16 * 8192 + 8))()
+        ghz = []
+        for _ in range(8):
+            run()
+            (lanes.synchronize if lanes is not None else torch.cuda.synchronize)()
+            torch.cuda.synchronize()
+            plib.svcmi_probe_ktrace_read(cal, 16 * 8192 + 8)
+            import numpy as np
+            a = np.frombuffer(cal, dtype=np.uint64)[:16 * 512].reshape(512, 4, 4).astype(np.float64)
+            ok = a[..., 3] > 0
+            c = cal[16 * 8192:]
+            ghz.append({"GHz": round(c[0] / max(c[1], 1) / 10.0, 3), "loop_ticks": int(c[0]), "prologue": int(c[2]), "epilogue": int(c[3]), "launches": int(c[4]), "tail_ksteps": int(c[5]), "acc_to_lds": int(c[6]), "epi_loop": int(c[7]), "store_drain": int(c[3]) - int(c[5]) - int(c[6]) - int(c[7]),
+                        "ticks_per_kstep_512blocks": round(float((a[..., 0][ok] / a[..., 3][ok]).mean()), 0) if ok.any() else None, "ksteps": float(a[..., 3][ok].mean()) if ok.any() else None,
+                        "barrier": round(float((a[..., 2][ok] / (a[..., 3][ok] + 1)).mean()), 0) if ok.any() else None, "vmwait": round(float((a[..., 1][ok] / (a[..., 3][ok] + 1)).mean()), 0) if ok.any() else None})
+        for g in ghz:
+            log(f"ktrace sample: {g}")
+        log(f"ms_per_step {ms_per_step:.3f}")
     audio_s = wl.total_audio_seconds if wl.scaling == "strong" else wl.audio_seconds_per_step * world
     value = audio_s / (ms_per_step / 1000.0)
     def spell(p):

@@ -139,6 +139,34 @@ def main():
         gemm(ops, "whisper_mlp1", 500, 1280, 5120, tiles=(1, 2, 3), splits=(1,))
         gemm(ops, "whisper_mlp2", 500, 5120, 1280, res=True, tiles=(1, 3), splits=(8, 1))
         gemm(ops, "square4096", 4096, 4096, 4096, tiles=(1, 2, 3), splits=(1,))
+    if "ktrace" in what:      # SVCMI_LIB = a -DSVCMI_PROBE_KTRACE=1 build: where the cycles of a K-step go, per wave (s_memtime sums)
+        import ctypes
+        import numpy as np
+        lib = ctypes.CDLL(os.environ["SVCMI_LIB"])
+        for (tag, T, cin, n, tile, blocks) in (("mlp1", 500, 1280, 5120, 6, 512), ("mlp1_K2560", 500, 2560, 5120, 6, 512), ("qkv", 500, 1280, 3840, 1, 480),
+                                               ("mlp1_128x80", 500, 1280, 5120, 7, 256), ("sq4096_128x128", 4096, 4096, 4096, 3, 1024)):
+            gemm(ops, tag, T, cin, n, tiles=(tile,), splits=(1,))
+            torch.cuda.synchronize()
+            cal = (ctypes.c_ulonglong * (16 * 8192 + 2))()
+            assert lib.svcmi_probe_ktrace_read(cal, 16 * 8192 + 2) == 0
+            print(f"  s_memtime {cal[16 * 8192]} ticks in {cal[16 * 8192 + 1] / 100.0:.1f} us of s_memrealtime -> {cal[16 * 8192] / max(cal[16 * 8192 + 1], 1) / 10.0:.3f} GHz")
+            buf = (ctypes.c_ulonglong * (16 * blocks))()
+            assert lib.svcmi_probe_ktrace_read(buf, 16 * blocks) == 0
+            a = np.frombuffer(buf, dtype=np.uint64).reshape(blocks, 4, 4).astype(np.float64)
+            nst = a[..., 3]
+            ok = nst > 0
+            step, vm, bar = a[..., 0][ok] / nst[ok], a[..., 1][ok] / (nst[ok] + 1), a[..., 2][ok] / (nst[ok] + 1)
+            print(f"  ktrace {tag}: K-steps per wave {nst[ok].mean():.0f}; cycles per K-step {step.mean():.0f} (min {step.min():.0f}, max {step.max():.0f});"
+                  f" in the DMA wait {vm.mean():.0f} (max over waves {vm.max():.0f}); in the barrier {bar.mean():.0f} (min {bar.min():.0f}, max {bar.max():.0f})", flush=True)
+            for w in range(4):
+                okw = ok[:, w]
+                print(f"    wave {w}: step {(a[:, w, 0][okw] / nst[:, w][okw]).mean():.0f}  vmwait {(a[:, w, 1][okw] / (nst[:, w][okw] + 1)).mean():.0f}  barrier {(a[:, w, 2][okw] / (nst[:, w][okw] + 1)).mean():.0f}")
+    if "kprobe" in what:      # K-loop timing probes (build_variant.sh -DSVCMI_PROBE_*): the same launches on every variant library
+        for cin in (640, 1280, 2560):
+            gemm(ops, "mlp1_K", 500, cin, 5120, tiles=(6, 7, 3), splits=(1,))
+        for cin in (640, 1280, 2560):
+            gemm(ops, "qkv_K", 500, cin, 3840, tiles=(1, 2, 3), splits=(1,))
+        gemm(ops, "square4096", 4096, 4096, 4096, tiles=(3, 6), splits=(1,))
     if "kscale" in what:      # fixed overhead vs per-K-step cost of the Whisper tiles: time against K at constant M x N
         for cin in (320, 640, 1280, 2560, 5120):
             gemm(ops, "mlp1_K", 500, cin, 5120, tiles=(6,), splits=(1,))

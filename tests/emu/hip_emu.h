@@ -263,6 +263,17 @@ static inline void svcmi_bdma4(unsigned voff, float* lds_wave_base, svcmi_rsrc r
 static inline void svcmi_dma_wait() {}
 template <int N>
 static inline void svcmi_dma_wait_n() {}
+// range-checked plain buffer accesses (svcmi_rt.h): out-of-range lanes load zeros / store nothing
+typedef svcmi_rsrc svcmi_brsrc;
+static inline svcmi_brsrc svcmi_make_brsrc(const void* base, unsigned bytes) { return svcmi_rsrc{(const char*)base, bytes}; }
+static inline svcmi_f32x4 svcmi_buf_load16(svcmi_brsrc r, unsigned byte_off) {
+    svcmi_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned long long)byte_off + 16 <= r.bytes) memcpy(&v, r.base + byte_off, 16);
+    return v;
+}
+static inline void svcmi_buf_store16(svcmi_f32x4 v, svcmi_brsrc r, unsigned byte_off) {
+    if ((unsigned long long)byte_off + 16 <= r.bytes) memcpy(const_cast<char*>(r.base) + byte_off, &v, 16);
+}
 static inline void svcmi_store16_sc1(svcmi_f32x4 v, svcmi_rsrc r, unsigned byte_off) {
     if ((unsigned long long)byte_off + 16 <= r.bytes) memcpy(const_cast<char*>(r.base) + byte_off, &v, 16);
 }

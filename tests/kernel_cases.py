@@ -5,6 +5,7 @@ runs the kernel through ``ops`` (C ABI) on ``device`` and compares.  Tolerances 
 class (different summation orders), stated per check.
 """
 import math
+import zlib
 
 import numpy as np
 import torch
@@ -125,7 +126,7 @@ def check_conv(ops, c, device):
     B, T, cin, n, k = c["B"], c["T"], c["cin"], c["n"], c["k"]
     stride, dil, pad = c.get("stride", 1), c.get("dil", 1), c.get("pad", 0)
     act = c.get("act", ACT_NONE)
-    g = _g(hash(c["id"]) % 10000)
+    g = _g(zlib.crc32(c["id"].encode()) % 10000)
     rep = c.get("repeat", False)
     t_phys = T // 2 if rep else T
     x = torch.randn(B, t_phys, cin, generator=g) * c.get("xscale", 1.0)
@@ -545,7 +546,7 @@ UPNOISE_CASES = [
 
 def check_upsample_noise(ops, c_, device):
     """ups[i] (ConvTranspose1d) + noise_convs[i] (strided Conv1d on the source) in one launch vs torch."""
-    g = _g(hash(c_["id"]) % 10000)
+    g = _g(zlib.crc32(c_["id"].encode()) % 10000)
     cin, cout, k, u, pp, T, B = c_["cin"], c_["cout"], c_["k"], c_["u"], c_["p"], c_["T"], c_["B"]
     cp = (cout + 3) // 4 * 4
     x = torch.randn(B, T, cin, generator=g)
@@ -585,7 +586,7 @@ SNAKE_CONV_CASES = [
 
 def check_snake_conv(ops, c_, device):
     """Fused SnakeAlias -> conv half-step vs oracle SnakeAlias + torch conv1d."""
-    g = _g(hash(c_["id"]) % 10000)
+    g = _g(zlib.crc32(c_["id"].encode()) % 10000)
     B, n, c, ld, k, d = c_["B"], c_["n"], c_["c"], c_["ld"], c_["k"], c_["d"]
     x = torch.zeros(B, n, ld)
     x[..., :c] = torch.randn(B, n, c, generator=g) * 1.5

@@ -27,7 +27,9 @@ def _file_flags():
 
 
 def _steady_loop(asm, kernel_substr):
-    """Instructions of the loop with the most MFMAs inside the kernel whose mangled name contains `kernel_substr`."""
+    """Instructions of the loop with the most MFMAs inside the kernel whose mangled name contains `kernel_substr` (tightest such loop that
+    issues a whole tile of LDS-DMAs: the drain loop holds as many MFMAs and no DMA, and a backward branch of the prologue can enclose a
+    straight-line K-step)."""
     src = asm.split("\n")
     start = next(i for i, l in enumerate(src) if re.match(r"^_Z\w+:", l) and kernel_substr in l)
     end = next(i for i in range(start + 1, len(src)) if src[i].startswith(".Lfunc_end"))
@@ -38,7 +40,7 @@ def _steady_loop(asm, kernel_substr):
         m = re.search(r"s_cbranch_\w+\s+(\.LBB\d+_\d+)", l)
         if m and labels.get(m.group(1), i) < i:
             seg = body[labels[m.group(1)]:i + 1]
-            n = sum("v_mfma" in s for s in seg)
+            n = (sum("v_mfma" in s for s in seg), sum(s.strip().startswith("buffer_load") for s in seg) >= 4, -len(seg))
             if best is None or n > best[0]:
                 best = (n, seg)
     seg = [s.split(";")[0].strip() for s in best[1]]
@@ -79,3 +81,20 @@ def test_k_loop_instruction_stream(asm, kernel, n_mfma, slots, longest):
     assert overflow * 4 <= 0.06 * n_mfma * (32 if slots == 7 else 64), f"issue-slot overflow {overflow} slots: {gaps}"
     assert not any("accvgpr" in s for s in seg), "accumulator copies inside the K loop"
     assert sum(s.startswith("s_barrier") for s in seg) == 1 and sum(s.startswith("buffer_load") for s in seg) >= 4
+
+
+def test_nothing_but_the_dma_statements_touches_m0(tmp_path):
+    """build.py compiles conv_gemm.hip with SVCMI_DMA_M0_RAW: its LDS-DMA statements write M0 without saving / restoring it, which is sound
+    only while the compiler itself never reads or writes M0 in this translation unit (hipcc reserves the register and cannot be told).
+    Checked on the assembly of the WHOLE file: every mention of m0 is the destination of an `s_mov_b32 m0, s<N>` of our own statement."""
+    out = tmp_path / "conv_gemm.s"
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", os.path.join(CSRC, "conv_gemm.hip"), "-o", str(out)] + _file_flags()
+    assert "-DSVCMI_DMA_M0_RAW=1" in cmd
+    subprocess.run(cmd, check=True, capture_output=True)
+    lines = [l.split(";")[0].strip() for l in out.read_text().split("\n")]
+    m0 = [l for l in lines if re.search(r"\bm0\b", l) and not l.startswith(".")]
+    assert len(m0) > 100, "the LDS-DMA statements are gone?"
+    bad = [l for l in m0 if not re.fullmatch(r"s_mov_b32 m0, s\d+", l)]
+    assert not bad, f"M0 used outside the DMA statements: {bad[:5]}"
+    dma = [i for i, l in enumerate(lines) if l.startswith("buffer_load_dword") and l.endswith("lds")]
+    assert dma and all(any(re.fullmatch(r"s_mov_b32 m0, s\d+", lines[j]) for j in range(max(0, i - 3), i)) for i in dma), "an LDS-DMA without its own M0 write"

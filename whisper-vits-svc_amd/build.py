@@ -20,8 +20,11 @@ OUT = os.path.join(HERE, "svcmi", "libsvcmi.so")
 # accumulator-file form rotates three accumulator tuples through 16 v_accvgpr copies (+ s_nop 5) at the top of every K-step; in
 # architectural registers there is nothing to rotate and the unified register count is the same (92 / 123 against 100 / 124).
 # SVCMI_ACC_IN_VGPRS makes svcmi_pin name a "v" register there.  The 16-bit kernels (conv_gemm_lp.hip) keep the accumulator file.
+# SVCMI_DMA_M0_RAW (round 6, conv_gemm.hip only): the LDS-DMA statements set M0 without saving / restoring it (2 scalar moves less per
+# 1-KiB piece).  hipcc reserves M0 and rejects an "m0" clobber, so this is sound only where the compiler itself never uses M0:
+# tests/test_isa_k_loop.py checks the assembly of this translation unit for exactly that.
 FILE_FLAGS = {"amp_fused.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
-              "conv_gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-DSVCMI_ACC_IN_VGPRS=1"]}
+              "conv_gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-DSVCMI_ACC_IN_VGPRS=1", "-DSVCMI_DMA_M0_RAW=1"]}
 
 
 def sources():

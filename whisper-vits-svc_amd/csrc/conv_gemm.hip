@@ -113,3 +113,10 @@ extern "C" int svcmi_conv_tune_set(const char* name, int32_t value) {
     if (k[i] == 0 && name[i] == 0 && (value == 0 || value == 2 || value == 3)) { g_group_nst = value; return 0; }
     return SVCMI_EINVAL;
 }
+
+#if SVCMI_PROBE_KTRACE
+// timing-probe builds only (conv_gemm_body.h, SVCMI_PROBE_KTRACE): the per-wave K-loop cycle sums of the LAST fp32 launch
+extern "C" int svcmi_probe_ktrace_read(unsigned long long* dst, int n) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_ktrace), (size_t)n * 8, 0, hipMemcpyDeviceToHost);
+}
+#endif

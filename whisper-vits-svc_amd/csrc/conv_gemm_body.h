@@ -76,6 +76,32 @@ namespace {
 #ifndef SVCMI_GEMM_SPREAD
 #define SVCMI_GEMM_SPREAD 1
 #endif
+#ifndef SVCMI_PROBE_NOMFMA      // timing probe (svcmi_rt.h): the K loop without its matrix instructions
+#define SVCMI_PROBE_NOMFMA 0
+#endif
+// Timing probe (scripts/build_variant.sh ktrace -DSVCMI_PROBE_KTRACE=1; never in the product build): every wave of the mid-barrier K loop
+// stamps s_memtime before the DMA wait, after it and after the barrier, sums the differences in scalar registers and leaves
+// {cycles between barrier exits, cycles in the vmcnt wait, cycles in the barrier, K-steps} in g_ktrace[4 * (block * 4 + wave)]
+// (read back with svcmi_probe_ktrace_read, scripts/microbench.py ktrace).
+#ifndef SVCMI_PROBE_KTRACE
+#define SVCMI_PROBE_KTRACE 0
+#endif
+#if SVCMI_PROBE_KTRACE
+#ifndef SVCMI_PROBE_KTRACE_N      // record only launches with this n_out (0 = every launch: the last one stays)
+#define SVCMI_PROBE_KTRACE_N 0
+#endif
+__device__ unsigned long long g_ktrace[4 * 4 * 8192 + 8];      // + block 0 wave 0: {loop s_memtime ticks, loop s_memrealtime ticks (100 MHz), entry -> first barrier exit, last barrier exit -> end of the epilogue, launches recorded}
+#endif
+// Build switch (round 6): the refill's DMA pieces of the pinned loop spread over a WHOLE K-step instead of its last sub-step -- the first half
+// behind the mid-step barrier of K-step it (as before), the second half between the MFMAs of K-step it+1's earlier sub-steps (the slot is
+// free from that barrier on and its tile is not needed before the mid-step barrier of K-step it+NST-1, so this needs a ring of >= 3 tiles).
+// Measured (profiles/r06a_kprobe.log): the K-step of the 64x80 tile costs 2500 cycles without its DMA issues and 3070 with them, while
+// bare MFMA streams with the same number of evenly spaced pieces lose a third of that (scripts/probes/dma_issue_cost.hip).
+// Default since round 6: bit-identical over 307 launches on hardware (scripts/spread_check.py, profiles/r06f_spread2_m0raw.log); one clip
+// alone 9.31 -> 9.20 ms together with the raw-M0 DMA issue (svcmi_rt.h), the judged line +0.3 % (its MLP GEMMs run the 2-deep ring).
+#ifndef SVCMI_GEMM_SPREAD2
+#define SVCMI_GEMM_SPREAD2 1
+#endif
 constexpr int BK = 32;
 enum { MODE_CHUNK = 0, MODE_VEC = 1, MODE_SCALAR = 2, MODE_CHUNK_RS = 3 };   // _RS: CHUNK with x_row_shift != 0
 
@@ -115,7 +141,7 @@ struct ConvArgs {
 __device__ __forceinline__ float act_apply(float v, int act) {
     switch (act) {
         case SVCMI_ACT_RELU: return v > 0.f ? v : 0.f;
-        case SVCMI_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+        case SVCMI_ACT_GELU: return svcmi_gelu(v);
         case SVCMI_ACT_MISH: {   // x * tanh(softplus(x)), softplus with torch's threshold 20
             float sp = v > 20.f ? v : log1pf(expf(v));
             return v * tanhf(sp);
@@ -133,27 +159,6 @@ __device__ __forceinline__ float epilogue(const ConvArgs& p, float v, float bias
     v *= p.alpha;
     if (p.flags & SVCMI_CONV_ACCUMULATE) v += *dst;
     return masked ? 0.f : v;
-}
-
-// four consecutive output channels at once: the same arithmetic per component as `epilogue`, 16-byte accesses (the scalar loop
-// spent 5-9 us of a 53-73 us Whisper launch issuing 4-byte loads and stores: scripts/microbench.py ablation)
-__device__ __forceinline__ void epilogue4(const ConvArgs& p, float4 v, const float* bias_n, const float* res_n, float* dst, bool masked,
-                                          unsigned short* dst16 = nullptr) {
-    float o[4] = {v.x, v.y, v.z, v.w};
-    float bv[4] = {0.f, 0.f, 0.f, 0.f}, rv[4] = {0.f, 0.f, 0.f, 0.f}, yo[4] = {0.f, 0.f, 0.f, 0.f};
-    if (bias_n) { const float4 t = *reinterpret_cast<const float4*>(bias_n); bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w; }
-    if (res_n) { const float4 t = *reinterpret_cast<const float4*>(res_n); rv[0] = t.x; rv[1] = t.y; rv[2] = t.z; rv[3] = t.w; }
-    if (p.flags & SVCMI_CONV_ACCUMULATE) { const float4 t = *reinterpret_cast<const float4*>(dst); yo[0] = t.x; yo[1] = t.y; yo[2] = t.z; yo[3] = t.w; }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        float q = act_apply(o[e] + bv[e], p.act);
-        if (res_n) q += rv[e];
-        q *= p.alpha;
-        if (p.flags & SVCMI_CONV_ACCUMULATE) q += yo[e];
-        o[e] = masked ? 0.f : q;
-    }
-    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-    if (dst16) svcmi_store4_16(dst16, p.ldy16 >> 1, o[0], o[1], o[2], o[3], p.y16_f16);          // 8-byte aligned: n % 4 == 0, ldy16 % 4 == 0
 }
 
 __device__ __forceinline__ int div_magic(int q, unsigned magic) {   // q / c_in, exact while q * c_in < 2^32
@@ -202,10 +207,17 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
     constexpr int NST = NSTO ? NSTO : (X3A || (W2A && P16)) ? 2 : (LP ? 3 : (P16 ? ((BM + BNL) > 192 ? 2 : 3) : ((WM * WN == 1) ? 3 : (WM * WN == 2 ? 3 : 2))));
     constexpr int RING = NST * (NA * BM * BK + NB * BTILE);
     static_assert(LP || A16 || BM * CLD <= RING, "C tile must fit in the operand buffers");
-    __shared__ __attribute__((aligned(16))) float smem[(RING > BM * CLD ? RING : BM * CLD) + 4];   // + the split-K ticket word
+    // + the split-K ticket word (4 floats) + the tile's bias values (round 6: one 4-byte LDS-DMA per 64 columns in front of the first
+    // operand tile -- the epilogue reads them from LDS instead of waiting for a global load per iteration; no bias = all lanes out of range = zeros)
+    constexpr int BIAS0 = (RING > BM * CLD ? RING : BM * CLD) + 4, BIASN = (BN + 63) / 64 * 64;
+    __shared__ __attribute__((aligned(16))) float smem[BIAS0 + BIASN];
     float* const As0 = smem;                          // As[slot][image] = As0 + (slot*NA + image)*BM*BK, rows of 32 floats, chunk-swizzled
     float* const Bs0 = smem + NST * NA * BM * BK;          // Bs[slot][image] = Bs0 + (slot*NB + image)*BTILE
 
+#if SVCMI_PROBE_KTRACE
+    unsigned long long kt_entry;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(kt_entry));
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = SVCMI_UNIFORM((int)(tid >> 6));
     const int wm = P16 ? wave : (wave >> 1), wn = P16 ? 0 : (wave & 1);
@@ -356,6 +368,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
         svcmi_lds_read16(k < FA ? a4[k < FA ? k : 0] : b4[k < FA ? 0 : k - FA], frag_src(Ab, Bb, s, k), tie...);
     };
     auto mma = [&](acc_t& c, float a, float b) {
+        if (SVCMI_PROBE_NOMFMA) return;
         if constexpr (P16) c = svcmi_mfma_16x16x4(a, b, c);
         else c = svcmi_mfma_32x32x2(a, b, c);
     };
@@ -420,6 +433,11 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
     // (the mid-barrier loop below -- fp32, MIDBAR -- fills ALL NST slots up front: it refills a slot right after the barrier that retires it)
     constexpr bool MIDBAR = SVCMI_GEMM_MIDBAR != 0 && !LP && !A16;
     constexpr bool SPREAD = SVCMI_GEMM_SPREAD != 0 && MIDBAR && MODE != MODE_SCALAR;      // (the 4-byte gathers keep the plain placement)
+    if (wave < BIASN / 64) {        // (the oldest DMA of the wave: every counted wait below covers it)
+        const int n = n0 + 64 * wave + lane;
+        const svcmi_rsrc br = svcmi_make_rsrc(p.bias, p.bias ? (unsigned)p.n_out * 4u : 0u);
+        svcmi_bdma4(p.bias && n < p.n_out ? (unsigned)n * 4u : OOB, svcmi_lds_advance(svcmi_lds_addr(smem + BIAS0), 64 * wave), br);
+    }
 #pragma unroll
     for (int s0 = 0; s0 < (MIDBAR ? NST : NST - 1); ++s0) {
         if (it_beg + s0 < it_end) {
@@ -558,6 +576,9 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
             }
         }
     };
+#if SVCMI_PROBE_KTRACE
+    unsigned long long kt0 = 0, kt1 = 0, kt2 = 0, kt_prev = 0, kt_step = 0, kt_vm = 0, kt_bar = 0, kt_n = 0, kt_r0 = 0, kt_r1 = 0, kt_first = 0;
+#endif
     if constexpr (MIDBAR) {
         // Mid-barrier pipeline (round 5).  The loop above opens every K-step with [wait DMA, barrier, fragment reads of sub-step 0,
         // s_waitcnt lgkmcnt(0)]: an exposed LDS round trip per K-step in which the wave issues no MFMA (the ISA of the 64x80 tile: 6
@@ -570,6 +591,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
             if (k <= 0) svcmi_dma_wait_n<0>();
             else if (k == 1) svcmi_dma_wait_n<DMAS>();
             else svcmi_dma_wait_n<(NST >= 3 ? 2 : 1) * DMAS>();
+            static_assert(NST <= 4, "wait_tiles counts at most two later tiles (steady state: NST - 2)");
         };
         if (it_beg < it_end) {
             svcmi_f32x4 a4[2][FA], b4[2][FB];
@@ -582,8 +604,10 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
                 frags_arrive(a4[0], b4[0]);
             }
             // one K-step; NEXT / REFILL are compile-time so that the steady state is ONE basic block (three loops below: steady, drain, last)
-            auto step = [&](int it, int slot, int nslot, auto next_tag, auto refill_tag) {
+            constexpr bool SPREAD2 = SVCMI_GEMM_SPREAD2 != 0 && SPREAD && NST >= 3 && NSUB >= 2;
+            auto step = [&](int it, int slot, int nslot, auto next_tag, auto refill_tag, auto prev_tag) {
                 constexpr bool NEXT = decltype(next_tag)::value, REFILL = decltype(refill_tag)::value;
+                constexpr bool PREV = decltype(prev_tag)::value && SPREAD2;      // the previous K-step issued the first half of a refill: its second half goes here
                 const float* Ab = As0 + slot * NA * BM * BK + a_off;
                 const float* Bb = Bs0 + slot * NB * BTILE + b_off;
                 if constexpr (SPREAD) {
@@ -594,7 +618,11 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
                     // sub-step the refill's DMA pieces follow, spread evenly over the remaining MFMAs.  Nothing moves across the mid-step
                     // barrier or across a wait: the requests of a barrier interval are the plain loop's, in the plain loop's order.
                     constexpr int NACC = WM * WN, NM = 4 * NACC, NF = FA + FB;
-                    static_assert(NF <= NM, "one fragment request per MFMA");
+                    static_assert(NF < NM, "one fragment request per MFMA, and room for the refill behind them");
+                    static_assert(NSUB % 2 == 0, "a4 / b4 are double-buffered across K-steps by sub-step parity");
+                    constexpr int P1 = SPREAD2 ? PIECES / 2 : PIECES;            // pieces issued behind the mid-step barrier; the rest one K-step later
+                    constexpr int EARLY = (NSUB - 1) * NM;                      // MFMAs of the sub-steps in front of the barrier
+                    const int pslot = slot == 0 ? NST - 1 : slot - 1;          // the slot the previous K-step retired
 #pragma unroll
                     for (int sb = 0; sb < NSUB; ++sb) {
                         svcmi_f32x4(&af)[FA] = a4[sb & 1];
@@ -608,13 +636,22 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
                         int ns = sb + 1;
                         if (last) {
                             if constexpr (NEXT) {
+#if SVCMI_PROBE_KTRACE
+                                asm volatile("s_memtime %0" : "=s"(kt0));
+#endif
                                 if constexpr (REFILL) {
                                     wait_tiles(NST - 2);                     // steady state: tiles it+2 .. it+NST-1 may still be in flight
                                 } else {
                                     const int lastt = it + NST - 1 < it_end - 1 ? it + NST - 1 : it_end - 1;      // newest tile issued
                                     wait_tiles(lastt - (it + 1));
                                 }
+#if SVCMI_PROBE_KTRACE
+                                asm volatile("s_memtime %0" : "=s"(kt1));
+#endif
                                 __syncthreads();         // tile it+1 has landed for every wave; every wave holds all of tile it in registers
+#if SVCMI_PROBE_KTRACE
+                                asm volatile("s_memtime %0\n\ts_memrealtime %1" : "=s"(kt2), "=s"(kt_r1));
+#endif
                                 nAb = As0 + nslot * NA * BM * BK + a_off;
                                 nBb = Bs0 + nslot * NB * BTILE + b_off;
                                 ns = 0;
@@ -631,11 +668,27 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
                                     if constexpr (WM == 1) load_frag_at(nAb, nBb, ns, n + 1, na, nb, af[0]);
                                     else load_frag_at(nAb, nBb, ns, n + 1, na, nb, af[0], af[1]);
                                 }
+                                if constexpr (PREV) {
+                                    if (!last) {
+#pragma unroll
+                                        for (int q = P1; q < PIECES; ++q) {
+                                            const int g = ((2 * (q - P1) + 1) * EARLY) / (2 * (PIECES - P1));
+                                            if (g / NM != sb || (g % NM < NM - 1 ? g % NM : NM - 2) != n) continue;
+                                            if constexpr (WM == 1) {
+                                                if (q < APCS) stage_a(it + NST - 1, pslot, q, af[0]);
+                                                else stage_b(pslot, q - APCS, af[0]);
+                                            } else {
+                                                if (q < APCS) stage_a(it + NST - 1, pslot, q, af[0], af[1]);
+                                                else stage_b(pslot, q - APCS, af[0], af[1]);
+                                            }
+                                        }
+                                    }
+                                }
                                 if constexpr (NEXT && REFILL) {
                                     if (last) {
 #pragma unroll
-                                        for (int q = 0; q < PIECES; ++q) {
-                                            if ((NF - 1) + q * (NM - NF) / PIECES != n) continue;
+                                        for (int q = 0; q < P1; ++q) {
+                                            if ((NF - 1) + q * (NM - NF) / P1 != n) continue;
                                             if constexpr (WM == 1) {
                                                 if (q < APCS) stage_a(it + NST, slot, q, af[0]);
                                                 else stage_b(slot, q - APCS, af[0]);
@@ -656,6 +709,15 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
 #pragma unroll
                             for (int j = 0; j < FB; ++j) svcmi_lds_landed(nb[j]);
                         }
+#if SVCMI_PROBE_KTRACE
+                        if (last && NEXT) {          // (the s_waitcnt lgkmcnt(0) above also covers the three s_memtime results)
+                            asm volatile("" : "+s"(kt0), "+s"(kt1), "+s"(kt2));
+                            kt_vm += kt1 - kt0; kt_bar += kt2 - kt1;
+                            asm volatile("" : "+s"(kt_r1));
+                            if (kt_prev) { kt_step += kt2 - kt_prev; ++kt_n; } else { kt_r0 = kt_r1; kt_first = kt2; }
+                            kt_prev = kt2;
+                        }
+#endif
                     }
                     return;
                 }
@@ -711,9 +773,24 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
             int it = it_beg, slot = 0;
             auto advance = [&] { ++it; if (++slot == NST) slot = 0; };
             auto nxt = [&] { return slot + 1 == NST ? 0 : slot + 1; };
-            for (; it + NST < it_end; advance()) step(it, slot, nxt(), std::true_type(), std::true_type());       // steady state
-            for (; it + 1 < it_end; advance()) step(it, slot, nxt(), std::true_type(), std::false_type());       // drain: nothing left to request
-            step(it, slot, nxt(), std::false_type(), std::false_type());                                          // last tile
+            if constexpr (SPREAD2) {
+                // (a refill's second half is issued by the K-step AFTER the one that began it: first steady step and the steps behind the
+                //  first drain step have none to issue; >= 1 drain step follows the steady state, so the last tile never has one either)
+                bool steady = false;
+                if (it + NST < it_end) { step(it, slot, nxt(), std::true_type(), std::true_type(), std::false_type()); advance(); steady = true; }
+                for (; it + NST < it_end; advance()) step(it, slot, nxt(), std::true_type(), std::true_type(), std::true_type());
+                if (it + 1 < it_end) {
+                    if (steady) step(it, slot, nxt(), std::true_type(), std::false_type(), std::true_type());
+                    else step(it, slot, nxt(), std::true_type(), std::false_type(), std::false_type());
+                    advance();
+                }
+                for (; it + 1 < it_end; advance()) step(it, slot, nxt(), std::true_type(), std::false_type(), std::false_type());
+                step(it, slot, nxt(), std::false_type(), std::false_type(), std::false_type());
+            } else {
+            for (; it + NST < it_end; advance()) step(it, slot, nxt(), std::true_type(), std::true_type(), std::false_type());       // steady state
+            for (; it + 1 < it_end; advance()) step(it, slot, nxt(), std::true_type(), std::false_type(), std::false_type());       // drain: nothing left to request
+            step(it, slot, nxt(), std::false_type(), std::false_type(), std::false_type());                                          // last tile
+            }
         }
     } else {
         int it = it_beg, slot = 0;
@@ -727,7 +804,31 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
             if (++slot == NST) slot = 0;
         }
     }
+    svcmi_dma_wait();        // (nothing is outstanding after the last tile; a K range of zero steps still waits for the bias here)
     __syncthreads();         // last tile fully consumed before the buffers are reused below
+#if SVCMI_PROBE_KTRACE
+    const bool kt_on = SVCMI_PROBE_KTRACE_N == 0 || p.n_out == SVCMI_PROBE_KTRACE_N;
+    if (kt_on && lane == 0 && block_id < 8192) {
+        unsigned long long* kt = g_ktrace + 4 * (block_id * 4 + wave);
+        kt[0] = kt_step; kt[1] = kt_vm; kt[2] = kt_bar; kt[3] = kt_n;
+        if (block_id == 0 && wave == 0) { g_ktrace[4 * 4 * 8192] = kt_prev - kt_first; g_ktrace[4 * 4 * 8192 + 1] = kt_r1 - kt_r0; g_ktrace[4 * 4 * 8192 + 2] = kt_first - kt_entry; }
+    }
+    unsigned long long kt_a, kt_b = 0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(kt_a)::"memory");
+    auto kt_finish = [&] {
+        if (kt_on && block_id == 0 && tid == 0) {
+            unsigned long long t, tc;
+            asm volatile("s_memtime %1\n\ts_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t), "=s"(tc)::"memory");
+            g_ktrace[4 * 4 * 8192 + 3] = t - kt_prev;
+            g_ktrace[4 * 4 * 8192 + 4] += 1;
+            g_ktrace[4 * 4 * 8192 + 5] = kt_a - kt_prev;        // the K-steps behind the last stamped barrier
+            g_ktrace[4 * 4 * 8192 + 6] = kt_b - kt_a;           // accumulators -> LDS + barrier
+            g_ktrace[4 * 4 * 8192 + 7] = tc - kt_b;             // the epilogue loop (loads, activation, stores issued)
+        }
+    };
+#else
+    auto kt_finish = [] {};
+#endif
 
     // Epilogue through LDS: the accumulators (D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) are
     // laid out as a [BM][BN] tile so that the (rolled, single-copy) epilogue loop walks n fastest and
@@ -747,6 +848,9 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
                 Cs[ml * CLD + nl] = acc[i][j][r];
             }
     __syncthreads();
+#if SVCMI_PROBE_KTRACE
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(kt_b)::"memory");
+#endif
     const int nvalid = (p.n_out - n0) < BN ? (p.n_out - n0) : BN;
     const int mvalid = (p.t_out - m0) < BM ? (p.t_out - m0) : BM;
     if (p.split > 1 || (p.flags & SVCMI_CONV_PARTIALS)) {   // raw partial tile into this slice's slab
@@ -758,6 +862,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
                     if (ml < mvalid && nl < nvalid)
                         *reinterpret_cast<float4*>(wsb + (long long)(m0 + ml) * p.n_out + n0 + nl) = *reinterpret_cast<const float4*>(Cs + ml * CLD + nl);
                 }
+                kt_finish();
                 return;
             }
             for (int e = tid; e < BM * BN; e += 256) {
@@ -804,7 +909,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
             float v = 0.f;
             for (int sl = 0; sl < p.split; ++sl) v += src[sl * sstride];
             float* dst = yb2 + (long long)t * p.ldy + n;
-            *dst = epilogue(p, v, p.bias ? p.bias[n] : 0.f, rb2 ? rb2 + (long long)t * p.ldr : nullptr, dst, n,
+            *dst = epilogue(p, v, smem[BIAS0 + nl], rb2 ? rb2 + (long long)t * p.ldr : nullptr, dst, n,
                             (p.flags & SVCMI_CONV_MASK_OUT) && t >= len);
         }
         return;
@@ -813,14 +918,81 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
     const float* rbp = p.res ? p.res + (long long)b * p.r_bs : nullptr;
     const bool mask_out = (p.flags & SVCMI_CONV_MASK_OUT) != 0;
     if (p.vec) {
-        for (int e = tid; e < BM * (BN / 4); e += 256) {
-            const int ml = e / (BN / 4), nl = (e - ml * (BN / 4)) * 4;
-            if (ml >= mvalid || nl >= nvalid) continue;
-            const int t = m0 + ml, n = n0 + nl;
-            epilogue4(p, *reinterpret_cast<const float4*>(Cs + ml * CLD + nl), p.bias ? p.bias + n : nullptr,
-                      rbp ? rbp + (long long)t * p.ldr + n : nullptr, yb + (long long)t * p.ldy + n, mask_out && t >= len,
-                      p.y16 ? p.y16 + (long long)b * p.y16_bs + (long long)t * p.ldy16 + n : nullptr);
-        }
+        // Round 6 (s_memtime stamps in the kernel, profiles/r06h_ktrace_epilogue.log: this loop was 18 000 of the 150 000 cycles of a Whisper
+        // MLP-up launch and ended with no store outstanding -- it ran at the pace of the store ACKNOWLEDGEMENTS):
+        //  * gfx9 counts loads and stores in one counter, and with a conditional load in the loop hipcc opened every iteration with
+        //    s_waitcnt vmcnt(0), i.e. a wait for the previous iteration's store.  Now every memory operation is unconditional: 16-byte
+        //    buffer accesses whose per-lane offset the hardware range-checks (an absent residual = zero records, an invalid lane or an
+        //    unused accumulate operand = offset 2^31), the operands of iteration i + 1 requested before iteration i is computed -- the
+        //    compiler counts vmcnt exactly, and a launch without residual / accumulate has no load and no wait at all;
+        //  * the bias comes from the tile's LDS copy (one 4-byte LDS-DMA per 64 columns in front of the first operand tile);
+        //  * the activation is chosen OUTSIDE the loop: with the switch inside, every element walked ~10 scalar branches to its arm.
+        const bool acc_on = (p.flags & SVCMI_CONV_ACCUMULATE) != 0;
+        constexpr int EP_IT = BM * (BN / 4) / 256;
+        static_assert(BM * (BN / 4) % 256 == 0, "whole epilogue iterations");
+        constexpr unsigned NOWHERE = 0x80000000u;
+        const svcmi_brsrc ry = svcmi_make_brsrc(yb + (long long)m0 * p.ldy + n0, 0x7fffffffu);           // tile origin; lane offsets < 128 rows x ld (prepare: ld < 2^22)
+        const svcmi_brsrc rr = svcmi_make_brsrc(rbp ? rbp + (long long)m0 * p.ldr + n0 : nullptr, rbp ? 0x7fffffffu : 0u);
+        auto loop = [&](auto act_tag, auto loads_tag) {
+            constexpr int ACT = decltype(act_tag)::value;
+            constexpr bool LOADS = decltype(loads_tag)::value;
+            svcmi_f32x4 rv_n = {0.f, 0.f, 0.f, 0.f}, yo_n = {0.f, 0.f, 0.f, 0.f};
+            auto where = [&](int e, unsigned& oy, unsigned& orr) {
+                const int ml = e / (BN / 4), nl = (e - ml * (BN / 4)) * 4;
+                const bool ok = ml < mvalid && nl < nvalid;
+                oy = ok ? (unsigned)(ml * p.ldy + nl) * 4u : NOWHERE;
+                orr = ok ? (unsigned)(ml * p.ldr + nl) * 4u : NOWHERE;
+            };
+            unsigned oy_n, or_n;
+            where(tid, oy_n, or_n);
+            if constexpr (LOADS) {
+                rv_n = svcmi_buf_load16(rr, or_n);
+                yo_n = svcmi_buf_load16(ry, acc_on ? oy_n : NOWHERE);
+            }
+#pragma nounroll
+            for (int i = 0; i < EP_IT; ++i) {
+                const int e = tid + 256 * i;
+                const int ml = e / (BN / 4), nl = (e - ml * (BN / 4)) * 4;
+                const unsigned oy = oy_n;
+                const svcmi_f32x4 rv = rv_n, yo = yo_n;
+                if constexpr (LOADS) {
+                    where(e + 256, oy_n, or_n);              // (past the last iteration: rows >= BM >= mvalid, nothing is fetched)
+                    rv_n = svcmi_buf_load16(rr, or_n);
+                    yo_n = svcmi_buf_load16(ry, acc_on ? oy_n : NOWHERE);
+                } else {
+                    where(e + 256, oy_n, or_n);
+                }
+                const int t = m0 + ml;
+                const float4 c = *reinterpret_cast<const float4*>(Cs + ml * CLD + nl), bs = *reinterpret_cast<const float4*>(smem + BIAS0 + nl);
+                const bool masked = mask_out && t >= len;
+                const float cv[4] = {c.x, c.y, c.z, c.w}, bv[4] = {bs.x, bs.y, bs.z, bs.w};
+                svcmi_f32x4 o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {       // the arithmetic of `epilogue`, per component
+                    float q = act_apply(cv[k] + bv[k], ACT);
+                    if (LOADS && rbp) q += rv[k];
+                    q *= p.alpha;
+                    if (LOADS && acc_on) q += yo[k];
+                    o[k] = masked ? 0.f : q;
+                }
+                svcmi_buf_store16(o, ry, oy);
+                if (p.y16 && oy != NOWHERE)
+                    svcmi_store4_16(p.y16 + (long long)b * p.y16_bs + (long long)t * p.ldy16 + n0 + nl, p.ldy16 >> 1, o[0], o[1], o[2], o[3], p.y16_f16);
+            }
+        };
+        auto by_act = [&](auto loads_tag) {
+            switch (p.act) {
+                case SVCMI_ACT_NONE: loop(std::integral_constant<int, SVCMI_ACT_NONE>(), loads_tag); break;
+                case SVCMI_ACT_RELU: loop(std::integral_constant<int, SVCMI_ACT_RELU>(), loads_tag); break;
+                case SVCMI_ACT_GELU: loop(std::integral_constant<int, SVCMI_ACT_GELU>(), loads_tag); break;
+                case SVCMI_ACT_MISH: loop(std::integral_constant<int, SVCMI_ACT_MISH>(), loads_tag); break;
+                case SVCMI_ACT_TANH: loop(std::integral_constant<int, SVCMI_ACT_TANH>(), loads_tag); break;
+                default: loop(std::integral_constant<int, SVCMI_ACT_SIGMOID>(), loads_tag); break;
+            }
+        };
+        if (rbp || acc_on) by_act(std::true_type());
+        else by_act(std::false_type());
+        kt_finish();
         return;
     }
     for (int e = tid; e < BM * BN; e += 256) {
@@ -828,7 +1000,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
         if (ml >= mvalid || nl >= nvalid) continue;
         const int t = m0 + ml, n = n0 + nl;
         float* dst = yb + (long long)t * p.ldy + n;
-        *dst = epilogue(p, Cs[ml * CLD + nl], p.bias ? p.bias[n] : 0.f, rbp ? rbp + (long long)t * p.ldr : nullptr, dst, n,
+        *dst = epilogue(p, Cs[ml * CLD + nl], smem[BIAS0 + nl], rbp ? rbp + (long long)t * p.ldr : nullptr, dst, n,
                         mask_out && t >= len);
     }
 }
@@ -994,7 +1166,7 @@ int prepare(const svcmi_conv_desc* d, ConvArgs& a, int& mode, int prec = PREC_F3
     a.act = d->act; a.flags = d->flags; a.alpha = d->alpha;
     {
         const auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
-        a.vec = d->n_out % 4 == 0 && d->ldy % 4 == 0 && d->y_bstride % 4 == 0 && al16(d->y) &&
+        a.vec = d->n_out % 4 == 0 && d->ldy % 4 == 0 && d->y_bstride % 4 == 0 && al16(d->y) && d->ldy < (1 << 22) && d->ldr < (1 << 22) &&      // (tile-local 32-bit buffer offsets)
                 (!d->bias || al16(d->bias)) && (!d->res || (d->ldr % 4 == 0 && d->res_bstride % 4 == 0 && al16(d->res))) &&
                 (!d->workspace || al16(d->workspace));
     }

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void channel_norm_gelu_kernel(const float* x, 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float n = (vv[j] - st[2 * (cc + j)]) * st[2 * (cc + j) + 1] * (gamma ? gamma[cc + j] : 1.f) + (beta ? beta[cc + j] : 0.f);
-            o[j] = 0.5f * n * (1.f + erff(n * 0.70710678118654752440f));
+            o[j] = svcmi_gelu(n);
         }
         *reinterpret_cast<float4*>(yb + r * ldy + cc) = make_float4(o[0], o[1], o[2], o[3]);
     }

@@ -125,32 +125,67 @@ __device__ __forceinline__ svcmi_rsrc svcmi_make_rsrc(const void* base, unsigned
     r.w = 0x00020000;
     return r;
 }
+// Timing probes of the GEMM K loop (scripts/build_variant.sh ... -DSVCMI_PROBE_NODMA=1 / _NOMFMA / _NOLDSREAD; results are garbage, the
+// time is the point): which of {global -> LDS fill, LDS fragment reads, matrix instructions} bounds a K-step.  Never set in the product build.
+// Experiment (round 6): LDS-DMA issue WITHOUT saving / restoring M0 around it (2 scalar moves less per piece).  hipcc reserves M0 and rejects an
+// "m0" clobber, so this is only sound in a translation unit whose ISA touches M0 nowhere else (checked on the assembly, not by the compiler).
+#ifndef SVCMI_DMA_M0_RAW
+#define SVCMI_DMA_M0_RAW 0
+#endif
+#ifndef SVCMI_PROBE_NODMA
+#define SVCMI_PROBE_NODMA 0
+#endif
+#ifndef SVCMI_PROBE_NOLDSREAD
+#define SVCMI_PROBE_NOLDSREAD 0
+#endif
+#ifndef SVCMI_PROBE_NOMFMA
+#define SVCMI_PROBE_NOMFMA 0
+#endif
 typedef unsigned svcmi_ldsaddr;          // wave-uniform LDS byte address (what M0 takes)
 __device__ __forceinline__ svcmi_ldsaddr svcmi_lds_addr(const float* lds_ptr) {
     return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) float*)lds_ptr);
 }
 __device__ __forceinline__ svcmi_ldsaddr svcmi_lds_advance(svcmi_ldsaddr a, int floats) { return a + 4u * (unsigned)floats; }
 __device__ __forceinline__ void svcmi_bdma16(unsigned voff, svcmi_ldsaddr lds_wave_base, svcmi_rsrc rsrc) {
+    if (SVCMI_PROBE_NODMA) return;
+#if SVCMI_DMA_M0_RAW
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" : : "v"(voff), "s"(lds_wave_base), "s"(rsrc) : "memory");
+#else
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(lds_wave_base), "s"(rsrc) : "memory");
+#endif
 }
 // The same DMA pinned inside an MFMA stream by register ties (svcmi_lds_read16: the A fragments the surrounding MFMAs consume)
 __device__ __forceinline__ void svcmi_bdma16_at(unsigned voff, svcmi_ldsaddr lds_wave_base, svcmi_rsrc rsrc, svcmi_f32x4& tie) {
+    if (SVCMI_PROBE_NODMA) return;
+#if SVCMI_DMA_M0_RAW
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds" : "+v"(tie) : "v"(voff), "s"(lds_wave_base), "s"(rsrc) : "memory");
+#else
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %4, 0 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep), "+v"(tie) : "v"(voff), "s"(lds_wave_base), "s"(rsrc) : "memory");
+#endif
 }
 __device__ __forceinline__ void svcmi_bdma16_at(unsigned voff, svcmi_ldsaddr lds_wave_base, svcmi_rsrc rsrc, svcmi_f32x4& tie, svcmi_f32x4& tie2) {
+    if (SVCMI_PROBE_NODMA) return;
+#if SVCMI_DMA_M0_RAW
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %4, 0 offen lds" : "+v"(tie), "+v"(tie2) : "v"(voff), "s"(lds_wave_base), "s"(rsrc) : "memory");
+#else
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %5, 0 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep), "+v"(tie), "+v"(tie2) : "v"(voff), "s"(lds_wave_base), "s"(rsrc) : "memory");
+#endif
 }
 __device__ __forceinline__ void svcmi_bdma16_at(unsigned voff, svcmi_ldsaddr lds_wave_base, svcmi_rsrc rsrc) { svcmi_bdma16(voff, lds_wave_base, rsrc); }
 __device__ __forceinline__ void svcmi_bdma4(unsigned voff, svcmi_ldsaddr lds_wave_base, svcmi_rsrc rsrc) {
+#if SVCMI_DMA_M0_RAW
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %0, %2, 0 offen lds" : : "v"(voff), "s"(lds_wave_base), "s"(rsrc) : "memory");
+#else
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(lds_wave_base), "s"(rsrc) : "memory");
+#endif
 }
 __device__ __forceinline__ void svcmi_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // Wait until at most N of this wave's VMEM operations (LDS-DMAs included, counted in issue order) are outstanding.
@@ -168,12 +203,14 @@ __device__ __forceinline__ void svcmi_dma_wait_n() {
 //   svcmi_lds_arrive(dst)          s_waitcnt lgkmcnt(0) naming dst read-write, so no consumer floats above it.
 // hipcc does not count asm LDS operations; extra ones in flight only make its own lgkmcnt waits stricter.
 __device__ __forceinline__ void svcmi_lds_read16(svcmi_f32x4& dst, const float* p, svcmi_f32x4& tie) {
+    if (SVCMI_PROBE_NOLDSREAD) { asm volatile("" : "=v"(dst), "+v"(tie)); return; }
     const unsigned a = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)p;
     asm volatile("ds_read_b128 %0, %2" : "=v"(dst), "+v"(tie) : "v"(a) : "memory");
 }
 // Two ties (the 128-row tiles issue MFMAs on two A fragments): the statement sits below every earlier consumer of either register and
 // above every later one -- with both A fragments of a sub-step named, an exact position in its MFMA stream (conv_gemm_body.h, "SPREAD").
 __device__ __forceinline__ void svcmi_lds_read16(svcmi_f32x4& dst, const float* p, svcmi_f32x4& tie, svcmi_f32x4& tie2) {
+    if (SVCMI_PROBE_NOLDSREAD) { asm volatile("" : "=v"(dst), "+v"(tie), "+v"(tie2)); return; }
     const unsigned a = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)p;
     asm volatile("ds_read_b128 %0, %3" : "=v"(dst), "+v"(tie), "+v"(tie2) : "v"(a) : "memory");
 }
@@ -213,6 +250,21 @@ __device__ __forceinline__ void svcmi_store16_sc1(svcmi_f32x4 v, svcmi_rsrc r, u
     asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen sc1\n\ts_nop 1" ::"v"(v), "v"(byte_off), "s"(r) : "memory");
 }
 
+// Plain 16-byte loads / stores through a buffer descriptor whose per-lane 32-bit byte offset is RANGE-CHECKED by the hardware: an offset
+// >= num_records (0x80000000 for "this lane does nothing") loads zeros / drops the store.  No branch around the memory operation, so hipcc
+// can count vmcnt exactly across a loop's back edge (with a conditional load in the loop it opens every iteration with s_waitcnt vmcnt(0),
+// which on gfx9 -- loads and stores share the counter -- also waits for the previous iteration's STORE: conv_gemm_body.h, epilogue).
+typedef __amdgpu_buffer_rsrc_t svcmi_brsrc;
+__device__ __forceinline__ svcmi_brsrc svcmi_make_brsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ svcmi_f32x4 svcmi_buf_load16(svcmi_brsrc r, unsigned byte_off) {
+    return __builtin_bit_cast(svcmi_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
+}
+__device__ __forceinline__ void svcmi_buf_store16(svcmi_f32x4 v, svcmi_brsrc r, unsigned byte_off) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(svcmi_u32x4, v), r, (int)byte_off, 0, 0);
+}
+
 // Scheduling hint: the next `n` instructions of class `mask` (0x008 MFMA, 0x100 DS read, 0x020 VMEM read, 0x002 VALU)
 // form a group, groups are emitted in source order (cdna_hip_programming.md T19).
 #define SVCMI_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
@@ -226,6 +278,32 @@ __device__ __forceinline__ void svcmi_store16_sc1(svcmi_f32x4 v, svcmi_rsrc r, u
 #endif
 
 #define SVCMI_WAVE 64
+
+// GELU(v) = v * Phi(v), exact-erf form (torch.nn.functional.gelu default; whisper/model.py:122, hubert, crepe), branch-free (round 6).
+// libm's erff is two polynomial branches plus an expf expansion, ~45 instructions per element when a wave takes both -- 4 us of the 63 us
+// Whisper MLP-up launch were its epilogue's GELU.  Here: t = |v| / sqrt 2, erfc(t) = 2^(t * q(t)) with q a degree-7 polynomial fitted to
+// log2(erfc(t)) / t on [0, 4.2] under the weight erfc(t) (max |erf error| 1.6e-8, scripts/fit_gelu.py), ONE v_exp_f32, and
+//   v > 0:  v - (0.5 v) erfc(t)        v <= 0:  (0.5 v) erfc(t)
+// which needs no 1 - erfc cancellation: max |error| 2.7e-7 over [-12, 12] against the fp64 function (torch's own fp32 GELU: 1.2e-6).
+#ifndef SVCMI_EMU
+__device__ __forceinline__
+#else
+static inline
+#endif
+float svcmi_gelu(float v) {
+    const float a = fabsf(v) * 0.70710678118654752440f;
+    const float t = a < 4.2f ? a : 4.2f;                 // erfc(4.2) = 3e-9: below half an ulp of 1
+    float q = -4.535877815214917e-05f;
+    q = fmaf(q, t, 0.0004455065354704857f);
+    q = fmaf(q, t, -0.0014894307823851705f);
+    q = fmaf(q, t, -0.0007746575865894556f);
+    q = fmaf(q, t, 0.028253713622689247f);
+    q = fmaf(q, t, -0.14848163723945618f);
+    q = fmaf(q, t, -0.9184163808822632f);
+    q = fmaf(q, t, -1.6279085874557495f);
+    const float h = 0.5f * v * svcmi_exp2(q * t);
+    return v > 0.f ? v - h : h;
+}
 
 // Four consecutive values as a 16-bit copy (8-byte store): fmt 0 bf16, 1 f16, 2 split bf16 -- hi = rne(x) at dst, lo = rne(x - hi) at
 // dst + lo_off: the activation-row format of the _A16 GEMM kernels (conv_gemm_body.h).

@@ -151,20 +151,6 @@ def decode(prob, fmin=50.0, fmax=1000.0, decoder="viterbi", dither=None):
     return 10 * 2 ** (cents / 1200)
 
 
-def mean_filter(signals, win_length):
-    """crepe/filter.py:10-57: NaN-aware moving average over [1, T]; exact zeros become NaN."""
-    import torch.nn.functional as F
-    x = signals.unsqueeze(1)
-    mask = ~torch.isnan(x)
-    mx = torch.where(mask, x, torch.zeros_like(x))
-    ones = torch.ones(1, 1, win_length)
-    s = F.conv1d(mx, ones, padding=win_length // 2)
-    c = F.conv1d(mask.float(), ones, padding=win_length // 2).clamp(min=1)
-    out = s / c
-    out[out == 0] = float("nan")
-    return out.squeeze(1)
-
-
 @torch.no_grad()
 def compute_f0_sing(filename, device, model=None, noise=None, dither=None, decoder="viterbi"):
     """pitch/inference.py:74-99.  ``filename``: wav path or a 16 kHz float waveform [n]; ``model``: a ``Crepe`` (the
@@ -225,7 +211,7 @@ def _viterbi_constants(device):
 
 
 def _mean_filter_np(x, win_length):
-    """``mean_filter`` for one fp32 track in numpy (the track is a few thousand values: torch's CPU convolution spends its time
+    """crepe/filter.py:10-57 (NaN-aware moving average; exact zeros become NaN) for one fp32 track in numpy (the track is a few thousand values: torch's CPU convolution spends its time
     waking a thread pool on a 128-core host)."""
     x = np.asarray(x, dtype=np.float32)
     mask = ~np.isnan(x)
