@@ -340,6 +340,22 @@ def measured_traffic(kernel="conv_gemm_kernel"):
         return None, None
 
 
+def measured_inflight_timeline():
+    """The implicit-GEMM family's in-flight timeline from the newest committed probe record (profiles/r*_inflight_timeline.json: block stamps
+    written by the kernels of a -DSVCMI_PROBE_KTRACE=1 build while 4 clips were in flight -- rocprofv3 serialises the queues, so the judged
+    regime cannot be traced from outside; scripts/inflight_timeline.py).  Returns (dict, source) or (None, source-if-stale)."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_inflight_timeline.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        if d.get("csrc_sha") != csrc_sha():
+            return None, os.path.relpath(files[-1], ROOT) + " [STALE: csrc changed since]"
+        return d, os.path.relpath(files[-1], ROOT)
+    except Exception:       # noqa: BLE001
+        return None, None
+
+
 def rocprof_gemm_ms_per_step(prefixes=("conv_gemm_kernel<", "conv_gemm_group_kernel<")):
     """Summed `calls_per_step x avg_us` of the implicit-GEMM kernels in the newest committed rocprofv3 --kernel-trace --stats
     summary of the judged configuration (profiles/r*_kernel_stats.csv, scripts/prof_summary.py).  Returns (ms, source)."""
@@ -607,6 +623,38 @@ def main():
         run = wl.step
     elapsed = timed(run, lanes.synchronize if lanes is not None else torch.cuda.synchronize, args.steps, args.warmup)
     ms_per_step = 1000.0 * elapsed / args.steps
+    if os.environ.get("SVCMI_TIMELINE"):
+        # In-flight timeline (probe library with -DSVCMI_PROBE_KTRACE=1 only; scripts/inflight_timeline.py): after the timed loop, record the
+        # block stamps of N more steps in THIS launch regime and summarise them -- gemm_ms_per_step is measured, not inferred.
+        import ctypes
+        import numpy as np
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts"))
+        import inflight_timeline as TLM
+        plib = ctypes.CDLL(os.environ["SVCMI_LIB"])
+        plib.svcmi_probe_timeline_read.restype = ctypes.c_longlong
+        plib.svcmi_probe_timeline_read.argtypes = [ctypes.c_void_p, ctypes.c_longlong]
+        sync = lanes.synchronize if lanes is not None else torch.cuda.synchronize
+        nrec = int(os.environ.get("SVCMI_TIMELINE_STEPS", "8"))
+        for _ in range(4):
+            run()                               # (the queues stay full across the reset below: nothing is drained in between)
+        sync(); torch.cuda.synchronize()
+        assert plib.svcmi_probe_timeline_reset() == 0
+        for _ in range(nrec):
+            run()
+        sync(); torch.cuda.synchronize()
+        cap = 1 << 22
+        buf = np.zeros(5 * cap, dtype=np.uint64)
+        got = plib.svcmi_probe_timeline_read(buf.ctypes.data_as(ctypes.c_void_p), cap)
+        summ = TLM.summarise(buf[:5 * got], clips=nrec * args.batch)
+        summ.update(records=int(got), regime=f"{inflight} clips in flight" if inflight > 1 else "one clip at a time", ms_per_step_timed=round(ms_per_step, 4))
+        try:
+            from workload import stamp as ST
+            summ["csrc_sha"] = ST.csrc_sha()
+        except Exception:       # noqa: BLE001
+            pass
+        with open(os.environ["SVCMI_TIMELINE"], "w") as f:
+            json.dump(summ, f, indent=1)
+        log("timeline: " + json.dumps({k: v for k, v in summ.items() if k != "classes"}))
     if os.environ.get("SVCMI_KTRACE_CLOCK"):       # timing-probe library (-DSVCMI_PROBE_KTRACE=1) only: the shader clock the GEMM K loops see in THIS launch regime
         import ctypes
         plib = ctypes.CDLL(os.environ["SVCMI_LIB"])
@@ -705,6 +753,17 @@ def main():
             agg_ach = gm["flops"] / (ms_per_step * 1e-3) / 1e12
             out["roofline"]["in_flight"] = {"achieved": round(agg_ach, 2), "frac": round(agg_ach / peak, 4),
                                             "note": f"GEMM FLOPs of one step / ms_per_step with {inflight} clips in flight (every other kernel's time included)"}
+        if dom == "f32" and args.config == 1 and args.batch == 1 and args.seconds == 10.0 and inflight > 1:
+            tl, tl_src = measured_inflight_timeline()
+            if tl:      # MEASURED in the judged regime (records written by the kernels of the probe build of this csrc; ~2 % slower than the shipped build)
+                out["roofline"]["in_flight"].update({
+                    "gemm_ms_per_step": tl["gemm_ms_per_step"], "ms_per_step_of_the_record": tl["ms_per_step_in_window"],
+                    "frac_measured": tl["frac_while_resident"], "gemm_launches_resident_share": tl["concurrency_share"],
+                    "sum_of_launch_durations_ms_per_step": tl["sum_ms_per_step"], "source": tl_src,
+                    "measured_note": "gemm_ms_per_step = wall time per clip with >= 1 implicit-GEMM launch resident (union of [first block entry, last block exit] "
+                                     "over every launch of every lane); frac_measured = GEMM FLOPs / that time / peak"})
+            elif tl_src:
+                out["roofline"]["in_flight"]["source"] = tl_src
         if dom == "f32" and args.config == 1 and args.batch == 1 and args.seconds == 10.0:
             rp_ms, rp_src = rocprof_gemm_ms_per_step()
             if rp_ms:
@@ -714,7 +773,8 @@ def main():
                 out["roofline"]["frac_rocprof_source"] = rp_src
         # committed profile summaries are only quoted when they were measured on THIS tree's kernel sources (workload/stamp.py)
         out["roofline"]["csrc_sha"] = csrc_sha()
-        out["roofline"]["stale"] = any("STALE" in str(out["roofline"].get(k) or "") for k in ("traffic_source", "frac_rocprof_source"))
+        out["roofline"]["stale"] = any("STALE" in str(out["roofline"].get(k) or "") for k in ("traffic_source", "frac_rocprof_source")) or \
+            "STALE" in str((out["roofline"].get("in_flight") or {}).get("source") or "")
         out["kernel_time_ms"] = {k.replace("svcmi_", ""): round(v["ms"], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
         sn = agg.get("svcmi_snake_alias_f32")
         if sn:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SVCMI_ABI_VERSION 21
+#define SVCMI_ABI_VERSION 22
 
 enum svcmi_status { SVCMI_OK = 0, SVCMI_EINVAL = -1, SVCMI_EUNSUPPORTED = -2, SVCMI_EALIGN = -3 };
 
@@ -49,6 +49,9 @@ enum svcmi_conv_flags {
     SVCMI_CONV_TILE_P16_128x80 = 0x700,
     SVCMI_CONV_TILE_P16_64x160 = 0x800,
     SVCMI_CONV_TILE_64x128 = 0x900, /* reduced-precision entry points only */
+    /* ABI 22: the 64x80 wave tile on EIGHT-wave (512-thread) blocks: 128 x 80 per block = one block per CU at M = 500 x N = 5120 with two
+     * waves per SIMD, 26 instead of 36 KB of LDS fill per CU and K-step; fp32 only, vector gathers; bit-identical to SVCMI_CONV_TILE_P16_64x80 */
+    SVCMI_CONV_TILE_P16W8_128x80 = 0xA00,
     SVCMI_CONV_TILE_MASK = 0xF00,
     /* tuning knob: 2-deep operand ring instead of the 3-deep one of the 64-row fp32 tiles (64x64, P16 64x48 / 64x80): 33 / 41 KB of LDS
      * per block instead of 49 / 61 KB = one more resident block per CU and room for other streams' blocks beside them.  Slower for a

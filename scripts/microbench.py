@@ -161,6 +161,13 @@ def main():
             for w in range(4):
                 okw = ok[:, w]
                 print(f"    wave {w}: step {(a[:, w, 0][okw] / nst[:, w][okw]).mean():.0f}  vmwait {(a[:, w, 1][okw] / (nst[:, w][okw] + 1)).mean():.0f}  barrier {(a[:, w, 2][okw] / (nst[:, w][okw] + 1)).mean():.0f}")
+    if "w8" in what:          # the 64x80 wave tile on four-wave (tile 6) and eight-wave blocks (tile 10), both ring depths (| 16 = SVCMI_CONV_RING2)
+        for T in (500, 750):
+            gemm(ops, "whisper_mlp1", T, 1280, 5120, tiles=(6, 10, 6 | 16, 10 | 16), splits=(1,))
+            gemm(ops, "whisper_qkv", T, 1280, 3840, tiles=(1, 6, 10), splits=(1,))
+            gemm(ops, "whisper_o", T, 1280, 1280, tiles=(6, 10), splits=(2, 4), partials=True)
+            gemm(ops, "whisper_mlp2", T, 5120, 1280, tiles=(6, 10), splits=(4, 8), partials=True)
+        gemm(ops, "mlp1_M4096", 4096, 1280, 5120, tiles=(6, 10, 3), splits=(1,))
     if "kprobe" in what:      # K-loop timing probes (build_variant.sh -DSVCMI_PROBE_*): the same launches on every variant library
         for cin in (640, 1280, 2560):
             gemm(ops, "mlp1_K", 500, cin, 5120, tiles=(6, 7, 3), splits=(1,))

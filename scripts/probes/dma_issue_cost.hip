@@ -23,7 +23,7 @@ template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_wai
 
 constexpr int KDIM = 1280, NROWS_A = 512, NROWS_B = 5120;
 
-template <int NMW, int NLW, int SELF, int LOAD, bool BAR, int FORCE_KB = 0, int UNROLL = 1, int DELAY = 0, int PAD = 0>
+template <int NMW, int NLW, int SELF, int LOAD, bool BAR, int FORCE_KB = 0, int UNROLL = 1, int DELAY = 0, int PAD = 0, int PLAIN = 0>
 __global__ __launch_bounds__(64 * (NMW + NLW)) void kern(const float* A, const float* W, float* out, int ksteps, unsigned* where, unsigned long long* stamps) {
     constexpr int PIECES = NMW * SELF + NLW * LOAD;          // per block per K-step
     constexpr int RING = 3;
@@ -56,6 +56,8 @@ __global__ __launch_bounds__(64 * (NMW + NLW)) void kern(const float* A, const f
         for (int k = 0; k < 5; ++k) for (int r = 0; r < 4; ++r) c[k][r] = 0.f;
         float a[4], b[4];
         for (int k = 0; k < 4; ++k) { a[k] = 0.001f * (float)(lane + k + 1); b[k] = 0.002f * (float)(lane * 3 + k + 1); }
+        f32x4 pl[2][PLAIN > 0 ? PLAIN : 1];          // PLAIN of the SELF pieces go straight to registers (16 rows x 64 B per instruction = an A fragment), used one K-step later
+        for (int u = 0; u < 2; ++u) for (int q = 0; q < (PLAIN > 0 ? PLAIN : 1); ++q) pl[u][q] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (PAD) asm volatile("s_nop 0");       // shifts the loop by 4 bytes: 8-byte instructions at 0 or 4 mod 8
         for (int it0 = 0; it0 < ksteps; it0 += UNROLL)
 #pragma unroll
@@ -73,12 +75,20 @@ __global__ __launch_bounds__(64 * (NMW + NLW)) void kern(const float* A, const f
                             const bool isA = piece * 5 < PIECES * 2;
                             const int rowbase = isA ? mt * 16 * NMW : nt * 80 - (PIECES * 2 / 5) * 8;
                             asm volatile("" : "+v"(c[m % 5]));        // keep the DMA at this position of the stream
+                            if (q < PLAIN) {        // fragment-shaped: lane l -> row l & 15, 16 bytes at 16 * (l >> 4) (+ 64 for the second half)
+                                const unsigned fo = (unsigned)((mt * 16 * NMW + wave * 16 + (lane & 15)) * KDIM * 4) + (unsigned)((it % (KDIM / 32)) * 128 + (q & 1) * 64 + (lane >> 4) * 16);
+                                asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(pl[u & 1][q]) : "v"(fo), "s"(ra) : "memory");
+                            } else
                             dma16(voff(piece, it) + (unsigned)(rowbase * KDIM * 4), lds0 + slot + (unsigned)piece * 1024u, isA ? ra : rw);
                             asm volatile("" : "+v"(c[(m + 1) % 5]));
                         }
                 }
             }
             if (SELF > 0) vm_wait<SELF>();                  // the previous K-step's pieces have landed
+            if (PLAIN > 0) {                                // ... and its register fragments are consumed
+#pragma unroll
+                for (int q = 0; q < PLAIN; ++q) { asm volatile("" : "+v"(pl[(u + 1) & 1][q])); a[q & 3] += pl[(u + 1) & 1][q][0] * 1e-30f; }
+            }
             if (BAR) __builtin_amdgcn_s_barrier();
         }
         float s = 0.f;
@@ -111,19 +121,19 @@ __global__ __launch_bounds__(64 * (NMW + NLW)) void kern(const float* A, const f
 static double waves_cu_f(int blocks, int nmw) { return (double)blocks * nmw / 256.0; }
 #include <map>
 #include <vector>
-template <int NMW, int NLW, int SELF, int LOAD, bool BAR, int FORCE_KB = 0, int UNROLL = 1, int DELAY = 0, int PAD = 0>
+template <int NMW, int NLW, int SELF, int LOAD, bool BAR, int FORCE_KB = 0, int UNROLL = 1, int DELAY = 0, int PAD = 0, int PLAIN = 0>
 static void run(const float* A, const float* W, float* out, int blocks_override = 0) {
     const int blocks = blocks_override ? blocks_override : (NMW == 4 ? 512 : 256), ksteps = 400, WV = NMW + NLW;
     static unsigned* where = nullptr;
     static unsigned long long* stamps = nullptr;
     if (!where) { hipMalloc(&where, 4096 * 16 * 4); hipMalloc(&stamps, 4096 * 16 * 16 + 64); }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    kern<NMW, NLW, SELF, LOAD, BAR, FORCE_KB, UNROLL, DELAY, PAD><<<blocks, 64 * WV>>>(A, W, out, ksteps, where, stamps);
+    kern<NMW, NLW, SELF, LOAD, BAR, FORCE_KB, UNROLL, DELAY, PAD, PLAIN><<<blocks, 64 * WV>>>(A, W, out, ksteps, where, stamps);
     hipDeviceSynchronize();
     float best = 1e9f;
     for (int rep = 0; rep < 5; ++rep) {
         hipEventRecord(e0);
-        kern<NMW, NLW, SELF, LOAD, BAR, FORCE_KB, UNROLL, DELAY, PAD><<<blocks, 64 * WV>>>(A, W, out, ksteps, where, stamps);
+        kern<NMW, NLW, SELF, LOAD, BAR, FORCE_KB, UNROLL, DELAY, PAD, PLAIN><<<blocks, 64 * WV>>>(A, W, out, ksteps, where, stamps);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (ms < best) best = ms;
@@ -159,8 +169,8 @@ static void run(const float* A, const float* W, float* out, int blocks_override 
     const double waves_cu = (double)blocks * NMW / 256.0;          // MFMA waves per CU
     const double ideal = 40.0 * 32.0 * (waves_cu / 4.0) / 2400.0;      // us per K-step at 2.4 GHz
     const double pieces_cu = (double)blocks * (NMW * SELF + NLW * LOAD) / 256.0;
-    printf("%d blocks, unroll %d, pad %d: mfma waves/block %d  loader waves %d  self %d  load %d  barrier %d : %.3f us per K-step (pipe floor %.3f = %.2f)  %.0f pieces per CU per K-step  LDS %d KB/block  err %d\n",
-           blocks, UNROLL, PAD, NMW, NLW, SELF, LOAD, (int)BAR, us_step, ideal, ideal / us_step, pieces_cu, (NMW * SELF + NLW * LOAD) * 3 > FORCE_KB ? (NMW * SELF + NLW * LOAD) * 3 : FORCE_KB, (int)hipGetLastError());
+    printf("%d blocks, unroll %d, pad %d, plain %d: mfma waves/block %d  loader waves %d  self %d  load %d  barrier %d : %.3f us per K-step (pipe floor %.3f = %.2f)  %.0f pieces per CU per K-step  LDS %d KB/block  err %d\n",
+           blocks, UNROLL, PAD, PLAIN, NMW, NLW, SELF, LOAD, (int)BAR, us_step, ideal, ideal / us_step, pieces_cu, (NMW * SELF + NLW * LOAD) * 3 > FORCE_KB ? (NMW * SELF + NLW * LOAD) * 3 : FORCE_KB, (int)hipGetLastError());
     {
         unsigned long long cal[2];
         hipMemcpy(cal, stamps + 2 * 4096 * 16 - 2, 16, hipMemcpyDeviceToHost);
@@ -182,6 +192,15 @@ int main(int argc, char** argv) {
     float *A, *W, *out;
     hipMalloc(&A, (size_t)NROWS_A * KDIM * 4); hipMalloc(&W, (size_t)NROWS_B * KDIM * 4); hipMalloc(&out, (size_t)512 * 1024 * 4);
     hipMemset(A, 0, (size_t)NROWS_A * KDIM * 4); hipMemset(W, 0, (size_t)NROWS_B * KDIM * 4);
+    if (argc > 4) {        // A fragments straight to registers: 2 of the 5 pieces per wave as plain fragment-shaped loads (unroll 2: static register sets)
+        run<4, 0, 0, 0, true, 60, 2>(A, W, out);
+        run<4, 0, 5, 0, true, 0, 2>(A, W, out);
+        run<4, 0, 5, 0, true, 0, 2, 0, 0, 2>(A, W, out);
+        run<4, 0, 3, 0, true, 0, 2>(A, W, out);
+        run<4, 0, 2, 0, true, 0, 2, 0, 0, 2>(A, W, out);
+        run<4, 0, 5, 0, true, 0, 2, 0, 0, 5>(A, W, out);
+        return 0;
+    }
     if (argc > 3) {        // the same loops shifted by 4 bytes
         run<4, 0, 0, 0, false, 60, 1, 0, 0>(A, W, out);
         run<4, 0, 0, 0, false, 60, 1, 0, 1>(A, W, out);

@@ -56,6 +56,10 @@ CONV_CASES_SMALL = [
     dict(id="p16_n160_chunk_k7_d3_splitk", B=1, T=200, cin=160, n=160, k=7, dil=3, pad=9, res=True, split_k=2, tile=8),
     dict(id="p16_n38_ragged_masks", B=2, T=150, cin=16, n=38, k=5, pad=2, lengths=[150, 111], mask_in=True, mask_out=True, tile=4),
     dict(id="p16_n70_128x80", B=1, T=200, cin=32, n=70, k=3, pad=1, act=ACT_GELU, tile=7),
+    # eight-wave blocks (tile 10 = SVCMI_CONV_TILE_P16W8_128x80): ragged rows / columns, several N tiles, residual + accumulate, split-K, masks
+    dict(id="w8_n200_chunk_k3_gelu", B=1, T=300, cin=64, n=200, k=3, pad=1, act=ACT_GELU, tile=10),
+    dict(id="w8_n70_vec_k5_d2_res_acc", B=2, T=150, cin=20, n=70, k=5, dil=2, pad=4, res=True, alpha=1.0 / 3.0, accumulate=True, tile=10),
+    dict(id="w8_n84_splitk3_masks", B=2, T=140, cin=32, n=84, k=7, pad=3, lengths=[140, 101], mask_in=True, mask_out=True, split_k=3, tile=10),
     # outlier-scale inputs: the exact-erf GELU / Mish far in both tails (|v| up to ~100)
     dict(id="gelu_large_arguments", B=1, T=70, cin=64, n=70, k=3, pad=1, act=ACT_GELU, xscale=30.0),
     dict(id="mish_large_arguments", B=1, T=70, cin=32, n=40, k=7, pad=3, act=ACT_MISH, xscale=30.0),
@@ -216,6 +220,25 @@ def check_conv_ring2(ops, device, tile, n, cin=64, k=5, T=150, B=2):
     ref = F.gelu(F.conv1d(x.cpu().transpose(1, 2), w.cpu()[:, :cin * k].view(n, k, cin).permute(0, 2, 1).contiguous(), bias.cpu(), padding=(k - 1) // 2).transpose(1, 2)) + res.cpu()
     _close(y2, ref, 2e-5, f"ring2 tile {tile}")
     return True
+
+def check_conv_w8(ops, device, n, cin=64, k=3, T=300, B=2, partials=False):
+    """SVCMI_CONV_TILE_P16W8_128x80 (tile 10: the 64x80 wave tile on eight-wave blocks) against SVCMI_CONV_TILE_P16_64x80 (tile 6): the same
+    wave tile and the same K order, so the same bits -- full launches (bias, GELU, residual) and raw split-K slabs, both ring depths."""
+    g = _g(1000 + n + cin + k)
+    x = (torch.randn(B, T, cin, generator=g)).to(device)
+    w = PW.pack_conv(torch.randn(n, cin, k, generator=g) / math.sqrt(cin * k)).to(device)
+    bias = torch.randn(n, generator=g).to(device)
+    res = torch.randn(B, T, n, generator=g).to(device)
+    for ring in (0, 16):
+        if partials:
+            y6 = ops.conv(x, w, None, ksize=k, pad=(k - 1) // 2, tile=6 | ring, split_k=2, partials=True)
+            y10 = ops.conv(x, w, None, ksize=k, pad=(k - 1) // 2, tile=10 | ring, split_k=2, partials=True)
+        else:
+            y6 = ops.conv(x, w, bias, ksize=k, pad=(k - 1) // 2, act=ACT_GELU, res=res, split_k=1, tile=6 | ring)
+            y10 = ops.conv(x, w, bias, ksize=k, pad=(k - 1) // 2, act=ACT_GELU, res=res, split_k=1, tile=10 | ring)
+        assert torch.equal(y6, y10), (n, cin, k, ring, float((y6 - y10).abs().max()))
+    return True
+
 
 def _split16(x):
     """fp32 [..., C] -> the SPLIT16 layout [..., 2*Cp] (ops.SPLIT16): hi = bf16(x), lo = bf16(x - hi), zero pads."""

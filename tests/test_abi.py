@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(hip_so):
     lib.svcmi_build_info.restype = ctypes.c_char_p
     assert lib.svcmi_build_info() == b"hip:gfx950"
     from svcmi import _lib
-    assert lib.svcmi_abi_version() == _lib.ABI_VERSION == 21
+    assert lib.svcmi_abi_version() == _lib.ABI_VERSION == 22
 
 
 def test_binding_table_matches_header():

@@ -193,6 +193,11 @@ def test_kernels_do_not_depend_on_the_thread_order_inside_a_barrier_interval(ops
     K.check_splitk_layernorm(ops, "cpu", B=1, S=3, T=5, c=1280)
 
 
-@pytest.mark.parametrize("tile,n,cin,k,T", [(1, 70, 64, 5, 150), (6, 80, 64, 5, 150), (4, 40, 40, 3, 300), (1, 70, 32, 1, 90), (3, 70, 64, 3, 150)])
+@pytest.mark.parametrize("tile,n,cin,k,T", [(1, 70, 64, 5, 150), (6, 80, 64, 5, 150), (4, 40, 40, 3, 300), (1, 70, 32, 1, 90), (3, 70, 64, 3, 150), (10, 150, 64, 3, 200)])
 def test_conv_gemm_two_deep_ring_is_bit_identical(ops, tile, n, cin, k, T):
     K.check_conv_ring2(ops, "cpu", tile, n, cin=cin, k=k, T=T)
+
+
+@pytest.mark.parametrize("n,cin,k,T,partials", [(200, 64, 3, 300, False), (70, 40, 5, 150, False), (160, 128, 1, 260, True)])
+def test_conv_gemm_eight_wave_tile_equals_the_four_wave_tile(ops, n, cin, k, T, partials):
+    K.check_conv_w8(ops, "cpu", n, cin=cin, k=k, T=T, partials=partials)

@@ -13,18 +13,21 @@ extern "C" int svcmi_conv_gemm_f32(const svcmi_conv_desc* d, void* stream) {
     int p16_nt = 0, p16_wm = 1;
     const int n16 = (d->n_out + 15) / 16;
     const bool p16_ok = mode == MODE_CHUNK || mode == MODE_VEC;
-    if (tile > SVCMI_CONV_TILE_P16_64x160) return SVCMI_EUNSUPPORTED;      // (64x128 exists on the reduced-precision kernels only)
+    if (tile > SVCMI_CONV_TILE_P16_64x160 && tile != SVCMI_CONV_TILE_P16W8_128x80) return SVCMI_EUNSUPPORTED;      // (64x128 exists on the reduced-precision kernels only)
+    int p16_nw = 4;                                                // waves per block of the 16x16x4 policy
     if (tile >= SVCMI_CONV_TILE_P16_64x48) {                       // explicit override (tuning / tests)
         if (!p16_ok) return SVCMI_EUNSUPPORTED;
         p16_nt = tile == SVCMI_CONV_TILE_P16_64x160 ? 10 : (tile >= SVCMI_CONV_TILE_P16_64x80 ? 5 : 3);
         p16_wm = (tile == SVCMI_CONV_TILE_P16_128x48 || tile == SVCMI_CONV_TILE_P16_128x80) ? 2 : 1;
+        if (tile == SVCMI_CONV_TILE_P16W8_128x80) p16_nw = 8;
     } else if (!tile && p16_ok && (n16 == 3 || n16 == 5) && d->t_out >= 1024) {
         // measured on MI355X (scripts/microbench.py p16): 64x80 beats 2 x (64x64) by 18 % at 80 channels, 64x48 beats 64x64
         // by 13 % at 40; the 128-row variants lose (half the blocks), and at 160 channels / 5000 rows 64x160 only ties
         p16_nt = n16;
     }
     if (p16_nt) {
-        blocks64 = (long long)((d->t_out + 64 * p16_wm - 1) / (64 * p16_wm)) * d->batch;
+        const int bm16 = 16 * p16_wm * p16_nw;
+        blocks64 = (long long)((d->t_out + bm16 - 1) / bm16) * d->batch;
         tile = SVCMI_CONV_TILE_64x64;       // (only steers the split-K branch below)
     }
     if (!tile) {
@@ -55,13 +58,14 @@ extern "C" int svcmi_conv_gemm_f32(const svcmi_conv_desc* d, void* stream) {
     }
 
     if (a.split > 1 && d->counters && !(d->flags & SVCMI_CONV_PARTIALS)) {       // in-launch combine needs one zeroed counter per output tile
-        const int bm = p16_nt ? 64 * p16_wm : (tile == SVCMI_CONV_TILE_64x64 ? 64 : 128);
+        const int bm = p16_nt ? 16 * p16_wm * p16_nw : (tile == SVCMI_CONV_TILE_64x64 ? 64 : 128);
         const int bn = p16_nt ? 16 * p16_nt : (tile == SVCMI_CONV_TILE_128x128 ? 128 : 64);
         const long long tiles = (long long)d->batch * ((d->t_out + bm - 1) / bm) * ((d->n_out + bn - 1) / bn);
         if (tiles <= d->counters_len && d->n_out % 4 == 0 && (((uintptr_t)d->workspace & 15) == 0) &&
             (long long)d->t_out * d->n_out < (1LL << 29)) a.cnt = d->counters;      // 16-byte write-through slab stores
     }
     if (p16_nt == 3) return p16_wm == 2 ? launch<2, 3, true>(a, d->batch, mode, stream) : launch<1, 3, true>(a, d->batch, mode, stream);
+    if (p16_nt == 5 && p16_nw == 8) return launch<1, 5, true, PREC_F32, 8>(a, d->batch, mode, stream);
     if (p16_nt == 5) return p16_wm == 2 ? launch<2, 5, true>(a, d->batch, mode, stream) : launch<1, 5, true>(a, d->batch, mode, stream);
     if (p16_nt == 10) return launch<1, 10, true>(a, d->batch, mode, stream);
     switch (tile) {
@@ -118,5 +122,18 @@ extern "C" int svcmi_conv_tune_set(const char* name, int32_t value) {
 // timing-probe builds only (conv_gemm_body.h, SVCMI_PROBE_KTRACE): the per-wave K-loop cycle sums of the LAST fp32 launch
 extern "C" int svcmi_probe_ktrace_read(unsigned long long* dst, int n) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_ktrace), (size_t)n * 8, 0, hipMemcpyDeviceToHost);
+}
+// ... and the in-flight timeline: reset the record counter / read the first `cap` records (5 x u64 each); returns the number recorded
+extern "C" int svcmi_probe_timeline_reset(void) {
+    const unsigned zero = 0;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_tl_n), &zero, 4, 0, hipMemcpyHostToDevice);
+}
+extern "C" long long svcmi_probe_timeline_read(unsigned long long* dst, long long cap) {
+    unsigned n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_tl_n), 4, 0, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    long long m = n < TL_CAP ? n : TL_CAP;
+    if (m > cap) m = cap;
+    if (m > 0 && hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_tl), (size_t)m * 40, 0, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return m;
 }
 #endif

@@ -90,6 +90,13 @@ namespace {
 #ifndef SVCMI_PROBE_KTRACE_N      // record only launches with this n_out (0 = every launch: the last one stays)
 #define SVCMI_PROBE_KTRACE_N 0
 #endif
+// In-flight timeline (round 6): rocprofv3 serialises the four HIP queues of the judged launch regime, so what overlaps
+// with what while clips are in flight has to be recorded by the kernels themselves.  EVERY block of every implicit-GEMM launch appends one
+// record {s_memrealtime at entry, at the end of its epilogue, output pointer (= which lane and layer), n_out << 32 | K, rows} to g_tl
+// (one atomic add + 40 bytes per block); scripts/inflight_timeline.py groups the blocks into launches and reconstructs the timeline.
+constexpr unsigned TL_CAP = 1u << 22;            // records (168 MB)
+__device__ unsigned long long g_tl[5ull * TL_CAP];
+__device__ unsigned g_tl_n;
 __device__ unsigned long long g_ktrace[4 * 4 * 8192 + 8];      // + block 0 wave 0: {loop s_memtime ticks, loop s_memrealtime ticks (100 MHz), entry -> first barrier exit, last barrier exit -> end of the epilogue, launches recorded}
 #endif
 // Build switch (round 6): the refill's DMA pieces of the pinned loop spread over a WHOLE K-step instead of its last sub-step -- the first half
@@ -184,8 +191,15 @@ constexpr unsigned OOB = 0x40000000u;   // added to an offset that must read as 
 //                right-sized N for the 40 / 80 / 160-channel generator stages (a 64-multiple pads them by 60 / 60 / 20 %),
 //                and since fp32 MFMA time is proportional to the padded tile, that padding is pure loss.
 // `grid_blocks` / `block_id`: the launch geometry of THIS problem (a grouped launch runs several problems back to back in one grid).
-template <int WM, int WN, int MODE, bool P16, int NSTO = 0, int PREC = PREC_F32>
+//   P16 = true, NW = 8 (round 6): the same wave tile on EIGHT waves -> block (128*WM) x (16*WN), 512 threads.  M = 500 x N = 5120 is then 256
+//                blocks = one per CU with today's two waves per SIMD, and the CU fills 128 + 80 rows per K-step instead of 2 x (64 + 80):
+//                26 instead of 36 KB -- the K-step of the 64x80 tile costs 2500 cycles without its LDS-DMA issues and 3040 with them
+//                (profiles/r06a_kprobe.log, r06e_ktrace_in_pipeline.log), so the pieces per FLOP are what is left to cut.  Same wave tile, same
+//                K order: the same bits as the four-wave tile.
+template <int WM, int WN, int MODE, bool P16, int NSTO = 0, int PREC = PREC_F32, int NW = 4>
 __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid_blocks, const int block_id) {
+    static_assert(NW == 4 || (NW == 8 && P16 && PREC == PREC_F32), "eight-wave blocks: fp32 16x16x4 policy only");
+    constexpr int NT = 64 * NW;                       // threads per block
     constexpr bool A16 = PREC >= PREC_BF16_A16;       // 16-bit activations AND weights in the fp32 kernel's tile geometry, K-step 64
     constexpr bool LP = PREC != PREC_F32 && !A16;     // 16-bit weight image(s) in 64-byte rows, fp32 activations rounded in registers
     constexpr int KS = A16 ? 2 * BK : BK;             // k per K-step
@@ -195,16 +209,16 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
     constexpr bool W2A = PREC == PREC_F16W2_A16;      // ... fp16 activations x (hi, lo) fp16 weights
     constexpr int NB = (PREC == PREC_BF16X3 || X3A || W2A) ? 2 : 1;   // B images per stage (hi, lo)
     constexpr int NA = X3A ? 2 : 1;                   // A images per stage
-    constexpr int BM = 64 * WM, BN = P16 ? 16 * WN : 64 * WN;
+    constexpr int BM = P16 ? 16 * WM * NW : 64 * WM, BN = P16 ? 16 * WN : 64 * WN;
     constexpr int BROW = LP ? BK / 2 : BK;            // floats per B row in LDS (LP: 32 x 2 bytes)
-    constexpr int BNL = LP ? (BN + 63) / 64 * 64 : (BN + 31) / 32 * 32;   // B rows held in LDS (whole 4-wave DMA rounds)
-    constexpr int A_PER = BM / 32, B_PER = LP ? BNL / 64 : BNL / 32;      // 1-KiB LDS-DMA pieces (8 x 128 B or 16 x 64 B rows) per wave per K-step (per image)
+    constexpr int BNL = LP ? (BN + 63) / 64 * 64 : (BN + 8 * NW - 1) / (8 * NW) * (8 * NW);   // B rows held in LDS (whole NW-wave DMA rounds)
+    constexpr int A_PER = BM / (8 * NW), B_PER = LP ? BNL / 64 : BNL / (8 * NW);      // 1-KiB LDS-DMA pieces (8 x 128 B or 16 x 64 B rows) per wave per K-step (per image)
     constexpr int BTILE = BNL * BROW;                 // floats per B image per stage
     constexpr int CLD = BN;                           // epilogue staging tile [BM][BN] reuses the operand buffers
     // LDS ring of NST operand tiles (48 / 72 / 64 KiB per block): tile it+NST-1 is in flight while tile
     // `it` is consumed, so a K-step never waits a full HBM/L2 round trip -- what short K ranges (split-K slices,
     // the k=1 projections of the prior encoder / flow, k=3 convolutions) would otherwise pay on every step.
-    constexpr int NST = NSTO ? NSTO : (X3A || (W2A && P16)) ? 2 : (LP ? 3 : (P16 ? ((BM + BNL) > 192 ? 2 : 3) : ((WM * WN == 1) ? 3 : (WM * WN == 2 ? 3 : 2))));
+    constexpr int NST = NSTO ? NSTO : NW == 8 ? 3 : (X3A || (W2A && P16)) ? 2 : (LP ? 3 : (P16 ? ((BM + BNL) > 192 ? 2 : 3) : ((WM * WN == 1) ? 3 : (WM * WN == 2 ? 3 : 2))));
     constexpr int RING = NST * (NA * BM * BK + NB * BTILE);
     static_assert(LP || A16 || BM * CLD <= RING, "C tile must fit in the operand buffers");
     // + the split-K ticket word (4 floats) + the tile's bias values (round 6: one 4-byte LDS-DMA per 64 columns in front of the first
@@ -215,8 +229,8 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
     float* const Bs0 = smem + NST * NA * BM * BK;          // Bs[slot][image] = Bs0 + (slot*NB + image)*BTILE
 
 #if SVCMI_PROBE_KTRACE
-    unsigned long long kt_entry;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(kt_entry));
+    unsigned long long kt_entry, tl_entry;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(kt_entry), "=s"(tl_entry));
 #endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = SVCMI_UNIFORM((int)(tid >> 6));
@@ -258,7 +272,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
     unsigned b_row[B_PER];
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
-        const int t = m0 + (wave + 4 * i) * 8 + prow;
+        const int t = m0 + (wave + NW * i) * 8 + prow;
         a_tb[i] = t * p.stride - p.pad;
         a_row[i] = t < p.t_out ? (unsigned)a_tb[i] * (unsigned)p.ldx * ESZ : OOB;
         if (t >= p.t_out) a_tb[i] = -0x40000000;
@@ -266,8 +280,10 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
         // LP: a piece is 16 rows of 64 bytes, lane l -> row l>>2, position l&3
-        const int n = n0 + (wave + 4 * i) * (LP ? 16 : 8) + (LP ? (lane >> 2) : prow);
-        b_row[i] = n < p.n_out ? ((LP || A16) ? (unsigned)(n * NB * p.ldw16) * 2u : (unsigned)(n * p.ldw) * 4u) : OOB;
+        const int nl = (wave + NW * i) * (LP ? 16 : 8) + (LP ? (lane >> 2) : prow), n = n0 + nl;
+        // (rows of the DMA round behind the tile's last column are never fetched: they used to pull the NEXT tile's weights through L2
+        //  into LDS rows nobody reads -- 2 of the 12 B pieces of the 64x80 tile, 2 of 8 at 64x48)
+        b_row[i] = (n < p.n_out && nl < BN) ? ((LP || A16) ? (unsigned)(n * NB * p.ldw16) * 2u : (unsigned)(n * p.ldw) * 4u) : OOB;
     }
     const int lkq16 = ((lane & 3) ^ swz16(lane >> 2)) * 16;    // LP: this lane's byte offset within the 64-byte K-step of a B row
     // CHUNK mode: wave-uniform (tap, first channel) of the K-step, advanced incrementally
@@ -314,10 +330,10 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
     auto stage_a = [&](int it, int buf, int i, auto&... tie) {          // piece i of the A tile (X3A: i >= A_PER = the lo image); tie: svcmi_bdma16_at
         if constexpr (X3A) {
             const int im = i >= A_PER, ii = i - im * A_PER;
-            svcmi_bdma16(a_row[ii] + a_koff + (im ? (unsigned)p.ldx : 0u), svcmi_lds_advance(lds_a, (buf * NA + im) * BM * BK + 4 * ii * 8 * BK), xr);
+            svcmi_bdma16(a_row[ii] + a_koff + (im ? (unsigned)p.ldx : 0u), svcmi_lds_advance(lds_a, (buf * NA + im) * BM * BK + NW * ii * 8 * BK), xr);
             return;
         }
-        const svcmi_ldsaddr dst = svcmi_lds_advance(lds_a, buf * BM * BK + 4 * i * 8 * BK);
+        const svcmi_ldsaddr dst = svcmi_lds_advance(lds_a, buf * BM * BK + NW * i * 8 * BK);
         if (MODE == MODE_SCALAR) {
             // 4-byte DMA: a wave-instruction fills 2 rows (64 floats); the piece needs 4 of them.
 #pragma unroll
@@ -325,7 +341,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
                 const int rr = 2 * h + (lane >> 5);                  // row within the piece
                 const int pc = (lane & 31) >> 2, e = lane & 3;       // physical chunk, element
                 const int q = it * BK + ((pc ^ swz(rr + 8 * wave)) << 2) + e;   // logical k of this LDS word
-                const int t = m0 + (wave + 4 * i) * 8 + rr;
+                const int t = m0 + (wave + NW * i) * 8 + rr;
                 const int k = div_magic(q, p.magic), ci = q - k * p.c_in;
                 const int tin = t * p.stride - p.pad + k * p.dil;
                 const bool ok = t < p.t_out && q < p.ktot && (unsigned)tin < (unsigned)t_lim;
@@ -340,8 +356,8 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
         }
     };
     auto stage_b = [&](int buf, int i, auto&... tie) {                  // piece i of the B tile(s): i < B_PER hi (or fp32), then the lo image
-        if (i < B_PER) svcmi_bdma16_at(b_row[i] + b_koff, svcmi_lds_advance(lds_b, buf * NB * BTILE + 4 * i * 8 * BK), wr, tie...);
-        else svcmi_bdma16(b_row[i - B_PER] + b_koff + (unsigned)p.ldw16 * 2u, svcmi_lds_advance(lds_b, (buf * NB + 1) * BTILE + 4 * (i - B_PER) * 8 * BK), wr);
+        if (i < B_PER) svcmi_bdma16_at(b_row[i] + b_koff, svcmi_lds_advance(lds_b, buf * NB * BTILE + NW * i * 8 * BK), wr, tie...);
+        else svcmi_bdma16(b_row[i - B_PER] + b_koff + (unsigned)p.ldw16 * 2u, svcmi_lds_advance(lds_b, (buf * NB + 1) * BTILE + NW * (i - B_PER) * 8 * BK), wr);
     };
 
     // fragment addresses.  32x32x2: row (lane&31) of the wave tile, logical chunk 2s + (lane>>5), 4 sub-steps of 8 k;
@@ -808,7 +824,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
     __syncthreads();         // last tile fully consumed before the buffers are reused below
 #if SVCMI_PROBE_KTRACE
     const bool kt_on = SVCMI_PROBE_KTRACE_N == 0 || p.n_out == SVCMI_PROBE_KTRACE_N;
-    if (kt_on && lane == 0 && block_id < 8192) {
+    if (kt_on && lane == 0 && block_id < 8192 && wave < 4) {
         unsigned long long* kt = g_ktrace + 4 * (block_id * 4 + wave);
         kt[0] = kt_step; kt[1] = kt_vm; kt[2] = kt_bar; kt[3] = kt_n;
         if (block_id == 0 && wave == 0) { g_ktrace[4 * 4 * 8192] = kt_prev - kt_first; g_ktrace[4 * 4 * 8192 + 1] = kt_r1 - kt_r0; g_ktrace[4 * 4 * 8192 + 2] = kt_first - kt_entry; }
@@ -816,6 +832,16 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
     unsigned long long kt_a, kt_b = 0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(kt_a)::"memory");
     auto kt_finish = [&] {
+        if (tid == 0) {       // timeline record of this block (every launch, every block)
+            unsigned long long te;
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(te)::"memory");
+            const unsigned idx = atomicAdd(&g_tl_n, 1u);
+            if (idx < TL_CAP) {
+                unsigned long long* r = g_tl + 5ull * idx;
+                r[0] = tl_entry; r[1] = te; r[2] = (unsigned long long)(size_t)p.y ^ ((unsigned long long)(size_t)p.ws << 1);
+                r[3] = ((unsigned long long)(unsigned)p.n_out << 32) | (unsigned)p.ktot; r[4] = ((unsigned long long)(unsigned)grid_blocks << 32) | (unsigned)p.t_out;
+            }
+        }
         if (kt_on && block_id == 0 && tid == 0) {
             unsigned long long t, tc;
             asm volatile("s_memtime %1\n\ts_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t), "=s"(tc)::"memory");
@@ -857,7 +883,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
         float* wsb = p.ws + ((long long)b * p.split + slice) * p.t_out * p.n_out;
         if (!p.cnt) {        // no ticket counters: splitk_reduce_kernel sums the slabs in a second launch
             if (p.vec) {
-                for (int e = tid; e < BM * (BN / 4); e += 256) {
+                for (int e = tid; e < BM * (BN / 4); e += NT) {
                     const int ml = e / (BN / 4), nl = (e - ml * (BN / 4)) * 4;
                     if (ml < mvalid && nl < nvalid)
                         *reinterpret_cast<float4*>(wsb + (long long)(m0 + ml) * p.n_out + n0 + nl) = *reinterpret_cast<const float4*>(Cs + ml * CLD + nl);
@@ -865,10 +891,11 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
                 kt_finish();
                 return;
             }
-            for (int e = tid; e < BM * BN; e += 256) {
+            for (int e = tid; e < BM * BN; e += NT) {
                 const int ml = e / BN, nl = e - ml * BN;
                 if (ml < mvalid && nl < nvalid) wsb[(long long)(m0 + ml) * p.n_out + n0 + nl] = Cs[ml * CLD + nl];
             }
+            kt_finish();
             return;
         }
         // In-launch combine (cdna_hip_programming.md section 5, "in-launch split-K reduction", write-through form): the
@@ -878,7 +905,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
         // sums all slabs IN SLICE ORDER (its own included, from memory): the result does not depend on who is last.
         {
             const svcmi_rsrc sr = svcmi_make_rsrc(wsb, (unsigned)p.t_out * (unsigned)p.n_out * 4u);   // n_out % 4 == 0 here
-            for (int e = tid; e < BM * BN / 4; e += 256) {
+            for (int e = tid; e < BM * BN / 4; e += NT) {
                 const int ml = e / (BN / 4), nl = (e - ml * (BN / 4)) * 4;
                 if (ml < mvalid && nl < nvalid)
                     svcmi_store16_sc1(*reinterpret_cast<const svcmi_f32x4*>(Cs + ml * CLD + nl), sr,
@@ -891,7 +918,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
         const int tile_id = (b * p.nt + by) * p.mt + bx;
         if (tid == 0) *flag = svcmi_ticket(p.cnt + tile_id);
         __syncthreads();
-        if (*flag != p.split - 1) return;
+        if (*flag != p.split - 1) { kt_finish(); return; }
         if (tid == 0) {
             SVCMI_ACQUIRE_AGENT();
             p.cnt[tile_id] = 0;                             // leave the counter ready for the next launch
@@ -901,7 +928,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
         const float* rb2 = p.res ? p.res + (long long)b * p.r_bs : nullptr;
         const float* ws0 = p.ws + (long long)b * p.split * p.t_out * p.n_out;
         const long long sstride = (long long)p.t_out * p.n_out;
-        for (int e = tid; e < BM * BN; e += 256) {
+        for (int e = tid; e < BM * BN; e += NT) {
             const int ml = e / BN, nl = e - ml * BN;
             if (ml >= mvalid || nl >= nvalid) continue;
             const int t = m0 + ml, n = n0 + nl;
@@ -912,6 +939,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
             *dst = epilogue(p, v, smem[BIAS0 + nl], rb2 ? rb2 + (long long)t * p.ldr : nullptr, dst, n,
                             (p.flags & SVCMI_CONV_MASK_OUT) && t >= len);
         }
+        kt_finish();
         return;
     }
     float* yb = p.y + (long long)b * p.y_bs;
@@ -928,8 +956,8 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
         //  * the bias comes from the tile's LDS copy (one 4-byte LDS-DMA per 64 columns in front of the first operand tile);
         //  * the activation is chosen OUTSIDE the loop: with the switch inside, every element walked ~10 scalar branches to its arm.
         const bool acc_on = (p.flags & SVCMI_CONV_ACCUMULATE) != 0;
-        constexpr int EP_IT = BM * (BN / 4) / 256;
-        static_assert(BM * (BN / 4) % 256 == 0, "whole epilogue iterations");
+        constexpr int EP_IT = BM * (BN / 4) / NT;
+        static_assert(BM * (BN / 4) % NT == 0, "whole epilogue iterations");
         constexpr unsigned NOWHERE = 0x80000000u;
         const svcmi_brsrc ry = svcmi_make_brsrc(yb + (long long)m0 * p.ldy + n0, 0x7fffffffu);           // tile origin; lane offsets < 128 rows x ld (prepare: ld < 2^22)
         const svcmi_brsrc rr = svcmi_make_brsrc(rbp ? rbp + (long long)m0 * p.ldr + n0 : nullptr, rbp ? 0x7fffffffu : 0u);
@@ -951,16 +979,16 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
             }
 #pragma nounroll
             for (int i = 0; i < EP_IT; ++i) {
-                const int e = tid + 256 * i;
+                const int e = tid + NT * i;
                 const int ml = e / (BN / 4), nl = (e - ml * (BN / 4)) * 4;
                 const unsigned oy = oy_n;
                 const svcmi_f32x4 rv = rv_n, yo = yo_n;
                 if constexpr (LOADS) {
-                    where(e + 256, oy_n, or_n);              // (past the last iteration: rows >= BM >= mvalid, nothing is fetched)
+                    where(e + NT, oy_n, or_n);              // (past the last iteration: rows >= BM >= mvalid, nothing is fetched)
                     rv_n = svcmi_buf_load16(rr, or_n);
                     yo_n = svcmi_buf_load16(ry, acc_on ? oy_n : NOWHERE);
                 } else {
-                    where(e + 256, oy_n, or_n);
+                    where(e + NT, oy_n, or_n);
                 }
                 const int t = m0 + ml;
                 const float4 c = *reinterpret_cast<const float4*>(Cs + ml * CLD + nl), bs = *reinterpret_cast<const float4*>(smem + BIAS0 + nl);
@@ -995,7 +1023,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
         kt_finish();
         return;
     }
-    for (int e = tid; e < BM * BN; e += 256) {
+    for (int e = tid; e < BM * BN; e += NT) {
         const int ml = e / BN, nl = e - ml * BN;
         if (ml >= mvalid || nl >= nvalid) continue;
         const int t = m0 + ml, n = n0 + nl;
@@ -1003,6 +1031,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
         *dst = epilogue(p, Cs[ml * CLD + nl], smem[BIAS0 + nl], rbp ? rbp + (long long)t * p.ldr : nullptr, dst, n,
                         mask_out && t >= len);
     }
+    kt_finish();
 }
 
 // Build experiment (scripts/build_variant.sh nst2 -DSVCMI_GEMM_NST=2): ring depth of the single-launch fp32 kernels.  The default 3-deep
@@ -1011,9 +1040,9 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& p, const int grid
 #ifndef SVCMI_GEMM_NST
 #define SVCMI_GEMM_NST 0
 #endif
-template <int WM, int WN, int MODE, bool P16, int PREC = PREC_F32, int NSTO = 0>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
-    conv_gemm_body<WM, WN, MODE, P16, (NSTO ? NSTO : (PREC == PREC_F32 && WM * WN <= 5 ? SVCMI_GEMM_NST : 0)), PREC>(p, (int)gridDim.x, (int)blockIdx.x);
+template <int WM, int WN, int MODE, bool P16, int PREC = PREC_F32, int NSTO = 0, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void conv_gemm_kernel(ConvArgs p) {
+    conv_gemm_body<WM, WN, MODE, P16, (NSTO ? NSTO : (PREC == PREC_F32 && WM * WN <= 5 ? SVCMI_GEMM_NST : 0)), PREC, NW>(p, (int)gridDim.x, (int)blockIdx.x);
 }
 
 // Grouped launch: up to GROUP_MAX problems of identical tile policy / gather mode in ONE grid, blocks of problem 0 first.  The
@@ -1052,9 +1081,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs p, int batc
     }
 }
 
-template <int WM, int WN, bool P16, int PREC = PREC_F32>
+template <int WM, int WN, bool P16, int PREC = PREC_F32, int NW = 4>
 int launch(const ConvArgs& a_in, int batch, int mode, void* stream) {
-    constexpr int BM = 64 * WM, BN = P16 ? 16 * WN : 64 * WN;
+    constexpr int BM = P16 ? 16 * WM * NW : 64 * WM, BN = P16 ? 16 * WN : 64 * WN;
     ConvArgs a = a_in;
     a.mt = (a.t_out + BM - 1) / BM;
     a.nt = (a.n_out + BN - 1) / BN;
@@ -1063,6 +1092,26 @@ int launch(const ConvArgs& a_in, int batch, int mode, void* stream) {
     dim3 grid((unsigned)blocks);
     // SVCMI_CONV_RING2: the 2-deep ring of the 64-row fp32 tiles (one more resident block per CU; for launches that share the chip)
     constexpr bool HAS_RING2 = PREC == PREC_F32 && WM == 1 && (P16 ? (WN == 3 || WN == 5) : WN == 1);
+    if constexpr (NW == 8) {          // eight-wave blocks (fp32, 16x16x4 policy, vector gathers): 3-deep ring, or 2-deep with SVCMI_CONV_RING2
+        if (mode != MODE_CHUNK && mode != MODE_VEC) return SVCMI_EUNSUPPORTED;
+        const bool r2 = (a.flags & SVCMI_CONV_RING2) != 0;
+        if (mode == MODE_CHUNK) {
+            if (r2) SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_CHUNK, P16, PREC, 2, 8>), grid, dim3(512), 0, stream, a);
+            else SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_CHUNK, P16, PREC, 3, 8>), grid, dim3(512), 0, stream, a);
+        } else {
+            if (r2) SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_VEC, P16, PREC, 2, 8>), grid, dim3(512), 0, stream, a);
+            else SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_VEC, P16, PREC, 3, 8>), grid, dim3(512), 0, stream, a);
+        }
+        int rc8 = SVCMI_LAST_ERROR();
+        if (rc8 == 0 && a.split > 1 && !a.cnt && !(a.flags & SVCMI_CONV_PARTIALS)) {
+            const long long total = (long long)batch * a.t_out * a.n_out;
+            long long nb = (total + 255) / 256;
+            if (nb > 2048) nb = 2048;
+            SVCMI_LAUNCH(splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream, a, batch);
+            rc8 = SVCMI_LAST_ERROR();
+        }
+        return rc8;
+    }
     bool ring2 = false;
     if constexpr (HAS_RING2) ring2 = (a.flags & SVCMI_CONV_RING2) && (mode == MODE_CHUNK || mode == MODE_VEC);
     if (ring2) {

@@ -311,11 +311,13 @@ __device__ __forceinline__ void store_orow(float* orow, int g4, const svcmi_f32x
     }
 }
 
-template <int D, int NS>
+// REL (round 6: a template parameter, was a run-time flag): the relative-position band.  The band-free instantiation (Whisper) carries none of
+// its code and none of its 18 registers (R[] / Pb[]) -- at the 64-register budget of 4 waves per SIMD those were accumulator-file spills.
+template <int D, int NS, bool REL = true>
 __global__ __launch_bounds__(64 * NS) void attention_kernel(AttnArgs p) {
     constexpr int DS = D / 16;         // 16-wide d groups: float4 K/Q fragments per row and 16-row tiles of O^T
     constexpr int OLD = D + 4;         // padded row of the partial-O tile: conflict-free ds_write_b128
-    __shared__ __attribute__((aligned(16))) float smem[NS * 16 * OLD + 2 * NS * 16 + NS * 16 * BST + 2 * NREL * D];
+    __shared__ __attribute__((aligned(16))) float smem[NS * 16 * OLD + 2 * NS * 16 + (REL ? NS * 16 * BST + 2 * NREL * D : 0)];
     float* const Opart = smem;                         // [NS][16][OLD]
     float* const Mpart = Opart + NS * 16 * OLD;        // [NS][16]
     float* const Lpart = Mpart + NS * 16;              // [NS][16]
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(64 * NS) void attention_kernel(AttnArgs p) {
     const int h = hb % p.heads, b = hb / p.heads;
     const int T = p.t;
     const int len = p.lengths ? p.lengths[b] : T;
-    const bool has_rel = p.rel_k != nullptr;
+    const bool has_rel = REL && p.rel_k != nullptr;
     const int W = p.window;
     const int nrel = has_rel ? 2 * W + 1 : 0;
     const float scale2 = p.scale * LOG2E;              // softmax in the log2 domain (v_exp_f32 computes 2^x)
@@ -1486,6 +1488,15 @@ int launch_attn(const AttnArgs& a_in, int batch, void* stream) {
             }
             return SVCMI_LAST_ERROR();
         }
+    }
+    if (!a.rel_k) {
+        switch (ns) {
+            case 1: SVCMI_LAUNCH((attention_kernel<D, 1, false>), grid, dim3(64), 0, stream, a); break;
+            case 2: SVCMI_LAUNCH((attention_kernel<D, 2, false>), grid, dim3(128), 0, stream, a); break;
+            case 4: SVCMI_LAUNCH((attention_kernel<D, 4, false>), grid, dim3(256), 0, stream, a); break;
+            default: SVCMI_LAUNCH((attention_kernel<D, 8, false>), grid, dim3(512), 0, stream, a); break;
+        }
+        return SVCMI_LAST_ERROR();
     }
     switch (ns) {
         case 1: SVCMI_LAUNCH((attention_kernel<D, 1>), grid, dim3(64), 0, stream, a); break;

@@ -8,7 +8,7 @@ DEFAULT_LIB = os.path.join(HERE, "libsvcmi.so")
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_MISH, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4, 5
 CONV_ACCUMULATE, CONV_MASK_IN, CONV_MASK_OUT, CONV_PARTIALS = 1, 2, 4, 8
-ABI_VERSION = 21
+ABI_VERSION = 22
 PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16, PREC_BF16_A16, PREC_F16_A16, PREC_BF16X3_A16 = 0, 1, 2, 3, 4, 5, 6
 PRECISIONS = {None: 0, "f32": 0, "fp32": 0, "bf16x3": 1, "bf16": 2, "f16": 3, "fp16": 3, "f16w2": 8}
 PREC_F16W2, PREC_F16W2_A16 = 8, 9          # fp16 activations x split fp16 weights: a mode like f16 whose 16-bit-activation launches take two MFMAs on (hi, lo) weight images
