@@ -474,6 +474,74 @@ def ranks_seen(world, device):
     return int(t.item())
 
 
+def dry_run(args, rank, world, C, W, D, PW):
+    """`--dry-run`: everything of a multi-rank bench job that is NOT the GPU pipeline, executed for real on CPU over gloo (the
+    exact command the driver launches -- torch.distributed.run, N ranks, `--gpus N --config 3` -- has run end to end once before a multi-GPU
+    node sees it).  Rank 0 packs tiny seeded weights, ONE broadcast per model ships the packed arena, every rank plans its shard
+    (svcmi.dist.plan_batches), the timed region is bracketed by barriers, the step time is the max over ranks, and the all-reduce of ones
+    must return the world size.  The stand-in "pipeline" only records which utterances this rank converted."""
+    import torch.distributed as dist
+    hp = C.tiny_hp()
+    vw = PW.VitsWeights(W.make_vits_state(hp, seed=1234), hp, "cpu") if rank == 0 else None
+    ww = PW.WhisperWeights(W.make_whisper_state(C.WHISPER_TINY_TEST), "cpu") if rank == 0 else None
+    if world > 1:
+        vw = D.broadcast_packed(vw, 0, "cpu")
+        ww = D.broadcast_packed(ww, 0, "cpu")
+    digest = float(sum(b[k].double().abs().sum() for b in ww.blocks for k in b) + ww.pos.double().abs().sum())
+    if args.config == 3:
+        batches = D.plan_batches(args.utterances, world, rank, args.batch)
+    else:
+        batches = [[rank + world * i for i in range(args.batch)]]
+    converted = []
+
+    def step():
+        for b in batches:
+            converted.extend(b)             # the stand-in for: stage the batch, replay the lane's graph, copy the result out
+            time.sleep(0.001)
+
+    def timed(steps, warmup):
+        for _ in range(warmup):
+            step()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+    del converted[:]
+    dt = timed(args.steps, args.warmup)
+    mine = sorted(set(converted))
+    seen = ranks_seen(world, "cpu")
+    info = [None] * world
+    if world > 1:
+        dist.all_gather_object(info, (rank, len(mine), digest, mine if args.config == 3 else None))
+    else:
+        info = [(rank, len(mine), digest, mine if args.config == 3 else None)]
+    if rank == 0:
+        ok_weights = len({round(d, 6) for (_, _, d, _) in info}) == 1
+        covered = sorted(i for (_, _, _, m) in info if m for i in m) == list(range(args.utterances)) if args.config == 3 else None
+        print(json.dumps({
+            "metric": "audio-seconds/sec end-to-end SVC @32kHz, 10s clips (Whisper-PPG -> flow -> NSF-BigVGAN)", "value": None, "unit": "audio-seconds/sec",
+            "dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000.0 * dt / max(args.steps, 1), 3),
+            "higher_is_better": True, "scaling": "strong" if args.config == 3 else "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "none (dry run: tiny seeded weights, stand-in pipeline)",
+            "config": {"workload": f"configs[{args.config}] launch contract on CPU", "world_size": world, "dist_backend": dist.get_backend() if world > 1 else None,
+                       "rccl_ranks_seen": seen, "utterances_per_rank": [n for (_, n, _, _) in sorted(info)], "batches_on_rank0": [len(b) for b in batches],
+                       "weights_identical_on_every_rank": ok_weights, "every_utterance_exactly_once": covered,
+                       "weights": "rank 0 packs, one broadcast of the packed arena per model" if world > 1 else "packed on this rank"}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -491,6 +559,10 @@ def main():
                          "for config 1 (config.single_stream then reports the one-clip-at-a-time figure too), 1 otherwise")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-single-stream", action="store_true", help="skip the one-clip-at-a-time timing that accompanies --inflight > 1")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: the launch contract of a multi-rank job end to end on CPU over gloo -- real rendezvous, real packed-arena broadcast "
+                         "(tiny weights), real plan_batches / barriers / max-over-ranks timing / rccl_ranks_seen, a stand-in for the GPU pipeline.  "
+                         "Prints the JSON line with \"dry_run\": true and value null (nothing is measured)")
     ap.add_argument("--precision", default=None,
                     help="GEMM operand precision of BOTH networks (fp32 accumulate in every mode): f32 | bf16x3 | bf16 | f16 | mixed | "
                          "mixed:<class>=<mode>,... (per-layer policy of the synthesizer, svcmi._lib.MIXED_DEFAULT; Whisper then runs f16).  "
@@ -512,6 +584,8 @@ def main():
     from svcmi.whisper.inference import WhisperEncoderModel
     import torch.distributed as dist
 
+    if args.dry_run:
+        os.environ.setdefault("SVCMI_DIST_BACKEND", "gloo")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: never print an N = 1 line under an N > 1 flag.  Re-exec the same command as N
         # ranks (one per GPU) under torch.distributed.run -- the launch line the driver itself uses -- and hand its exit code back.
@@ -520,6 +594,8 @@ def main():
     if world != args.gpus:
         log(f"bench.py: WORLD_SIZE {world} != --gpus {args.gpus}: refusing to print a line for a job of another size")
         sys.exit(2)
+    if args.dry_run:
+        sys.exit(dry_run(args, rank, world, C, W, D, PW))
     assert torch.cuda.is_available(), "bench.py needs a GPU (svcmi has no CPU path)"
     if world > 1 and dist.get_backend() == "nccl" and torch.cuda.device_count() < min(world, int(os.environ.get("LOCAL_WORLD_SIZE", world))):
         log(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPUs visible (RCCL wants one device per rank)")

@@ -316,6 +316,9 @@ int svcmi_snake_post_f32(const float* x, const float* w, float* y, const float* 
  *              {2, 4, 8} query tiles x KS in {1, 2, 4} key ranges per block (1 = 4 x 2; compiled shapes 21 22 24 41 42 44 81 82)
  * Process-wide, not thread-safe against concurrent launches.  Returns 0, or SVCMI_EINVAL for an unknown name / value. */
 int svcmi_tune_set(const char* name, int32_t value);
+/* ABI 22: the current value of "ring2" / "amp_grouped" / "amp_lp" / "group_nst", and "last_conv_ring" = which instantiation the last
+ * svcmi_conv_gemm_f32 launch took: 2 = the SVCMI_CONV_RING2 one, 3 = the tile's default (tests assert which kernel a flag selected).  0, or SVCMI_EINVAL. */
+int svcmi_tune_get(const char* name, int32_t* value);
 
 /* WaveNet gate, vits/commons.py:126-133 with input_b == 0 (vits/modules.py:190-193):
  *   out[b, t, c] = tanh(v[b, t, c]) * sigmoid(v[b, t, h + c]),  c < h,  v = bias + sum_s a[b][s][t][:]

@@ -213,9 +213,13 @@ def check_conv_ring2(ops, device, tile, n, cin=64, k=5, T=150, B=2):
     bias = torch.randn(n, generator=g).to(device)
     res = torch.randn(B, T, n, generator=g).to(device)
     kw = dict(ksize=k, pad=(k - 1) // 2, act=ACT_GELU, res=res, split_k=1)
-    launches = ops.launches
+    import ctypes
+    ring = ctypes.c_int32(0)
     y3 = ops.conv(x, w, bias, tile=tile, **kw)
+    assert ops.lib.svcmi_tune_get(b"last_conv_ring", ctypes.byref(ring)) == 0 and ring.value == 3
     y2 = ops.conv(x, w, bias, tile=tile | 16, **kw)          # (tile << 8) | 0x1000 = SVCMI_CONV_RING2
+    # the flag is IGNORED where no 2-deep instantiation exists (128-row four-wave tiles): a regression that stops dispatching it must not pass silently
+    assert ops.lib.svcmi_tune_get(b"last_conv_ring", ctypes.byref(ring)) == 0 and ring.value == (2 if tile in (1, 4, 6, 10) else 3), (tile, ring.value)
     assert torch.equal(y2, y3), (tile, n, cin, k, float((y2 - y3).abs().max()))
     ref = F.gelu(F.conv1d(x.cpu().transpose(1, 2), w.cpu()[:, :cin * k].view(n, k, cin).permute(0, 2, 1).contiguous(), bias.cpu(), padding=(k - 1) // 2).transpose(1, 2)) + res.cpu()
     _close(y2, ref, 2e-5, f"ring2 tile {tile}")

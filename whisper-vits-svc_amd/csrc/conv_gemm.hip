@@ -1,4 +1,6 @@
 // conv_gemm.hip -- fp32 entry points of the implicit-GEMM convolution (kernel body: conv_gemm_body.h).
+#include <string.h>
+
 #include "conv_gemm_body.h"
 
 extern "C" int svcmi_conv_gemm_f32(const svcmi_conv_desc* d, void* stream) {
@@ -115,6 +117,12 @@ extern "C" int svcmi_conv_tune_set(const char* name, int32_t value) {
     int i = 0;
     while (k[i] && name[i] == k[i]) ++i;
     if (k[i] == 0 && name[i] == 0 && (value == 0 || value == 2 || value == 3)) { g_group_nst = value; return 0; }
+    return SVCMI_EINVAL;
+}
+
+extern "C" int svcmi_conv_tune_get(const char* name, int32_t* value) {
+    if (strcmp(name, "group_nst") == 0) { *value = g_group_nst; return 0; }
+    if (strcmp(name, "last_conv_ring") == 0) { *value = g_last_ring; return 0; }
     return SVCMI_EINVAL;
 }
 

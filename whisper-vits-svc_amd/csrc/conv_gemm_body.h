@@ -1081,6 +1081,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs p, int batc
     }
 }
 
+static int g_last_ring = 0;        // ring depth of the last single fp32 launch's instantiation (svcmi_tune_get("last_conv_ring"): tests assert the dispatch)
+
 template <int WM, int WN, bool P16, int PREC = PREC_F32, int NW = 4>
 int launch(const ConvArgs& a_in, int batch, int mode, void* stream) {
     constexpr int BM = P16 ? 16 * WM * NW : 64 * WM, BN = P16 ? 16 * WN : 64 * WN;
@@ -1095,6 +1097,7 @@ int launch(const ConvArgs& a_in, int batch, int mode, void* stream) {
     if constexpr (NW == 8) {          // eight-wave blocks (fp32, 16x16x4 policy, vector gathers): 3-deep ring, or 2-deep with SVCMI_CONV_RING2
         if (mode != MODE_CHUNK && mode != MODE_VEC) return SVCMI_EUNSUPPORTED;
         const bool r2 = (a.flags & SVCMI_CONV_RING2) != 0;
+        g_last_ring = r2 ? 2 : 3;
         if (mode == MODE_CHUNK) {
             if (r2) SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_CHUNK, P16, PREC, 2, 8>), grid, dim3(512), 0, stream, a);
             else SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_CHUNK, P16, PREC, 3, 8>), grid, dim3(512), 0, stream, a);
@@ -1114,6 +1117,7 @@ int launch(const ConvArgs& a_in, int batch, int mode, void* stream) {
     }
     bool ring2 = false;
     if constexpr (HAS_RING2) ring2 = (a.flags & SVCMI_CONV_RING2) && (mode == MODE_CHUNK || mode == MODE_VEC);
+    if constexpr (PREC == PREC_F32) g_last_ring = ring2 ? 2 : 3;       // (the default depth of the 128-row tiles is 2 as well: only the 64-row tiles have both)
     if (ring2) {
         if constexpr (HAS_RING2) {
             if (mode == MODE_CHUNK) SVCMI_LAUNCH((conv_gemm_kernel<WM, WN, MODE_CHUNK, P16, PREC, 2>), grid, dim3(256), 0, stream, a);

@@ -979,6 +979,16 @@ extern "C" int svcmi_struct_sizes(int64_t* out, int32_t cap) {
     return n < cap ? n : cap;
 }
 
+extern "C" int svcmi_conv_tune_get(const char* name, int32_t* value);      // conv_gemm.hip
+// The current value of a knob (ABI 22): a caller that changes one for a while restores what it found (svcmi.serving.ClipLanes).
+extern "C" int svcmi_tune_get(const char* name, int32_t* value) {
+    if (!name || !value) return SVCMI_EINVAL;
+    if (strcmp(name, "ring2") == 0) { *value = g_ring2; return 0; }
+    if (strcmp(name, "amp_grouped") == 0) { *value = g_amp_grouped; return 0; }
+    if (strcmp(name, "amp_lp") == 0) { *value = g_amp_lp; return 0; }
+    return svcmi_conv_tune_get(name, value);
+}
+
 extern "C" int svcmi_host_tune_set(const char* name, int32_t value) {
     if (strcmp(name, "amp_grouped") == 0 && (value == 0 || value == 1)) { g_amp_grouped = value; return 0; }
     if (strcmp(name, "amp_lp") == 0 && (value == 0 || value == 1)) { g_amp_lp = value; return 0; }

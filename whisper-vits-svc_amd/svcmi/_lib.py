@@ -182,6 +182,7 @@ SIGNATURES = {
     "svcmi_upsample_noise_supported": (c_int, [_I, _I, _I]),
     "svcmi_upsample_noise_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _L, _I, _I, _I, _I, _P]),
     "svcmi_tune_set": (c_int, [c_char_p, _I]),
+    "svcmi_tune_get": (c_int, [c_char_p, POINTER(c_int32)]),
     "svcmi_wn_gate_f32": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "svcmi_wn_update_f32": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "svcmi_coupling_pre_f32": (c_int, [_P, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P]),

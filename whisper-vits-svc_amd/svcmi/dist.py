@@ -156,22 +156,28 @@ def unpack_arena(skel, arena, arena16=None):
 
 def gemm_operands(min_elements=1 << 20):
     """``fp16_filter`` for ``broadcast_packed`` -- called with (attribute / dict key of the tensor, tensor): the large 2-D GEMM
-    operands, which the packed weight objects name ``*_w`` (Whisper's QKV / out / MLP matrices and its conv stem are 0.3-6.6 M elements
-    each, 99.6 % of its 1.91 GB).  LayerNorm gains, biases and the positional table -- added to fp32 activations -- stay fp32."""
+    operands, which the packed weight objects name ``*_w`` with at least ``min_elements`` elements (default 2^20: Whisper's QKV / out / MLP
+    matrices, 1.6-6.6 M elements each = 99.6 % of its 1.91 GB; the conv stem's 0.3 M-element first operand stays fp32).  LayerNorm gains, biases and the positional table -- added to fp32 activations -- stay fp32."""
     return lambda name, t: name.endswith("_w") and t.dim() == 2 and t.numel() >= min_elements
 
 
 def broadcast_packed(weights, src=0, device="cpu", group=None, fp16_filter=None):
     """ONE collective for a whole model: rank ``src`` passes its packed weight object, the others ``None``; everybody gets
     back an equivalent object whose tensors are views of one flat arena on ``device`` (a single large RCCL broadcast over
-    xGMI; the small skeleton travels as a pickled object).  World size 1: the object is returned unchanged.
+    xGMI; the small skeleton travels as a pickled object).  World size 1: the object is returned unchanged (with ``fp16_filter``: re-packed
+    locally with the same rounding, so results do not depend on the world size).
 
     ``fp16_filter`` (e.g. ``gemm_operands()``; must be passed on every rank): the selected tensors travel as fp16 in a second
     message -- Whisper large-v2 0.96 GB instead of 1.91 GB ("~1.0 GB with fp16 Whisper"), for a model that is RUN in
     an f16 mode (BASELINE.json configs[4]): every rank, ``src`` included, then holds the fp16-rounded values of those operands, so all
     ranks compute identical results and the f16 kernels see exactly the operands they would have rounded themselves."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return weights
+        if fp16_filter is None or weights is None:
+            return weights
+        # the same values at every world size: a single rank also holds the fp16-rounded operands it would have received over the wire
+        # (launches that stay on the fp32 kernel -- below lp_min_flops -- then compute with the same operands as in a multi-rank job)
+        skel, arena, arena16 = pack_arena(weights, device, fp16_filter)
+        return unpack_arena(skel, arena, arena16)
     rank = dist.get_rank(group)
     arena16 = None
     if rank == src:

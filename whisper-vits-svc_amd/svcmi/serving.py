@@ -81,14 +81,19 @@ class ClipLanes:
     def capture(self):
         """Warm up and capture every lane on its own stream (call after the first inputs are staged: the warm-up runs on them)."""
         if self.lanes is None:
-            lib = self.model.ops.lib
-            if self.ring2 and lib.svcmi_tune_set(b"ring2", self.ring2) != 0:
-                raise ValueError(f"ring2 mask {self.ring2}")
-            try:
-                self.lanes = GraphLanes(self._fns)         # the kernels chosen during capture are what every replay runs
-            finally:
-                if self.ring2:
-                    lib.svcmi_tune_set(b"ring2", getattr(self.model.ops, "tune", {}).get("ring2", 0))
+            import ctypes
+            ops = self.model.ops
+            lib = ops.lib
+            with ops._lock:                                # the knob is process-wide: no other thread of this Ops captures or launches meanwhile
+                prev = ctypes.c_int32(0)
+                if lib.svcmi_tune_get(b"ring2", ctypes.byref(prev)) != 0:
+                    raise ValueError("svcmi_tune_get(ring2)")
+                if self.ring2 != prev.value and lib.svcmi_tune_set(b"ring2", self.ring2) != 0:
+                    raise ValueError(f"ring2 mask {self.ring2}")
+                try:
+                    self.lanes = GraphLanes(self._fns)         # the kernels chosen during capture are what every replay runs
+                finally:
+                    lib.svcmi_tune_set(b"ring2", prev.value)   # what the host had set (svcmi_tune_set / SVCMI_TUNE), not a default
         return self
 
     def launch(self, lane=None):
