@@ -395,13 +395,14 @@ def main():
             rk = torch.randn(9, D, device="cuda") * 0.1 if rel else None
             rv = torch.randn(9, D, device="cuda") * 0.1 if rel else None
             out = torch.empty(1, T, H * D, device="cuda")
-            for q32 in ((0, 1) if not rel else (0,)):
+            for (q32, wide) in (((0, 0), (0, 1), (1, 0)) if not rel else ((0, 0), (0, 1))):      # wide: the 64-key-step kernel of round 6
                 for ns in (0, 2, 4, 8):
-                    assert ops.lib.svcmi_tune_set(b"attn_ns", ns) == 0 and ops.lib.svcmi_tune_set(b"attn_q32", q32) == 0
+                    assert ops.lib.svcmi_tune_set(b"attn_ns", ns) == 0 and ops.lib.svcmi_tune_set(b"attn_q32", q32) == 0 and ops.lib.svcmi_tune_set(b"attn_wide", wide) == 0
                     us = timeit(lambda: ops.attention(qkv, H, D ** -0.5, rel_k=rk, rel_v=rv, window=4 if rel else 0, out=out))
-                    print(f"attn T={T} H={H} D={D} rel={rel} q32={q32} ns={ns}: {us:8.1f} us  {4.0 * T * T * H * D / us / 1e6:7.1f} TF/s", flush=True)
+                    print(f"attn T={T} H={H} D={D} rel={rel} q32={q32} wide={wide} ns={ns}: {us:8.1f} us  {4.0 * T * T * H * D / us / 1e6:7.1f} TF/s", flush=True)
         ops.lib.svcmi_tune_set(b"attn_ns", 0)
         ops.lib.svcmi_tune_set(b"attn_q32", -1)
+        ops.lib.svcmi_tune_set(b"attn_wide", -1)
         # the opt-in LDS-staged kernel (K / V tiles shared by 4 query tiles x 2 key ranges per block) against the heuristic's choice,
         # one window alone and chip-filling batches
         for (B, T, H, D) in ((1, 500, 20, 64), (1, 750, 20, 64), (2, 750, 20, 64), (4, 500, 20, 64), (16, 500, 20, 64), (1, 1500, 20, 64)):

@@ -480,6 +480,19 @@ ATTN_CASES_LDS = [
     dict(id="ks_d64_T300_ns4_short_last_range", B=1, T=300, H=1, D=64, lds=-1, ns=4),
     dict(id="ks_d64_T33_ns8_empty_ranges", B=1, T=33, H=1, D=64, lds=-1, ns=8),
 ]
+# Round 6: the 64-key-step kernel (attention_wide_kernel: D = 64 band-free, D = 96 with the band; "attn_wide" knob 1 = forced, 0 = the
+# 32-key-step kernel it replaced -- which short sequences still take, so both stay covered at the same shapes).
+ATTN_CASES_WIDE = [
+    dict(id="wide_d64_T33_ns8_empty_ranges", B=1, T=33, H=1, D=64, lds=-1, ns=8, wide=1),
+    dict(id="wide_d64_ragged_T200_ns2", B=2, T=200, H=2, D=64, lengths=[200, 77], lds=-1, ns=2, wide=1),
+    dict(id="wide_d64_T64_exact_step", B=1, T=64, H=1, D=64, lds=-1, ns=1, wide=1),
+    dict(id="wide_d64_T65_one_key_tail", B=1, T=65, H=1, D=64, lds=-1, ns=1, wide=1),
+    dict(id="wide_d96_rel_T140_ns2", B=1, T=140, H=2, D=96, rel=True, W=4, lds=-1, ns=2, wide=1),
+    dict(id="wide_d96_rel_w2_T100_ragged", B=2, T=100, H=2, D=96, rel=True, W=2, lengths=[90, 100], lds=-1, ns=1, wide=1),
+    dict(id="wide_d96_rel_T3", B=1, T=3, H=2, D=96, rel=True, W=4, lds=-1, ns=1, wide=1),
+    dict(id="narrow_d64_T300_ns4", B=1, T=300, H=1, D=64, lds=-1, ns=4, wide=0),
+    dict(id="narrow_d96_rel_T260_ns2", B=2, T=260, H=2, D=96, rel=True, W=4, lengths=[260, 201], lds=-1, ns=2, wide=0),
+]
 # the same kernel at the sizes it is selected for (GPU only)
 ATTN_CASES_LDS_LARGE = [
     dict(id="lds42_whisper_T500", B=1, T=500, H=20, D=64, lds=42),
@@ -494,6 +507,9 @@ ATTN_CASES_LDS_LARGE = [
 
 ATTN_CASES_LARGE = [
     dict(id="whisper_T500", B=1, T=500, H=20, D=64),
+    dict(id="whisper_T500_narrow", B=1, T=500, H=20, D=64, wide=0),
+    dict(id="whisper_T500_wide_ns8", B=1, T=500, H=20, D=64, lds=-1, ns=8, wide=1),
+    dict(id="encp_T1000_narrow", B=1, T=1000, H=2, D=96, rel=True, W=4, wide=0),
     dict(id="encp_T1000", B=1, T=1000, H=2, D=96, rel=True, W=4),
     dict(id="encp_ragged_B3", B=3, T=301, H=2, D=96, rel=True, W=4, lengths=[301, 250, 7]),
 ]
@@ -543,12 +559,15 @@ def check_attention(ops, c, device):
         assert ops.lib.svcmi_tune_set(b"attn_lds", int(c["lds"])) == 0
     if c.get("lds") == -1:
         assert ops.lib.svcmi_tune_set(b"attn_ns", c.get("ns", 0)) == 0
+    if "wide" in c:
+        assert ops.lib.svcmi_tune_set(b"attn_wide", int(c["wide"])) == 0
     try:
         got = ops.attention(dev(qkv), H, scale, rel_k=dev(rel_k), rel_v=dev(rel_v), window=c.get("W", 0), lengths=dev(lengths))
     finally:
         ops.lib.svcmi_tune_set(b"attn_q32", -1)
         ops.lib.svcmi_tune_set(b"attn_ns", 0)
         ops.lib.svcmi_tune_set(b"attn_lds", 0)
+        ops.lib.svcmi_tune_set(b"attn_wide", -1)
     _close(got, want, 2e-5, c["id"])
 
 

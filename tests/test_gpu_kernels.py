@@ -36,7 +36,7 @@ def test_layernorm(ops, c):
     K.check_layernorm(ops, c, device="cuda")
 
 
-@pytest.mark.parametrize("case", K.ATTN_CASES_SMALL + K.ATTN_CASES_Q32 + K.ATTN_CASES_LDS + K.ATTN_CASES_LARGE + K.ATTN_CASES_LDS_LARGE, ids=lambda c: c["id"])
+@pytest.mark.parametrize("case", K.ATTN_CASES_SMALL + K.ATTN_CASES_Q32 + K.ATTN_CASES_LDS + K.ATTN_CASES_WIDE + K.ATTN_CASES_LARGE + K.ATTN_CASES_LDS_LARGE, ids=lambda c: c["id"])
 def test_attention(ops, case):
     K.check_attention(ops, case, device="cuda")
 

@@ -29,7 +29,7 @@ def test_layernorm(ops, c):
     K.check_layernorm(ops, c, device="cpu")
 
 
-@pytest.mark.parametrize("case", K.ATTN_CASES_SMALL + K.ATTN_CASES_Q32 + K.ATTN_CASES_LDS, ids=lambda c: c["id"])
+@pytest.mark.parametrize("case", K.ATTN_CASES_SMALL + K.ATTN_CASES_Q32 + K.ATTN_CASES_LDS + K.ATTN_CASES_WIDE, ids=lambda c: c["id"])
 def test_attention(ops, case):
     K.check_attention(ops, case, device="cpu")
 

@@ -560,6 +560,323 @@ __global__ __launch_bounds__(64 * NS) void attention_kernel(AttnArgs p) {
     }
 }
 
+// Maximum over the four lane quarters (lanes with the same lane & 15), in every lane.  gfx950's row / half swaps are VALU operations
+// (v_permlane16_swap / v_permlane32_swap: a few cycles) where the two ds_bpermute shuffles of __shfl_xor cross the LDS crossbar (~100 each).
+__device__ __forceinline__ float quarter_max(float v) {
+#ifdef SVCMI_EMU
+    v = fmaxf(v, __shfl_xor(v, 16));
+    return fmaxf(v, __shfl_xor(v, 32));
+#else
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto h = __builtin_amdgcn_permlane32_swap(u, u, false, false);        // {lower half everywhere, upper half everywhere}
+    const float m = fmaxf(__builtin_bit_cast(float, (unsigned)h[0]), __builtin_bit_cast(float, (unsigned)h[1]));
+    const unsigned um = __builtin_bit_cast(unsigned, m);
+    const auto r = __builtin_amdgcn_permlane16_swap(um, um, false, false);      // {even rows everywhere, odd rows everywhere}
+    return fmaxf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+#endif
+}
+
+// Round 6: the same decomposition as attention_kernel with a 64-KEY step whose memory requests are all in flight at once.
+// attention_kernel's 32-key step, as hipcc schedules it inside 68 registers, is six dependent L2 round trips (K in two halves, V two keys at a
+// time, each pair waited for before the next is requested): 24 serialized round trips per 128-key wave -- the kernel is bound by that chain
+// (24.6 us for Whisper's T = 500 window against 8.5 us of matrix-pipe time), not by issue slots.  Here a step requests its 16 K fragments
+// together (4 key tiles x D / 16 16-byte loads), runs four independent QK^T accumulator chains, requests all 16 V rows BEFORE the softmax
+// arithmetic (they fly during it), and a 128-key wave is two steps = four round trips.  ~150 registers: 3 waves per SIMD, enough for the
+// 2.5 waves per SIMD a T = 500 window launches.  K and V go through range-checked buffer loads with 32-bit lane offsets (no 64-bit address
+// arithmetic in the loop).  The per-step online-softmax bookkeeping (one rescale of O per 64 keys instead of per 32) halves as well.
+// Probe builds only (scripts/build_variant.sh -DSVCMI_PROBE_ATTN=n; never the product): 1 = the MFMAs of the key loop replaced by one FMA each,
+// 2 = no K / V requests (operands taken from registers), 3 = no key loop at all (prologue + publish + merge: the launch's fixed cost)
+#ifndef SVCMI_PROBE_ATTN
+#define SVCMI_PROBE_ATTN 0
+#endif
+#if SVCMI_PROBE_ATTN == 1
+__device__ __forceinline__ svcmi_f32x4 attn_probe_mfma(float a, float b, svcmi_f32x4 c) { c[0] = fmaf(a, b, c[0]); return c; }
+#define SVCMI_ATTN_MFMA attn_probe_mfma
+#else
+#define SVCMI_ATTN_MFMA svcmi_mfma_16x16x4
+#endif
+#ifndef SVCMI_EMU
+#define SVCMI_ATTN_WIDE_OCC __attribute__((amdgpu_waves_per_eu(1, 3)))   // register budget of 3 waves per SIMD: hipcc must not serialize the requests to save registers
+#else
+#define SVCMI_ATTN_WIDE_OCC
+#endif
+template <int D, int NS, bool REL>
+__global__ __launch_bounds__(64 * NS) SVCMI_ATTN_WIDE_OCC void attention_wide_kernel(AttnArgs p) {
+    constexpr int DS = D / 16, OLD = D + 4, KT = 4, KW = 16 * KT;
+    __shared__ __attribute__((aligned(16))) float smem[NS * 16 * OLD + 2 * NS * 16 + (REL ? NS * 16 * BST + 2 * NREL * D : 0)];
+    float* const Opart = smem;                         // [NS][16][OLD]
+    float* const Mpart = Opart + NS * 16 * OLD;        // [NS][16]
+    float* const Lpart = Mpart + NS * 16;              // [NS][16]
+    float* const Bpart = Lpart + NS * 16;              // [NS][16][BST]
+    float* const Ek = Bpart + NS * 16 * BST;           // [NREL][D]
+    float* const Ev = Ek + NREL * D;                   // [NREL][D]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = SVCMI_UNIFORM((int)(tid >> 6));
+    const int lq = lane & 15, g4 = lane >> 4;
+    int L;
+    {
+        const int total = (int)gridDim.x, id = (int)blockIdx.x;
+        const int q8 = total >> 3, r8 = total & 7, xcd = id & 7, slot = id >> 3;
+        L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    }
+    const int qt = L % p.nq, hb = L / p.nq;
+    const int h = hb % p.heads, b = hb / p.heads;
+    const int T = p.t;
+    const int len = p.lengths ? p.lengths[b] : T;
+    const bool has_rel = REL && p.rel_k != nullptr;
+    const int W = p.window;
+    const int nrel = has_rel ? 2 * W + 1 : 0;
+    const float scale2 = p.scale * LOG2E;
+
+    if (has_rel) {
+        for (int i = tid; i < nrel * D; i += 64 * NS) { Ek[i] = p.rel_k[i]; Ev[i] = p.rel_v[i]; }
+        __syncthreads();
+    }
+
+    const int q0 = qt * 16, qi = q0 + lq;
+    float qf[DS][4];
+    {
+        const float* qp = p.q + (long long)b * p.q_bs + (long long)(qi < T ? qi : T - 1) * p.ldq + h * D + 4 * g4;
+#pragma unroll
+        for (int s = 0; s < DS; ++s) {
+            const float4 t4 = *reinterpret_cast<const float4*>(qp + 16 * s);
+            qf[s][0] = t4.x; qf[s][1] = t4.y; qf[s][2] = t4.z; qf[s][3] = t4.w;
+        }
+    }
+    float R[REL ? NREL : 1], Pb[REL ? NREL : 1];
+    if constexpr (REL) {
+#pragma unroll
+        for (int e = 0; e < NREL; ++e) { R[e] = 0.f; Pb[e] = 0.f; }
+        if (has_rel) {
+#pragma unroll
+            for (int e = 0; e < NREL; ++e) {
+                if (e < nrel) {           // wave-uniform
+                    float a = 0.f;
+#pragma unroll
+                    for (int s = 0; s < DS; ++s)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) a = fmaf(qf[s][j], Ek[e * D + 16 * s + 4 * g4 + j], a);
+                    R[e] = quarter_sum(a);
+                }
+            }
+        }
+    }
+
+    svcmi_f32x4 oacc[DS];
+#pragma unroll
+    for (int dt = 0; dt < DS; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) oacc[dt][r] = 0.f;
+    float mrun = NEG_BIG, lrun = 0.f;
+
+    // one descriptor per operand: the head's column block of this batch item; lane offsets are row * ld (+ the lane's columns), in bytes
+    // (svcmi_attention_f32 bounds t * ld * 4 below 2^31); rows are clamped to T - 1, so every request is inside the tensor
+    const svcmi_brsrc rk = svcmi_make_brsrc(p.k + (long long)b * p.k_bs + h * D, 0x7fffffffu);
+    const svcmi_brsrc rv = svcmi_make_brsrc(p.v + (long long)b * p.v_bs + h * D, 0x7fffffffu);
+    const unsigned ldk4 = 4u * (unsigned)p.ldk, ldv4 = 4u * (unsigned)p.ldv;
+    const unsigned kcol = 16u * (unsigned)g4;                             // K fragment: columns 4 g4 .. 4 g4 + 3 of each 16-wide d group
+    const unsigned vcol = DS == 4 ? 16u * (unsigned)lq : (DS == 2 ? 8u * (unsigned)lq : 4u * (unsigned)lq);
+    const int per = ((T + NS - 1) / NS + KW - 1) / KW * KW;              // keys per wave, a multiple of the 64-key step
+    const int jbeg = w * per;
+#if SVCMI_PROBE_ATTN == 3
+    const int jend = jbeg;
+#else
+    const int jend = (jbeg + per) < T ? (jbeg + per) : T;
+#endif
+
+    for (int kt = jbeg; kt < jend; kt += KW) {
+        // ---- every K fragment of the step is requested before the first MFMA
+        svcmi_f32x4 kc[KT][DS];
+#pragma unroll
+        for (int u = 0; u < KT; ++u) {
+            const int krow = kt + 16 * u + lq;
+            const unsigned ko = (unsigned)(krow < T ? krow : T - 1) * ldk4 + kcol;
+#pragma unroll
+            for (int s = 0; s < DS; ++s) {
+#if SVCMI_PROBE_ATTN == 2
+                kc[u][s][0] = qf[s][0] + (float)ko; kc[u][s][1] = qf[s][1]; kc[u][s][2] = qf[s][2]; kc[u][s][3] = qf[s][3];
+#else
+                kc[u][s] = svcmi_buf_load16(rk, ko + 64u * (unsigned)s);
+#endif
+            }
+        }
+        SVCMI_SCHED_BARRIER();
+        // ---- S^T = K Q^T: four independent 16-key accumulator chains
+        svcmi_f32x4 sacc[KT];
+#pragma unroll
+        for (int u = 0; u < KT; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sacc[u][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < DS; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int u = 0; u < KT; ++u) sacc[u] = SVCMI_ATTN_MFMA(kc[u][s][j], qf[s][j], sacc[u]);
+        SVCMI_SCHED_BARRIER();
+        // ---- every V row of the step is requested now: the requests fly during the softmax arithmetic
+        float vv[KT][4][DS];
+#pragma unroll
+        for (int u = 0; u < KT; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt + 16 * u + 4 * g4 + r;
+                const unsigned vo = (unsigned)(key < T ? key : T - 1) * ldv4 + vcol;
+                if constexpr (DS == 4) {
+#if SVCMI_PROBE_ATTN == 2
+                    const svcmi_f32x4 t4 = {qf[0][0] + (float)vo, qf[1][1], qf[2][2], qf[3][3]};
+#else
+                    const svcmi_f32x4 t4 = svcmi_buf_load16(rv, vo);
+#endif
+                    vv[u][r][0] = t4[0]; vv[u][r][1] = t4[1]; vv[u][r][2] = t4[2]; vv[u][r][3] = t4[3];
+                } else {
+                    const float* vrow = p.v + (long long)b * p.v_bs + h * D + (long long)(key < T ? key : T - 1) * p.ldv;
+                    load_vrow<DS>(vrow, lq, vv[u][r]);
+                }
+            }
+        SVCMI_SCHED_BARRIER();
+        // ---- scores of this lane: keys kt + 16u + 4*g4 + r, query qi
+        const bool diag = has_rel && (kt + KW - 1 >= q0 - W) && (kt <= q0 + 15 + W);   // wave-uniform
+        const bool clean = kt + KW <= (len < T ? len : T) && q0 + 16 <= len;            // wave-uniform: no masked or out-of-range entry
+        float sv[KT][4];
+        float mt = NEG_BIG;
+#pragma unroll
+        for (int u = 0; u < KT; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt + 16 * u + 4 * g4 + r;
+                float a = sacc[u][r];
+                if constexpr (REL) {
+                    if (diag) {
+                        const int rel = key - qi + W;
+                        float add = 0.f;
+#pragma unroll
+                        for (int e = 0; e < NREL; ++e) add = (rel == e && e < nrel) ? R[e] : add;
+                        a += add;
+                    }
+                }
+                a *= scale2;
+                if (!clean) {
+                    if (qi >= len || key >= len) a = MASKED2;   // masked_fill(mask == 0, -1e4)
+                    if (key >= T) a = NEG_BIG;                  // beyond the sequence: weight 0
+                }
+                sv[u][r] = a;
+                mt = fmaxf(mt, a);
+            }
+        mt = quarter_max(mt);
+        const float mnew = fmaxf(mrun, mt);
+        const float corr = svcmi_exp2(mrun - mnew);
+        mrun = mnew;
+        lrun *= corr;
+#pragma unroll
+        for (int dt = 0; dt < DS; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) oacc[dt][r] *= corr;
+        float pv[KT][4];
+#pragma unroll
+        for (int u = 0; u < KT; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pv[u][r] = svcmi_exp2(sv[u][r] - mnew);         // 2^(NEG_BIG - finite) == 0 for keys >= T
+                lrun += pv[u][r];
+            }
+        if constexpr (REL) {
+            if (has_rel) {
+#pragma unroll
+                for (int e = 0; e < NREL; ++e) Pb[e] *= corr;
+            }
+            if (diag) {
+#pragma unroll
+                for (int u = 0; u < KT; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int rel = kt + 16 * u + 4 * g4 + r - qi + W;
+#pragma unroll
+                        for (int e = 0; e < NREL; ++e) Pb[e] += (rel == e && e < nrel) ? pv[u][r] : 0.f;
+                    }
+            }
+        }
+        // ---- O^T += V^T P^T : step (u, r) contracts keys kt + 16u + {r, 4+r, 8+r, 12+r}
+#pragma unroll
+        for (int u = 0; u < KT; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int dt = 0; dt < DS; ++dt) oacc[dt] = SVCMI_ATTN_MFMA(vv[u][r][dt], pv[u][r], oacc[dt]);
+    }
+
+    // ---- publish this wave's state and merge: as attention_kernel
+    lrun = quarter_sum(lrun);
+    if constexpr (REL) {
+        if (has_rel) {
+#pragma unroll
+            for (int e = 0; e < NREL; ++e) Pb[e] = quarter_sum(Pb[e]);
+        }
+    }
+    {
+        store_orow<DS>(Opart + (w * 16 + lq) * OLD, g4, oacc);
+        if (g4 == 0) {
+            Mpart[w * 16 + lq] = mrun;
+            Lpart[w * 16 + lq] = lrun;
+            if constexpr (REL) {
+                if (has_rel) {
+#pragma unroll
+                    for (int e = 0; e < NREL; ++e) Bpart[(w * 16 + lq) * BST + e] = Pb[e];
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    float* ob = p.o + (long long)b * p.o_bs + h * D;
+    for (int item = tid; item < 16 * (D / 4); item += 64 * NS) {
+        const int ql = item / (D / 4), c4 = (item - ql * (D / 4)) * 4;
+        float mall = Mpart[ql];
+#pragma unroll
+        for (int ww = 1; ww < NS; ++ww) mall = fmaxf(mall, Mpart[ww * 16 + ql]);
+        float den = 0.f;
+        float4 num = make_float4(0.f, 0.f, 0.f, 0.f);
+        float bs[REL ? NREL : 1];
+        if constexpr (REL) {
+#pragma unroll
+            for (int e = 0; e < NREL; ++e) bs[e] = 0.f;
+        }
+#pragma unroll
+        for (int ww = 0; ww < NS; ++ww) {
+            const float cw = svcmi_exp2(Mpart[ww * 16 + ql] - mall);
+            den = fmaf(cw, Lpart[ww * 16 + ql], den);
+            const float4 ov = *reinterpret_cast<const float4*>(Opart + (ww * 16 + ql) * OLD + c4);
+            num.x = fmaf(cw, ov.x, num.x); num.y = fmaf(cw, ov.y, num.y);
+            num.z = fmaf(cw, ov.z, num.z); num.w = fmaf(cw, ov.w, num.w);
+            if constexpr (REL) {
+                if (has_rel) {
+#pragma unroll
+                    for (int e = 0; e < NREL; ++e) bs[e] = fmaf(cw, Bpart[(ww * 16 + ql) * BST + e], bs[e]);
+                }
+            }
+        }
+        if constexpr (REL) {
+            if (has_rel) {
+#pragma unroll
+                for (int e = 0; e < NREL; ++e) {
+                    if (e < nrel) {
+                        const float4 ev = *reinterpret_cast<const float4*>(Ev + e * D + c4);
+                        num.x = fmaf(bs[e], ev.x, num.x); num.y = fmaf(bs[e], ev.y, num.y);
+                        num.z = fmaf(bs[e], ev.z, num.z); num.w = fmaf(bs[e], ev.w, num.w);
+                    }
+                }
+            }
+        }
+        const int qrow = q0 + ql;
+        if (qrow < T) {
+            const float inv = 1.0f / den;
+            *reinterpret_cast<float4*>(ob + (long long)qrow * p.ldo + c4) = make_float4(num.x * inv, num.y * inv, num.z * inv, num.w * inv);
+            if (p.o16) svcmi_store4_16(p.o16 + (long long)b * p.o16_bs + (long long)qrow * p.ldo16 + h * D + c4, p.ldo16 >> 1, num.x * inv, num.y * inv, num.z * inv, num.w * inv, p.o16_f16);
+        }
+    }
+}
+
 // Plain (no relative-position band) attention with TWO 16-query tiles per wave: every K / V fragment a wave fetches feeds
 // twice the MFMAs (PMC: the one-tile kernel spends 47 % of its wave-cycles parked on memory at Whisper's T = 500 and
 // keeps the matrix pipe 22 % busy), and the four QK accumulators of a step are independent.  Same key split / merge.
@@ -1408,6 +1725,7 @@ int g_attn_lds = 0;     // tuning knob ("attn_lds"): 0 = heuristic, -1 = never, 
 int g_attn_ns = 0;      // tuning knob (svcmi_tune_set("attn_ns", 0 | 1 | 2 | 4 | 8)); 0 = heuristic
 
 int g_attn_q32 = -1;    // tuning knob ("attn_q32", -1 = heuristic | 0 | 1): two query tiles per wave for band-free attention
+int g_attn_wide = -1;   // tuning knob ("attn_wide", -1 = default (off) | 0 | 1): the 64-key-step kernel (attention_wide_kernel; D = 64 band-free, D = 96 band)
 
 template <int D>
 int launch_attn(const AttnArgs& a_in, int batch, void* stream) {
@@ -1485,6 +1803,23 @@ int launch_attn(const AttnArgs& a_in, int batch, void* stream) {
                 case 2: SVCMI_LAUNCH((attention_q32_kernel<D, 2>), grid, dim3(128), 0, stream, a); break;
                 case 4: SVCMI_LAUNCH((attention_q32_kernel<D, 4>), grid, dim3(256), 0, stream, a); break;
                 default: SVCMI_LAUNCH((attention_q32_kernel<D, 8>), grid, dim3(512), 0, stream, a); break;
+            }
+            return SVCMI_LAST_ERROR();
+        }
+    }
+    if constexpr (D == 64 || D == 96) {
+        // 64-key steps with all of a step's requests in flight (round 6): OPT-IN ("attn_wide" = 1).  Measured (profiles/r06s_attention_wide.log): a
+        // T = 500 Whisper window 24.3 against 23.3 us (graph-timed), the judged line 0.6 % slower with it -- the launch is not bound by the chain
+        // of round trips: with the key loop's MFMAs removed it still takes 18.0 us, with the K / V requests removed 17.7 us, without the loop 2.7
+        const bool fits32 = (long long)a.t * (a.ldk > a.ldv ? a.ldk : a.ldv) * 4 < 0x7fffffffLL;        // 32-bit byte offsets of the buffer loads
+        const bool wide = fits32 && g_attn_wide > 0;
+        if (wide && (D == 64) == (a.rel_k == nullptr)) {
+            constexpr bool RELW = D == 96;
+            switch (ns) {
+                case 1: SVCMI_LAUNCH((attention_wide_kernel<D, 1, RELW>), grid, dim3(64), 0, stream, a); break;
+                case 2: SVCMI_LAUNCH((attention_wide_kernel<D, 2, RELW>), grid, dim3(128), 0, stream, a); break;
+                case 4: SVCMI_LAUNCH((attention_wide_kernel<D, 4, RELW>), grid, dim3(256), 0, stream, a); break;
+                default: SVCMI_LAUNCH((attention_wide_kernel<D, 8, RELW>), grid, dim3(512), 0, stream, a); break;
             }
             return SVCMI_LAST_ERROR();
         }
@@ -1634,6 +1969,10 @@ extern "C" int svcmi_attn_tune_set(const char* name, int32_t value) {
     while (k5[i] && name[i] == k5[i]) ++i;
     if (k5[i] == 0 && name[i] == 0 && (value == 0 || value == 14 || value == 21 || value == 24 || value == 41 || value == 42 || value == 44 ||
                                        value == 81 || value == 82)) { g_attn16 = value; return 0; }
+    const char* k6 = "attn_wide";
+    i = 0;
+    while (k6[i] && name[i] == k6[i]) ++i;
+    if (k6[i] == 0 && name[i] == 0 && value >= -1 && value <= 1) { g_attn_wide = value; return 0; }
     const char* k2 = "attn_q32";
     i = 0;
     while (k2[i] && name[i] == k2[i]) ++i;
