@@ -417,6 +417,30 @@ def check_whisper_stress(ops, device, dims, n, tol=TIGHT):
     return dict(err=err, out_max=scale)
 
 
+def check_whisper_batched_rows_flattened(ops, device, dims, B=3, n=90, small_m_rows=48, tol=TIGHT):
+    """Batched windows above ``small_m_rows`` GEMM rows: the four k = 1 projections of a block see ONE matrix of B * tw rows (M tiles span
+    batch items, host_stages.hip: whisper_fwd).  Every item equals its solo run on the library's own tiles (bit for bit) and the oracle."""
+    from svcmi.whisper.inference import load_model
+    ck = W.make_whisper_state(dims)
+    wm = load_model(ck, device, ops=ops)
+    wm.encoder.small_m_rows = small_m_rows
+    g = torch.Generator().manual_seed(n + B)
+    mel = (torch.randn(B, 80, n, generator=g) * 0.5).clamp(-1, 1.5)
+    nz = torch.randn(B, 80, n, generator=g)
+    tw = (n - 1) // 2 + 1
+    assert B * tw > small_m_rows >= tw, "batched rows above the threshold, one item below it"
+    out = wm.encoder(mel, nz, 0.1)
+    wm.encoder.small_m_rows = 1                 # solo runs on the same (library-chosen) tiles: a lone item is never flattened (B = 1)
+    for i in range(B):
+        solo = wm.encoder(mel[i:i + 1], nz[i:i + 1], 0.1)
+        assert torch.equal(out[i:i + 1], solo), f"item {i}: max diff {float((out[i:i + 1] - solo).abs().max()):.3e}"
+    with torch.no_grad():
+        ref = O.audio_encoder(ck["model_state_dict"], mel + 0.1 * nz, dims["n_audio_head"], O.whisper_kept_layers(dims))
+    err = maxerr(out, ref)
+    assert err <= tol * max(1.0, float(ref.abs().max())), err
+    return err
+
+
 def stress_floor(sd, hp, d, lens, o_src, o_wav, wav):
     """Noise floor of an outlier-stress run: the oracle in fp64 vs itself in fp32, and the engine vs the fp64 result.  The
     stress sets are tuned to stay well-conditioned (asserted: the fp32 oracle stays within 3e-4 of fp64 -- with LayerNorm
@@ -532,15 +556,26 @@ def check_hubert_windows_batched(ops, device, dims, seconds=45.0):
     return err
 
 
-def check_clip_lanes(ops, device, lanes=3, requests=7, T=300, layers=4):
+def check_clip_lanes(ops, device, lanes=3, requests=7, T=300, layers=4, precision=None, capture_first=False):
     """svcmi.serving.ClipLanes: ``requests`` different clips (own inputs, pinned noise, one of them ragged) submitted through ``lanes`` lanes,
-    collected in order, each against the same conversion run eagerly on the current stream -- bit-identical."""
+    collected in order, each against the same conversion run eagerly on the current stream -- bit-identical.
+    ``precision`` + ``capture_first``: the graph capture is the FIRST thing that runs the models in a reduced-precision mode, i.e. the
+    lazily built 16-bit weight images are packed inside ClipLanes.capture (round 6: that deadlocked on a non-reentrant Ops lock)."""
     from svcmi.serving import ClipLanes, convert_step
     from svcmi.whisper.inference import load_model
     hp = C.base_hp()
     m, _ = make_model(hp, ops, device)
     wm = load_model(W.make_whisper_state(dict(C.WHISPER_LARGE_V2, n_audio_layer=layers)), device, ops=ops)
+    if precision:
+        m.precision = precision
+        wm.encoder.precision = "f16" if precision.startswith("mixed") else precision
     cl = ClipLanes(m, wm, T, B=1, lanes=lanes, device=device, pinned_noise=True)
+    if capture_first:
+        d0 = {k: v.to(device) for k, v in I.synth_clip(T=T, hp=hp, seed=69, B=1, ppg=False).items()}
+        for lane in range(lanes):
+            cl.stage(lane, noise={k: d0[k] for k in ("mel_noise", "rand_ini", "src_noise", "enc_noise")},
+                     lengths=torch.tensor([T], dtype=torch.int32), **{k: d0[k] for k in ("mel", "vec", "pit", "spk")})
+        cl.capture()
     reqs, want = [], []
     for i in range(requests):
         d = {k: v.to(device) for k, v in I.synth_clip(T=T, hp=hp, seed=70 + i, B=1, ppg=False).items()}

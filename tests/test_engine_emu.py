@@ -80,6 +80,11 @@ def test_whisper_tiny_bf16x3_split_activations(ops):
     print(E.check_whisper_golden(ops, "cpu", "whisper_tiny", C.WHISPER_TINY_TEST, tol=1e-4, precision="bf16x3"))
 
 
+def test_whisper_batched_windows_flatten_their_rows(ops):
+    """B * tw rows above small_m_rows: one M = B * tw matrix per projection, items bit-identical to their solo runs."""
+    print(E.check_whisper_batched_rows_flattened(ops, "cpu", C.WHISPER_TINY_TEST))
+
+
 def test_outlier_stress_weights_whisper_and_generator(ops):
     """parity must not rest on N(0, sigma) weights only."""
     print(E.check_whisper_stress(ops, "cpu", C.WHISPER_TINY_TEST, n=120))

@@ -239,6 +239,13 @@ def test_clip_lanes_serving_object_matches_eager_conversions(ops):
     E.check_clip_lanes(ops, "cuda")
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("precision", ["f16", "mixed"])
+def test_clip_lanes_capture_packs_the_16bit_weight_images(ops, precision):
+    """bench.py --precision f16 | bf16x3 | mixed on configs[1]: the capture is the first run of the models in that mode."""
+    E.check_clip_lanes(ops, "cuda", lanes=2, requests=3, precision=precision, capture_first=True)
+
+
 def test_svc_infer_chunks_in_flight_are_bit_identical(ops):
     E.check_chunk_streams(ops, "cuda")
 

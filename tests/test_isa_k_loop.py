@@ -57,6 +57,7 @@ def asm(tmp_path_factory):
                    "template __global__ void conv_gemm_kernel<1, 5, MODE_CHUNK, true, PREC_F32, 2>(ConvArgs);      // ... with clips in flight: 2-deep ring\n"
                    "template __global__ void conv_gemm_kernel<1, 1, MODE_CHUNK, false, PREC_F32, 0>(ConvArgs);     // QKV, prior encoder, flow\n"
                    "template __global__ void conv_gemm_kernel<2, 2, MODE_CHUNK, false, PREC_F32, 0>(ConvArgs);     // 128 x 128: chip-filling launches\n"
+                   "template __global__ void conv_gemm_kernel<1, 5, MODE_CHUNK, true, PREC_F32, 3, 8>(ConvArgs);   // round 6: the 64x80 wave tile on eight waves (128 x 80, opt-in)\n"
                    "}\n")
     out = d / "k_loop.s"
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", str(hip), "-o", str(out)] + _file_flags()
@@ -66,10 +67,11 @@ def asm(tmp_path_factory):
 
 # (kernel, MFMAs per K-step, issue slots one MFMA covers: 32 / 64 cycles at one instruction per ~4 cycles, longest tolerated run)
 CASES = [("ILi1ELi5ELi0ELb1ELi0ELi0E", 40, 7, 14), ("ILi1ELi5ELi0ELb1ELi0ELi2E", 40, 7, 14),
-         ("ILi1ELi1ELi0ELb0ELi0ELi0E", 16, 15, 24), ("ILi2ELi2ELi0ELb0ELi0ELi0E", 64, 15, 18)]
+         ("ILi1ELi1ELi0ELb0ELi0ELi0E", 16, 15, 24), ("ILi2ELi2ELi0ELb0ELi0ELi0E", 64, 15, 18),
+         ("ILi1ELi5ELi0ELb1ELi0ELi3ELi8E", 40, 7, 14)]
 
 
-@pytest.mark.parametrize("kernel,n_mfma,slots,longest", CASES, ids=["64x80", "64x80_ring2", "64x64", "128x128"])
+@pytest.mark.parametrize("kernel,n_mfma,slots,longest", CASES, ids=["64x80", "64x80_ring2", "64x64", "128x128", "128x80_eight_waves"])
 def test_k_loop_instruction_stream(asm, kernel, n_mfma, slots, longest):
     seg = _steady_loop(asm, kernel)
     seq = "".join("M" if s.startswith("v_mfma") else "x" for s in seg)

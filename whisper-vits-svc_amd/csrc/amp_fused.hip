@@ -429,8 +429,13 @@ __device__ __forceinline__ void snake_conv16_body(const AmpArgs& p, float* smem,
     if constexpr (!UT) pack_weights();
 
     // ---- S = SnakeAlias(x) as fp16 rows; the pad columns [CP, 8 CK) meet zero weights but must not hold NaN patterns
+#ifdef SVCMI_PROBE_AMP16_NOACT
+    for (int i = tid; i < TL::S_FLOATS; i += TPB) smem[i] = 0.f;      // (probe: no activation phase)
+    __syncthreads();
+#else
     if constexpr (UT) snake_tile_u<CP, CR, LSH, (((TL::ROWS + RT - 1) / RT) * CP + TPB - 1) / TPB, true>(smem, xb, p.alpha_log, p.beta_log, p.filt, n, ld, t_blk, halo, rows, tid);
     else snake_tile<CP, CR, LSH, true>(smem, xb, p.alpha_log, p.beta_log, p.filt, n, ld, t_blk, halo, rows, tid);
+#endif
     if constexpr (UT) pack_weights();
     unsigned short* S16 = reinterpret_cast<unsigned short*>(smem);
     if constexpr (CP < CK * 8)
@@ -479,7 +484,11 @@ __device__ __forceinline__ void snake_conv16_body(const AmpArgs& p, float* smem,
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
+#ifdef SVCMI_PROBE_AMP16_NOMFMA
+                for (int tt = 0; tt < NT; ++tt) acc[tt][ct][0] += __builtin_bit_cast(float, af[ct][tm][0] ^ bf[tt][1]);      // (probe: operands stay live, no matrix-core instruction)
+#else
                 for (int tt = 0; tt < NT; ++tt) acc[tt][ct] = svcmi_mfma16_16x16x32<true>(af[ct][tm], bf[tt], acc[tt][ct]);
+#endif
     }
 
     // ---- epilogue: lane = (time tq of the tile, output channels ct * 16 + 4 kq .. + 3)

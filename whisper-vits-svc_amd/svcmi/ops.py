@@ -74,7 +74,7 @@ class Ops:
         # 1.35 ms through either kernel), so rounding its operands buys nothing and costs accuracy.  At batch 16 the same
         # layers are 16x the work and cross the threshold.
         self._tls = threading.local()          # `precision` is per calling thread (worker threads of the folder driver share one Ops)
-        self._lock = threading.Lock()          # guards the lazily built per-tensor 16-bit weight images
+        self._lock = threading.RLock()         # guards the lazily built per-tensor 16-bit weight images; re-entrant: ClipLanes.capture holds it around a capture whose warm-up may build them
         self.lp_min_flops = 1.5e9
         # development knobs of the library (svcmi_tune_set: tile variants, fused / unfused paths).  Tile / split / launch-shape knobs
         # leave every result bit-identical; two select another KERNEL FORM of the narrow generator stages and change the fp32
