@@ -8,7 +8,7 @@ mkdir -p _obj/$NAME svcmi/exp
 rm -f _obj/$NAME/*.o svcmi/exp/libsvcmi_$NAME.so
 for f in csrc/*.hip; do
   EXTRA=""
-  [ "$(basename $f)" = amp_fused.hip ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form=1"      # (build.py FILE_FLAGS)
+  [ "$(basename $f)" = amp_fused.hip ] && [ -z "$SVCMI_VARIANT_AMP_ACC_FILE" ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form=1"      # (build.py FILE_FLAGS)
   [ "$(basename $f)" = conv_gemm.hip ] && [ -z "$SVCMI_VARIANT_ACC_FILE" ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form=1 -DSVCMI_ACC_IN_VGPRS=1 -DSVCMI_DMA_M0_RAW=1"      # (SVCMI_VARIANT_ACC_FILE=1: accumulator-file form, the build before the pinned K loop)
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $EXTRA "$@" -c $f -o _obj/$NAME/$(basename $f).o &
 done

@@ -70,7 +70,7 @@ def runs_of(rl):
         pv = x
     runs.append((st, pv))
     return runs
-def trial(tag, culprit, victim, inputs, reps=4, dump=0):
+def trial(tag, culprit, victim, inputs, reps=int(os.environ.get("PROBE_REPS", 4)), dump=0):
     Ag = graph(culprit); Bg = graph(victim)
     torch.cuda.synchronize()
     with torch.cuda.stream(Bg[2]):
@@ -78,13 +78,18 @@ def trial(tag, culprit, victim, inputs, reps=4, dump=0):
     Bg[2].synchronize()
     ref = [o.clone() for o in Bg[1]]
     in0 = [t.clone() for t in inputs]
-    bad, worst = 0, 0.0
+    with torch.cuda.stream(Ag[2]):
+        Ag[0].replay()
+    Ag[2].synchronize()
+    cref = [o.clone() for o in Ag[1]]
+    bad, worst, cbad = 0, 0.0, 0
     for rep in range(reps):
         for g, o, s in (Ag, Bg):
             with torch.cuda.stream(s):
                 g.replay()
         torch.cuda.synchronize()
         errs = [float((o - r).abs().max()) for o, r in zip(Bg[1], ref)]
+        cbad += any(not torch.equal(o, r) for o, r in zip(Ag[1], cref))
         e = max(errs); bad += e > 0; worst = max(worst, e)
         if dump and e > 0 and rep < 2:
             shown = 0
@@ -102,7 +107,7 @@ def trial(tag, culprit, victim, inputs, reps=4, dump=0):
                 sh = [d for d in range(-16, 17) if 0 <= t0 + d < b.shape[0] and d != 0 and torch.equal(a[t0], b[t0 + d])]
                 print(f"      row {t0}: got {a[t0, :4].tolist()} ref {b[t0, :4].tolist()}  equal to the reference of a shifted row: {sh}")
     intact = all(torch.equal(t, t0) for t, t0 in zip(inputs, in0))
-    print(f"[probe10] {tag}: victim differs in {bad}/{reps} replays, worst {worst:.3e}; inputs intact {intact}", flush=True)
+    print(f"[probe10] {tag}: victim differs in {bad}/{reps} replays, worst {worst:.3e}; inputs intact {intact}; the CULPRIT's own outputs differ from its solo run in {cbad}/{reps}", flush=True)
     del Ag, Bg, ref
 which = os.environ.get("PROBE_SET", "all")
 cf, cprob = culprit_amp(20, 20, 48000, "f16w2")

@@ -43,6 +43,8 @@ typedef float svcmi_f32x4 __attribute__((vector_size(16)));
 typedef float svcmi_f32x2 __attribute__((vector_size(8)));
 static inline svcmi_f32x2 svcmi_fma2(svcmi_f32x2 a, svcmi_f32x2 b, svcmi_f32x2 c) { return svcmi_f32x2{fmaf(a[0], b[0], c[0]), fmaf(a[1], b[1], c[1])}; }
 static inline svcmi_f32x2 svcmi_splat2(float v) { return svcmi_f32x2{v, v}; }
+static inline svcmi_f32x2 svcmi_mul2(svcmi_f32x2 a, svcmi_f32x2 b) { return svcmi_f32x2{a[0] * b[0], a[1] * b[1]}; }
+static inline float svcmi_hsum2(svcmi_f32x2 p) { return p[0] + p[1]; }
 static inline svcmi_f32x2 svcmi_splat_lo(svcmi_f32x2 p) { return svcmi_f32x2{p[0], p[0]}; }
 static inline svcmi_f32x2 svcmi_splat_hi(svcmi_f32x2 p) { return svcmi_f32x2{p[1], p[1]}; }
 static inline float svcmi_sgpr_const(float v) { return v; }

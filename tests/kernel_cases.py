@@ -1012,3 +1012,93 @@ def check_attention16(ops, c, device):
     assert torch.equal(o16.cpu(), o.cpu().to(dt)), c["id"]
     # the only rounding left is P -> 16 bits before the PV product: rel. 2^-11 (f16) / 2^-8 (bf16) per probability
     _close(o, want, 1.5e-3 if c["fmt"] == "f16" else 1.2e-2, c["id"])
+
+
+def check_kernels_in_flight_beside_fp16_half_step(ops, victim="alias", replays=8, launches=30, culprit_launches=60):
+    """Round 6: launches of one kernel (`victim`) on one stream while the fp16 fused half-step (v_mfma_f32_16x16x32_f16) runs on another must
+    give the bits they give alone.  They did not: MI355X computes packed-fp32 instructions with the src1 half-select wrongly in lanes 48..63
+    beside that matrix-core shape (tests/test_isa_packed_operand_select.py, scripts/probes/pkfma_mfma_corun.hip), which showed as SnakeAlias
+    values of one clip off by 1e-2 with two 16-bit clips in flight.  Victims: the SnakeAlias stream kernel, the fp32 fused half-steps (vector and
+    matrix-core forms), the stage entry (upsample + noise convolution) -- every kernel family that holds packed fp32 arithmetic."""
+    dev = "cuda"
+    g = _g(4242)
+    filt = W.kaiser_sinc_filter().view(-1).to(dev)
+
+    def graph(fn):
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            fn(); fn()
+        s.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=s):
+            o = fn()
+        return gr, o, s
+
+    def amp_problems(c, ld, n):
+        probs = []
+        for k, dil in ((3, 1), (11, 5), (7, 3)):
+            x = torch.zeros(1, n, ld); x[..., :c] = torch.randn(1, n, c, generator=g)
+            res = torch.zeros(1, n, ld); res[..., :c] = torch.randn(1, n, c, generator=g)
+            al, be = torch.zeros(ld), torch.zeros(ld)
+            al[:c], be[:c] = torch.randn(c, generator=g) * 0.3, torch.randn(c, generator=g) * 0.3
+            w = PW.pack_conv(torch.randn(c, c, k, generator=g) / math.sqrt(c * k), ld, ld).to(dev)
+            bias = PW.pad_vec(torch.randn(c, generator=g), ld).to(dev)
+            probs.append(dict(x=x.to(dev), alpha_log=al.to(dev), beta_log=be.to(dev), w=w, bias=bias, ksize=k, dilation=dil, res=res.to(dev), alpha=0.5))
+        return probs
+
+    cp = amp_problems(20, 20, 48000)
+    couts = [torch.empty_like(p["x"]) for p in cp]
+
+    def culprit():
+        for _ in range(culprit_launches):
+            ops.snake_conv_group([dict(p, out=o) for p, o in zip(cp, couts)], filt, c=20, precision="f16w2")
+        return couts
+
+    if victim == "alias":
+        xs = [torch.randn(1, 24000, 40, generator=g).to(dev) for _ in range(3)]
+        al = [(torch.randn(40, generator=g) * 0.3).to(dev) for _ in range(3)]
+        be = [(torch.randn(40, generator=g) * 0.3).to(dev) for _ in range(3)]
+        outs = [[torch.empty_like(x) for x in xs] for _ in range(launches)]
+
+        def vfn():
+            for r in range(launches):
+                ops.snake_alias_group(xs, al, be, filt, outs[r])
+            return [o for oo in outs for o in oo]
+    elif victim in ("amp10", "amp20", "amp20_vector"):
+        c, ld, n = (10, 12, 96000) if victim == "amp10" else (20, 20, 48000)
+        vp = amp_problems(c, ld, n)
+        outs = [[torch.empty_like(p["x"]) for p in vp] for _ in range(launches)]
+
+        def vfn():
+            for r in range(launches):
+                ops.snake_conv_group([dict(p, out=o) for p, o in zip(vp, outs[r])], filt, c=c)
+            return [o for oo in outs for o in oo]
+    else:
+        raise ValueError(victim)
+    tuned = victim == "amp20_vector"
+    if tuned:
+        assert ops.lib.svcmi_tune_set(b"amp_mfma", 0) == 0
+    try:
+        A, B = graph(culprit), graph(vfn)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(B[2]):
+            B[0].replay()
+        B[2].synchronize()
+        ref = [o.clone() for o in B[1]]
+        with torch.cuda.stream(A[2]):
+            A[0].replay()
+        A[2].synchronize()
+        cref = [o.clone() for o in A[1]]
+        for rep in range(replays):
+            for gr, _, s in (A, B):
+                with torch.cuda.stream(s):
+                    gr.replay()
+            torch.cuda.synchronize()
+            for i, (o, r) in enumerate(zip(B[1], ref)):
+                assert torch.equal(o, r), f"{victim}: replay {rep}, launch {i // 3}, problem {i % 3}: {int((o != r).sum())} values differ, max {float((o - r).abs().max()):.3e}"
+            for o, r in zip(A[1], cref):
+                assert torch.equal(o, r), f"the fp16 half-step itself differs beside {victim} (replay {rep})"
+    finally:
+        if tuned:
+            assert ops.lib.svcmi_tune_set(b"amp_mfma", 1) == 0

@@ -52,11 +52,7 @@ __global__ __launch_bounds__(TPB) void snake_alias_kernel(SnakeArgs p) {
     for (int k = 0; k < 12; ++k) f[k] = filt[k];
     // x window with replicate padding (resample.py:25-27): xw[i] = x[clamp(t0 - 5 + i)]
     SnakeWindow<RT + 10> xw;
-#ifdef SVCMI_PROBE_ALIAS_GENERIC
-    if (false) {
-#else
     if (t0 >= 5 && t0 + RT + 4 < n) {
-#endif
         // interior run (all but the first and last of a sequence): no clamps, and one 32-bit offset per lane from the wave-uniform batch
         // base, advanced by ld per row -- the general form costs a clamp + a 64-bit multiply-add + a 64-bit add per load (ISA: 90 of the
         // ~520 vector instructions of a work item were address arithmetic)

@@ -19,6 +19,19 @@ typedef float svcmi_f32x16 __attribute__((ext_vector_type(16)));
 typedef float svcmi_f32x4 __attribute__((ext_vector_type(4)));
 typedef float svcmi_f32x2 __attribute__((ext_vector_type(2)));      // packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32)
 __device__ __forceinline__ svcmi_f32x2 svcmi_fma2(svcmi_f32x2 a, svcmi_f32x2 b, svcmi_f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+// lo + hi of a pair as ONE scalar v_add_f32.  Written plainly (`p[0] + p[1]`) the compiler emits v_pk_add_f32 ... op_sel:[0,1] op_sel_hi:[1,0]
+// (both halves = the sum): a packed instruction whose LOW lane takes the HIGH half of src1 -- the form that computes lanes 48..63 wrongly on
+// MI355X while another wave of the SIMD executes v_mfma_f32_16x16x32_{f16,bf16} (round 6: scripts/probes/pkfma_mfma_corun.hip,
+// profiles/r06y_pkfma_mfma_corun.log; DESIGN.md "the packed-fp32 operand-select erratum").  The empty asm takes the high half out of the
+// pair for the optimiser; no instruction, no hazard.
+__device__ __forceinline__ float svcmi_hsum2(svcmi_f32x2 p) {
+    float hi = p[1];
+#ifndef SVCMI_EMU
+    asm("" : "+v"(hi));
+#endif
+    return p[0] + hi;
+}
+__device__ __forceinline__ svcmi_f32x2 svcmi_mul2(svcmi_f32x2 a, svcmi_f32x2 b) { return a * b; }
 __device__ __forceinline__ svcmi_f32x2 svcmi_splat2(float v) { return svcmi_f32x2{v, v}; }
 // (lo, lo) / (hi, hi) of a register pair: folds into the op_sel modifiers of the packed instruction that consumes it
 __device__ __forceinline__ svcmi_f32x2 svcmi_splat_lo(svcmi_f32x2 p) { return __builtin_shufflevector(p, p, 0, 0); }
