@@ -285,8 +285,10 @@ __device__ __forceinline__ void snake_conv_body(const AmpArgs& p, float* S) {
 #pragma unroll
             for (int c = 0; c < NCO; c += 2) {
                 if (co0 + c < CR) {                    // wave-uniform
-                    const float4 w0 = *reinterpret_cast<const float4*>(wt + (long long)c * p.ldw + 4 * c4);         // uniform addresses: scalar loads
-                    const float4 w1 = *reinterpret_cast<const float4*>(wt + (long long)(c + 1) * p.ldw + 4 * c4);
+                    // (w1 from w0's row pointer: formed independently, the second row's address was 14 more scalar adds per tap, and the tap loop is bound by
+                    // what a wave can issue -- 30 more instructions among its 180 measured +9.4 us per launch, scripts/sessions/r6_s16.sh)
+                    const float* wr = wt + (long long)c * p.ldw + 4 * c4;                                         // uniform addresses: scalar loads
+                    const float4 w0 = *reinterpret_cast<const float4*>(wr), w1 = *reinterpret_cast<const float4*>(wr + p.ldw);
 #pragma unroll
                     for (int j = 0; j < TT; ++j) {
                         acc[j][c / 2] = svcmi_fma2(svcmi_splat_lo(x01[j]), svcmi_f32x2{w0.x, w1.x}, acc[j][c / 2]);
