@@ -246,6 +246,14 @@ def test_clip_lanes_capture_packs_the_16bit_weight_images(ops, precision):
     E.check_clip_lanes(ops, "cuda", lanes=2, requests=3, precision=precision, capture_first=True)
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("precision", ["f16", "mixed", "bf16x3"])
+def test_four_lanes_in_a_reduced_precision_mode_equal_their_eager_runs(ops, precision):
+    """Round 6: with the library of round 5 every one of these differed by ~1e-2 (profiles/r06ze_lanes_soak_before.log) -- SnakeAlias / vector
+    half-step waves of one clip beside the 16x16x32 matrix-core instructions of another; fp32 was never affected."""
+    E.check_clip_lanes(ops, "cuda", lanes=4, requests=12, precision=precision)
+
+
 def test_svc_infer_chunks_in_flight_are_bit_identical(ops):
     E.check_chunk_streams(ops, "cuda")
 
