@@ -67,8 +67,27 @@ def build_hip(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    audit_packed_operand_select(verbose)
     build_example(hipcc, verbose)
     return OUT
+
+
+def audit_packed_operand_select(verbose=False):
+    """The fresh library must not hold a packed-fp32 instruction with the src1 half-select (isa_audit.py, DESIGN 4.6: MI355X computes it wrongly
+    beside the 16x16x32 16-bit matrix-core shapes; hipcc emits it from innocent source).  ~10 s; SVCMI_SKIP_ISA_AUDIT=1 skips, and so does a
+    missing llvm-objdump (the test suite then skips its copy of the check as well)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("svcmi_isa_audit", os.path.join(HERE, "isa_audit.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if os.environ.get("SVCMI_SKIP_ISA_AUDIT") or not os.path.exists(mod.OBJDUMP):
+        return
+    n_obj, n_packed, offenders = mod.audit(OUT)
+    if verbose:
+        print(f"isa audit: {n_obj} code objects, {n_packed} packed fp32 instructions, {sum(len(v) for v in offenders.values())} with the src1 half-select", flush=True)
+    if offenders:
+        raise RuntimeError("libsvcmi.so holds packed fp32 instructions with the src1 half-select (op_sel:[.,1,..]) -- rewrite the source so the "
+                           "swizzled operand is src0 (snake_math.h, svcmi_hsum2): " + mod.describe(offenders))
 
 
 def build_example(hipcc, verbose=False):
